@@ -1,0 +1,811 @@
+// extern "C" entry points of libdfhip.so (see include/dfhip.h for the contract and the
+// reference functions each one replaces) and the GP object that lives in HBM.
+#include "common.h"
+#include <math.h>
+#include <limits.h>
+#include <string.h>
+#include <algorithm>
+
+struct dfh_gp {
+  dfh_ctx* ctx = nullptr;
+  KernDev kd;
+  int64_t n = 0, d = 0, nblk = 0;
+  double noise_var = 0.0;
+  double diag_jitter = 0.0;      // what the ladder added on top of noise_var (0 if none)
+  double* Xp = nullptr;          // [n][P] packed scaled training inputs
+  double* Np = nullptr;          // [n][n_parts]
+  double* L = nullptr;           // [n][n] lower factor (strict upper part unspecified)
+  double* inv = nullptr;         // [nblk][NB][NB] inverses of the diagonal blocks of L
+  double* alpha = nullptr;       // [n]
+  bool upper_zeroed = false;
+};
+
+namespace {
+
+int64_t pick_chunk(int64_t n, int64_t m) {
+  // candidate rows per posterior chunk: keep the m_c x n cross matrix near 2 GiB
+  int64_t mc = (int64_t)(1LL << 28) / (n > 0 ? n : 1);
+  mc = std::max<int64_t>(512, std::min<int64_t>(mc, 32768));
+  mc = (mc / 512) * 512;
+  if (mc > m) mc = m;
+  return mc;
+}
+
+// numpy argmax ordering: a NaN beats everything, earlier index wins ties
+__device__ __forceinline__ bool better(double va, long ia, double vb, long ib) {
+  const bool na = va != va, nb = vb != vb;
+  if (na || nb) {
+    if (na && nb) return ia < ib;
+    return na;
+  }
+  if (va > vb) return true;
+  if (va < vb) return false;
+  return ia < ib;
+}
+
+__global__ void k_argmax_stage1(const double* __restrict__ v, long m, long idx_base,
+                                double* __restrict__ pv, long* __restrict__ pi) {
+  __shared__ double sv[256];
+  __shared__ long si[256];
+  double bv = -INFINITY;
+  long bi = LONG_MAX;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long)gridDim.x * blockDim.x) {
+    const double x = v[i];
+    if (bi == LONG_MAX || better(x, idx_base + i, bv, bi)) { bv = x; bi = idx_base + i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = sv[threadIdx.x + s]; const long oi = si[threadIdx.x + s];
+      if (oi != LONG_MAX && (si[threadIdx.x] == LONG_MAX || better(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
+        sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { pv[blockIdx.x] = sv[0]; pi[blockIdx.x] = si[0]; }
+}
+
+__global__ void k_argmax_stage2(const double* pv, const long* pi, int nparts, double* out_v, long* out_i) {
+  __shared__ double sv[256];
+  __shared__ long si[256];
+  double bv = -INFINITY; long bi = LONG_MAX;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    if (pi[i] != LONG_MAX && (bi == LONG_MAX || better(pv[i], pi[i], bv, bi))) { bv = pv[i]; bi = pi[i]; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = sv[threadIdx.x + s]; const long oi = si[threadIdx.x + s];
+      if (oi != LONG_MAX && (si[threadIdx.x] == LONG_MAX || better(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
+        sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out_v[0] = sv[0]; out_i[0] = si[0]; }
+}
+
+bool host_better(double va, int64_t ia, double vb, int64_t ib) {
+  const bool na = va != va, nb = vb != vb;
+  if (na || nb) { if (na && nb) return ia < ib; return na; }
+  if (va > vb) return true;
+  if (va < vb) return false;
+  return ia < ib;
+}
+
+// arg-max of v[0..m) (device), indices offset by idx_base; merges into host running best
+int argmax_update(dfh_ctx* ctx, const double* v, int64_t m, int64_t idx_base, bool* have,
+                  double* best_v, int64_t* best_i) {
+  if (m <= 0) return DFH_OK;
+  const int nblocks = (int)std::min<int64_t>(1024, (m + 255) / 256);
+  char* buf = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_RED, (size_t)(nblocks + 1) * 16 + 64, (void**)&buf));
+  double* pv = reinterpret_cast<double*>(buf);
+  long* pi = reinterpret_cast<long*>(buf + (size_t)(nblocks + 1) * 8);
+  hipLaunchKernelGGL(k_argmax_stage1, dim3(nblocks), dim3(256), 0, ctx->stream, v, (long)m, (long)idx_base, pv, pi);
+  DFH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_argmax_stage2, dim3(1), dim3(256), 0, ctx->stream, pv, pi, nblocks, pv + nblocks, pi + nblocks);
+  DFH_LAUNCH_CHECK();
+  double hv; long hi;
+  DFH_HIP(hipMemcpyAsync(&hv, pv + nblocks, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(&hi, pi + nblocks, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  if (!*have || host_better(hv, (int64_t)hi, *best_v, *best_i)) { *best_v = hv; *best_i = (int64_t)hi; *have = true; }
+  return DFH_OK;
+}
+
+// Phi(x): scipy.special.ndtr structure (xsf/cephes/ndtr.h) on the device erf/erfc
+__device__ __forceinline__ double ndtr_dev(double a) {
+  if (a != a) return a;
+  const double x = a * 0.70710678118654752440;   // M_SQRT1_2
+  const double z = fabs(x);
+  double y;
+  if (z < 1.0) {
+    y = 0.5 + 0.5 * erf(x);
+  } else {
+    y = 0.5 * erfc(z);
+    if (x > 0) y = 1.0 - y;
+  }
+  return y;
+}
+__device__ __forceinline__ double norm_pdf_dev(double x) {
+  return exp(-(x * x) / 2.0) / 2.5066282746310002;   // scipy _norm_pdf: exp(-x**2/2.0)/sqrt(2*pi)
+}
+__device__ __forceinline__ double ei_norm_diff(double nd) {
+  return nd * ndtr_dev(nd) + norm_pdf_dev(nd);       // gpb_acquisitions.py:247-249
+}
+
+// mu/sd/acquisition for one chunk.
+//   mu_raw = K(Xs,X) alpha ; ss = ||L^-1 k||^2 ; ss2 = extra hallucination term (or null)
+__global__ void k_posterior_acq(int acq, double p0, double p1, double kxx, double mean_const,
+                                const double* __restrict__ mean_vals, const double* __restrict__ mu_raw,
+                                const double* __restrict__ ss, const double* __restrict__ ss2, long m,
+                                double* __restrict__ mu_out, double* __restrict__ sd_out,
+                                double* __restrict__ val_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const double mu = (mean_vals ? mean_vals[i] : mean_const) + mu_raw[i];   // gp_core.py:173-175
+  double sd = 0.0;
+  if (ss) {
+    double var = kxx - ss[i];                               // diag(K_tete - V^T V), gp_core.py:181
+    if (ss2) var = kxx - (ss[i] + ss2[i]);
+    sd = sqrt(var);                                         // gp_core.py:187 (NaN if var < 0)
+  }
+  if (mu_out) mu_out[i] = mu;
+  if (sd_out) sd_out[i] = sd;
+  if (!val_out) return;
+  double v;
+  switch (acq) {
+    case DFH_ACQ_MEAN: v = mu; break;
+    case DFH_ACQ_STD: v = sd; break;
+    case DFH_ACQ_UCB: v = mu + p0 * sd; break;              // gpb_acquisitions.py:222
+    case DFH_ACQ_EI: {                                      // :256-260
+      const double nd = (mu - p0) / sd;
+      v = sd * ei_norm_diff(nd);
+      break;
+    }
+    case DFH_ACQ_PI: v = ndtr_dev((mu - p0) / sd); break;   // :238
+    case DFH_ACQ_TTEI: {                                    // :275-279
+      const double comb = sqrt(p1 * p1 + sd * sd);
+      const double nd = (mu - p0) / comb;
+      v = comb * ei_norm_diff(nd);
+      break;
+    }
+    default: v = mu;
+  }
+  val_out[i] = v;
+}
+
+// hallucination tail: T[m x q] holds k(x, Xh) - V1 W^T ; solve rows with Lh (q x q lower) and
+// return the squared norms.
+__global__ void k_halluc_rows(double* __restrict__ T, long m, int q, const double* __restrict__ Lh,
+                              double* __restrict__ ss2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double* t = T + i * q;
+  double acc = 0.0;
+  for (int c = 0; c < q; ++c) {
+    double s = t[c];
+    for (int k = 0; k < c; ++k) s = fma(-Lh[c * q + k], t[k], s);
+    s = s / Lh[c * q + c];
+    t[c] = s;
+    acc = fma(s, s, acc);
+  }
+  ss2[i] = acc;
+}
+
+__global__ void k_add_vec(double* __restrict__ y, const double* __restrict__ a, double c, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (a ? a[i] : 0.0) + c + y[i];
+}
+
+// state of the hallucinated augmentation (gp_core.py:192-220)
+struct Halluc {
+  int64_t q = 0;
+  double* Xhp = nullptr; double* Nhp = nullptr;   // packed Xh
+  double* Wt = nullptr;                           // [q][n] = K(Xh,X) L^-T
+  double* Lh = nullptr;                           // [q][q] chol(K_hh + noise I - Wt Wt^T)
+};
+
+int halluc_prepare(dfh_gp* gp, const double* Xh_user, int64_t q, Halluc* h) {
+  dfh_ctx* ctx = gp->ctx;
+  h->q = q;
+  if (q <= 0) return DFH_OK;
+  DFH_ARG(q <= 4096);
+  const KernDev& kd = gp->kd;
+  const double* Xh = nullptr;
+  DFH_TRY(to_device(ctx, Xh_user, (size_t)q * gp->d * 8, SCR_STAGE_C, &Xh));
+  char* buf = nullptr;
+  const size_t b_xhp = (size_t)q * kd.P * 8, b_nhp = (size_t)q * kd.n_parts * 8;
+  const size_t b_wt = (size_t)q * gp->n * 8, b_lh = (size_t)q * q * 8;
+  DFH_TRY(scratch_get(ctx, SCR_AUG, b_xhp + b_nhp + b_wt + b_lh + 1024, (void**)&buf));
+  h->Xhp = reinterpret_cast<double*>(buf);
+  h->Nhp = reinterpret_cast<double*>(buf + ((b_xhp + 255) / 256) * 256);
+  h->Wt = reinterpret_cast<double*>(reinterpret_cast<char*>(h->Nhp) + ((b_nhp + 255) / 256) * 256);
+  h->Lh = reinterpret_cast<double*>(reinterpret_cast<char*>(h->Wt) + ((b_wt + 255) / 256) * 256);
+  DFH_TRY(pack_scaled(ctx, kd, 0, kd.n_parts, false, Xh, q, gp->d, h->Xhp, h->Nhp));
+  // Wt = K(Xh, X) L^-T
+  DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, gp->Xp, gp->Np, gp->n, false, 0.0, h->Wt, gp->n));
+  DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, h->Wt, q, gp->n));
+  // S = K(Xh,Xh) + (noise + jitter) I - Wt Wt^T ; Lh = chol(S)
+  DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, h->Xhp, h->Nhp, q, true, gp->noise_var, h->Lh, q));
+  if (gp->diag_jitter != 0.0) DFH_TRY(add_diag(ctx, h->Lh, q, q, gp->diag_jitter));
+  DFH_TRY(gemm_f64(ctx, 0, q, q, gp->n, -1.0, h->Wt, gp->n, h->Wt, gp->n, 1.0, h->Lh, q, h->Lh, q));
+  int64_t piv = 0;
+  int rc = cholesky_device(ctx, h->Lh, q, q, nullptr, &piv);
+  if (rc == DFH_ERR_NOT_PD)
+    dfh_set_error("augmented (hallucinated) kernel matrix is not positive definite at pivot %lld",
+                  (long long)(gp->n + piv));
+  return rc;
+}
+
+// One chunk of candidates (device pointer Xs_dev, mc rows): fills mu_raw, ss (and ss2).
+// pre_gathered/part range select the add-UCB group path.
+int posterior_chunk(dfh_gp* gp, const double* Xs_dev, int64_t mc, int64_t ldxs, int part_lo, int part_hi,
+                    bool pre_gathered, bool want_var, const Halluc* h, double** Kct_out,
+                    double* mu_raw, double* ss, double* ss2) {
+  dfh_ctx* ctx = gp->ctx;
+  const KernDev& kd = gp->kd;
+  double* Xsp = nullptr; double* Nsp = nullptr; double* Kct = nullptr;
+  char* xs = nullptr;
+  const size_t b_xsp = ((size_t)mc * kd.P * 8 + 255) / 256 * 256;
+  DFH_TRY(scratch_get(ctx, SCR_XS, b_xsp + (size_t)mc * kd.n_parts * 8, (void**)&xs));
+  Xsp = reinterpret_cast<double*>(xs);
+  Nsp = reinterpret_cast<double*>(xs + b_xsp);
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)mc * gp->n * 8, (void**)&Kct));
+  {
+    SectionTimer t(ctx, DFH_T_CROSS);
+    DFH_TRY(pack_scaled(ctx, kd, part_lo, part_hi, pre_gathered, Xs_dev, mc, ldxs, Xsp, Nsp));
+    DFH_TRY(kernmat_packed(ctx, kd, part_lo, part_hi, true, Xsp, Nsp, mc, gp->Xp, gp->Np, gp->n, false, 0.0, Kct, gp->n));
+    DFH_TRY(gemv_rows(ctx, Kct, mc, gp->n, gp->n, gp->alpha, 1.0, nullptr, 0.0, mu_raw));   // gp_core.py:174
+  }
+  if (want_var) {
+    {
+      SectionTimer t(ctx, DFH_T_TRSM);
+      DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, Kct, mc, gp->n));                // gp_core.py:180
+    }
+    SectionTimer t(ctx, DFH_T_ACQ);
+    DFH_TRY(row_sumsq(ctx, Kct, mc, gp->n, gp->n, ss));
+    if (h && h->q > 0) {
+      const int64_t q = h->q;
+      double* T = nullptr;
+      DFH_TRY(scratch_get(ctx, SCR_AUG2, (size_t)mc * q * 8, (void**)&T));
+      // T = k(Xs, Xh) - V1t Wt^T
+      DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xsp, Nsp, mc, h->Xhp, h->Nhp, q, false, 0.0, T, q));
+      DFH_TRY(gemm_f64(ctx, 0, mc, q, gp->n, -1.0, Kct, gp->n, h->Wt, gp->n, 1.0, T, q, T, q));
+      hipLaunchKernelGGL(k_halluc_rows, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, T, (long)mc, (int)q, h->Lh, ss2);
+      DFH_LAUNCH_CHECK();
+    }
+  }
+  if (Kct_out) *Kct_out = Kct;
+  return DFH_OK;
+}
+
+int ladder_pow(int p, double max_M, double* out) {
+  *out = pow(10.0, (double)p) * max_M;      // (10 ** diag_noise_power) * max_M, general_utils.py:189
+  return DFH_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dfh_kernel_matrix(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* X1, int64_t n1,
+                                 const double* X2, int64_t n2, double diag_add, double* K_out) {
+  DFH_ARG(ctx && k && K_out);
+  DFH_ARG(n1 >= 0 && (X2 == nullptr || n2 >= 0));
+  const bool sym = (X2 == nullptr);
+  if (sym) n2 = n1;
+  if (n1 == 0 || n2 == 0) return DFH_OK;     // kernel.py:81-82: empty result
+  DFH_ARG(X1 != nullptr);
+  DFH_HIP(hipSetDevice(ctx->device));
+  KernDev kd;
+  int rc = kerndev_build(ctx, k, &kd);
+  if (rc != DFH_OK) { kerndev_free(&kd); return rc; }
+  auto body = [&]() -> int {
+    const int64_t d = k->dim;
+    const double *dX1 = nullptr, *dX2 = nullptr;
+    DFH_TRY(to_device(ctx, X1, (size_t)n1 * d * 8, SCR_STAGE_A, &dX1));
+    if (!sym) DFH_TRY(to_device(ctx, X2, (size_t)n2 * d * 8, SCR_STAGE_B, &dX2));
+    char* buf = nullptr;
+    const size_t b1 = ((size_t)n1 * kd.P * 8 + 255) / 256 * 256, bn1 = ((size_t)n1 * kd.n_parts * 8 + 255) / 256 * 256;
+    const size_t b2 = sym ? 0 : ((size_t)n2 * kd.P * 8 + 255) / 256 * 256, bn2 = sym ? 0 : (size_t)n2 * kd.n_parts * 8;
+    DFH_TRY(scratch_get(ctx, SCR_XS, b1 + bn1 + b2 + bn2 + 256, (void**)&buf));
+    double* Xp1 = reinterpret_cast<double*>(buf);
+    double* Np1 = reinterpret_cast<double*>(buf + b1);
+    double* Xp2 = sym ? Xp1 : reinterpret_cast<double*>(buf + b1 + bn1);
+    double* Np2 = sym ? Np1 : reinterpret_cast<double*>(buf + b1 + bn1 + b2);
+    DFH_TRY(pack_scaled(ctx, kd, 0, kd.n_parts, false, dX1, n1, d, Xp1, Np1));
+    if (!sym) DFH_TRY(pack_scaled(ctx, kd, 0, kd.n_parts, false, dX2, n2, d, Xp2, Np2));
+    const bool dev_out = is_device_ptr(K_out);
+    double* Kd = K_out;
+    if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n1 * n2 * 8, (void**)&Kd));
+    {
+      SectionTimer t(ctx, sym ? DFH_T_KERNMAT : DFH_T_CROSS);
+      DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xp1, Np1, n1, Xp2, Np2, n2, sym, diag_add, Kd, n2));
+    }
+    if (!dev_out) DFH_TRY(from_device(ctx, K_out, Kd, (size_t)n1 * n2 * 8));
+    return DFH_OK;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(ctx->stream);
+  kerndev_free(&kd);
+  return rc;
+}
+
+extern "C" int dfh_dist_squared(dfh_ctx* ctx, const double* X1, int64_t n1, const double* X2, int64_t n2,
+                                int64_t d, double* D_out) {
+  DFH_ARG(ctx && D_out && d >= 1 && n1 >= 0 && n2 >= 0);
+  if (n1 == 0 || n2 == 0) return DFH_OK;
+  DFH_ARG(X1 && X2);
+  DFH_HIP(hipSetDevice(ctx->device));
+  KernDev kd;
+  int rc = kerndev_build_dist(ctx, (int)d, &kd);
+  if (rc != DFH_OK) { kerndev_free(&kd); return rc; }
+  auto body = [&]() -> int {
+    const double *dX1 = nullptr, *dX2 = nullptr;
+    DFH_TRY(to_device(ctx, X1, (size_t)n1 * d * 8, SCR_STAGE_A, &dX1));
+    DFH_TRY(to_device(ctx, X2, (size_t)n2 * d * 8, SCR_STAGE_B, &dX2));
+    char* buf = nullptr;
+    const size_t b1 = ((size_t)n1 * kd.P * 8 + 255) / 256 * 256, bn1 = ((size_t)n1 * 8 + 255) / 256 * 256;
+    const size_t b2 = ((size_t)n2 * kd.P * 8 + 255) / 256 * 256, bn2 = (size_t)n2 * 8;
+    DFH_TRY(scratch_get(ctx, SCR_XS, b1 + bn1 + b2 + bn2 + 256, (void**)&buf));
+    double* Xp1 = reinterpret_cast<double*>(buf);
+    double* Np1 = reinterpret_cast<double*>(buf + b1);
+    double* Xp2 = reinterpret_cast<double*>(buf + b1 + bn1);
+    double* Np2 = reinterpret_cast<double*>(buf + b1 + bn1 + b2);
+    DFH_TRY(pack_scaled(ctx, kd, 0, 1, false, dX1, n1, d, Xp1, Np1));
+    DFH_TRY(pack_scaled(ctx, kd, 0, 1, false, dX2, n2, d, Xp2, Np2));
+    const bool dev_out = is_device_ptr(D_out);
+    double* Kd = D_out;
+    if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n1 * n2 * 8, (void**)&Kd));
+    DFH_TRY(kernmat_packed(ctx, kd, 0, 1, false, Xp1, Np1, n1, Xp2, Np2, n2, false, 0.0, Kd, n2));
+    if (!dev_out) DFH_TRY(from_device(ctx, D_out, Kd, (size_t)n1 * n2 * 8));
+    return DFH_OK;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(ctx->stream);
+  kerndev_free(&kd);
+  return rc;
+}
+
+extern "C" int dfh_gemm(dfh_ctx* ctx, int transb, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+                        double* C, int64_t ldc, int lower_only) {
+  DFH_ARG(ctx && C && M >= 0 && N >= 0 && K >= 0);
+  if (M == 0 || N == 0) return DFH_OK;
+  DFH_ARG((K == 0 || (A && B)) && lda >= K && ldc >= N && ldb >= (transb ? N : K));
+  DFH_HIP(hipSetDevice(ctx->device));
+  const double *dA = nullptr, *dB = nullptr, *dCin = nullptr;
+  DFH_TRY(to_device(ctx, A, (size_t)M * lda * 8, SCR_STAGE_A, &dA));
+  DFH_TRY(to_device(ctx, B, (size_t)(transb ? K : N) * ldb * 8, SCR_STAGE_B, &dB));
+  const bool dev_out = is_device_ptr(C);
+  double* dC = C;
+  if (!dev_out) {
+    DFH_TRY(scratch_get(ctx, SCR_STAGE_C, (size_t)M * ldc * 8, (void**)&dC));
+    DFH_HIP(hipMemcpyAsync(dC, C, (size_t)M * ldc * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  dCin = dC;
+  int flags = (transb ? GEMM_TRANSB : 0) | (lower_only ? GEMM_LOWER : 0);
+  DFH_TRY(gemm_f64(ctx, flags, M, N, K, alpha, dA, lda, dB, ldb, beta, dCin, ldc, dC, ldc));
+  if (!dev_out) DFH_TRY(from_device(ctx, C, dC, (size_t)M * ldc * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+extern "C" int dfh_cholesky(dfh_ctx* ctx, double* A, int64_t n, int64_t* info_pivot) {
+  DFH_ARG(ctx && n >= 0);
+  if (info_pivot) *info_pivot = 0;
+  if (n == 0) return DFH_OK;
+  DFH_ARG(A != nullptr);
+  DFH_HIP(hipSetDevice(ctx->device));
+  const bool dev = is_device_ptr(A);
+  double* dA = A;
+  if (!dev) {
+    DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)n * n * 8, (void**)&dA));
+    DFH_HIP(hipMemcpyAsync(dA, A, (size_t)n * n * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int rc;
+  {
+    SectionTimer t(ctx, DFH_T_CHOL);
+    rc = cholesky_device(ctx, dA, n, n, nullptr, info_pivot);
+  }
+  if (rc != DFH_OK) return rc;
+  DFH_TRY(zero_upper(ctx, dA, n, n));
+  if (!dev) DFH_TRY(from_device(ctx, A, dA, (size_t)n * n * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+// factor dL (holding M) in place with the stable_cholesky ladder; M is re-created by `rebuild`
+// when a retry is needed (the failed factorisation destroys it).
+template <typename Rebuild>
+static int stable_cholesky_device(dfh_ctx* ctx, double* dL, int64_t n, double* keep_inv, bool allow_jitter,
+                                  Rebuild rebuild, int32_t* jitter_power, double* jitter_added) {
+  if (jitter_power) *jitter_power = INT32_MIN;
+  if (jitter_added) *jitter_added = 0.0;
+  int64_t piv = 0;
+  int rc = cholesky_device(ctx, dL, n, n, keep_inv, &piv);
+  if (rc != DFH_ERR_NOT_PD || !allow_jitter) return rc;
+  // general_utils.py:183-203
+  DFH_TRY(rebuild());
+  double max_M = 0.0;
+  DFH_TRY(diag_max(ctx, dL, n, n, &max_M));
+  bool first = true;
+  for (int p = -11; p < 5; ++p) {
+    double diag_noise;
+    ladder_pow(p, max_M, &diag_noise);
+    if (!first) DFH_TRY(rebuild());
+    first = false;
+    DFH_TRY(add_diag(ctx, dL, n, n, diag_noise));       // M + diag_noise * np.eye(n)
+    rc = cholesky_device(ctx, dL, n, n, keep_inv, &piv);
+    if (rc == DFH_OK) {
+      if (jitter_power) *jitter_power = p;
+      if (jitter_added) *jitter_added = diag_noise;
+      return DFH_OK;
+    }
+    if (rc != DFH_ERR_NOT_PD) return rc;
+    if (p + 1 >= 5) {
+      dfh_set_error("Could not compute Cholesky decomposition despite adding %0.4f to the diagonal. "
+                    "This is likely because the M is not positive semi-definite or has infinities/nans.",
+                    diag_noise);
+      return DFH_ERR_JITTER;
+    }
+  }
+  return DFH_ERR_JITTER;
+}
+
+extern "C" int dfh_stable_cholesky(dfh_ctx* ctx, const double* M_in, int64_t n, double* L_out,
+                                   int32_t* jitter_power) {
+  DFH_ARG(ctx && n >= 0);
+  if (jitter_power) *jitter_power = INT32_MIN;
+  if (n == 0) return DFH_OK;                         // general_utils.py:174-175
+  DFH_ARG(M_in && L_out);
+  DFH_HIP(hipSetDevice(ctx->device));
+  const double* dM = nullptr;
+  DFH_TRY(to_device(ctx, M_in, (size_t)n * n * 8, SCR_TSK, &dM));
+  const bool dev_out = is_device_ptr(L_out);
+  double* dL = L_out;
+  if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)n * n * 8, (void**)&dL));
+  auto rebuild = [&]() -> int { return copy_matrix(ctx, dM, n, dL, n, n, n); };
+  DFH_TRY(rebuild());
+  int rc;
+  {
+    SectionTimer t(ctx, DFH_T_CHOL);
+    rc = stable_cholesky_device(ctx, dL, n, nullptr, true, rebuild, jitter_power, nullptr);
+  }
+  if (rc != DFH_OK) return rc;
+  DFH_TRY(zero_upper(ctx, dL, n, n));
+  if (!dev_out) DFH_TRY(from_device(ctx, L_out, dL, (size_t)n * n * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+extern "C" int dfh_solve_triangular(dfh_ctx* ctx, const double* L, int64_t n, int upper, const double* b,
+                                    int64_t nrhs, double* x_out) {
+  DFH_ARG(ctx && n >= 0 && nrhs >= 1);
+  if (n == 0) return DFH_OK;
+  DFH_ARG(L && b && x_out);
+  DFH_HIP(hipSetDevice(ctx->device));
+  const double *dL = nullptr, *dB = nullptr;
+  DFH_TRY(to_device(ctx, L, (size_t)n * n * 8, SCR_TSL, &dL));
+  DFH_TRY(to_device(ctx, b, (size_t)n * nrhs * 8, SCR_STAGE_B, &dB));
+  const int64_t nblk = (n + CHOL_NB - 1) / CHOL_NB;
+  double* inv = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nblk * CHOL_NB * CHOL_NB * 8, (void**)&inv));
+  DFH_TRY(tri_block_inverses(ctx, dL, n, n, inv));
+  double* dX = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)n * nrhs * 8, (void**)&dX));
+  if (nrhs == 1) {
+    DFH_HIP(hipMemcpyAsync(dX, dB, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!upper) DFH_TRY(trsv_forward(ctx, dL, n, n, inv, dX));
+    else DFH_TRY(trsv_backward(ctx, dL, n, n, inv, dX));
+  } else {
+    double* Bt = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n * nrhs * 8, (void**)&Bt));
+    DFH_TRY(transpose_matrix(ctx, dB, nrhs, Bt, n, n, nrhs));       // Bt[nrhs][n]
+    {
+      SectionTimer t(ctx, DFH_T_TRSM);
+      if (!upper) DFH_TRY(trsm_rows(ctx, dL, n, n, inv, Bt, nrhs, n));
+      else DFH_TRY(trsm_rows_backward(ctx, dL, n, n, inv, Bt, nrhs, n));
+    }
+    DFH_TRY(transpose_matrix(ctx, Bt, n, dX, nrhs, nrhs, n));
+  }
+  DFH_TRY(from_device(ctx, x_out, dX, (size_t)n * nrhs * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dfh_gp_free(dfh_gp* gp) {
+  if (!gp) return DFH_OK;
+  if (gp->ctx) {
+    (void)hipSetDevice(gp->ctx->device);
+    (void)hipStreamSynchronize(gp->ctx->stream);
+  }
+  kerndev_free(&gp->kd);
+  if (gp->Xp) (void)hipFree(gp->Xp);
+  if (gp->Np) (void)hipFree(gp->Np);
+  if (gp->L) (void)hipFree(gp->L);
+  if (gp->inv) (void)hipFree(gp->inv);
+  if (gp->alpha) (void)hipFree(gp->alpha);
+  delete gp;
+  return DFH_OK;
+}
+
+extern "C" int64_t dfh_gp_n(dfh_gp* gp) { return gp ? gp->n : -1; }
+
+extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* X, int64_t n, int64_t d,
+                          const double* y_centred, double noise_var, int flags, dfh_gp** out,
+                          double* lml, int32_t* jitter_power) {
+  DFH_ARG(ctx && k && out && n >= 1 && d >= 1 && X && y_centred);
+  DFH_ARG(k->dim == d);
+  *out = nullptr;
+  if (jitter_power) *jitter_power = INT32_MIN;
+  DFH_HIP(hipSetDevice(ctx->device));
+  dfh_gp* gp = new dfh_gp();
+  gp->ctx = ctx; gp->n = n; gp->d = d; gp->noise_var = noise_var;
+  gp->nblk = (n + CHOL_NB - 1) / CHOL_NB;
+  auto body = [&]() -> int {
+    DFH_TRY(kerndev_build(ctx, k, &gp->kd));
+    const KernDev& kd = gp->kd;
+    DFH_HIP(hipMalloc(&gp->Xp, (size_t)n * kd.P * 8));
+    DFH_HIP(hipMalloc(&gp->Np, (size_t)n * kd.n_parts * 8));
+    DFH_HIP(hipMalloc(&gp->L, (size_t)n * n * 8));
+    DFH_HIP(hipMalloc(&gp->inv, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8));
+    DFH_HIP(hipMalloc(&gp->alpha, (size_t)n * 8));
+    const double *dX = nullptr, *dy = nullptr;
+    DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
+    DFH_TRY(to_device(ctx, y_centred, (size_t)n * 8, SCR_STAGE_B, &dy));
+    auto build_M = [&]() -> int {     // K + noise_var * I     (gp_core.py:843)
+      SectionTimer t(ctx, DFH_T_KERNMAT);
+      return kernmat_packed(ctx, kd, 0, kd.n_parts, true, gp->Xp, gp->Np, n, gp->Xp, gp->Np, n, true, noise_var, gp->L, n);
+    };
+    {
+      SectionTimer t(ctx, DFH_T_KERNMAT);
+      DFH_TRY(pack_scaled(ctx, kd, 0, kd.n_parts, false, dX, n, d, gp->Xp, gp->Np));
+    }
+    DFH_TRY(build_M());
+    {
+      SectionTimer t(ctx, DFH_T_CHOL);
+      DFH_TRY(stable_cholesky_device(ctx, gp->L, n, gp->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
+                                     jitter_power, &gp->diag_jitter));
+    }
+    {
+      SectionTimer t(ctx, DFH_T_SOLVE);
+      // alpha = L^T \ (L \ y_centred)      (gp_core.py:161-163)
+      DFH_HIP(hipMemcpyAsync(gp->alpha, dy, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      DFH_TRY(trsv_forward(ctx, gp->L, n, n, gp->inv, gp->alpha));
+      DFH_TRY(trsv_backward(ctx, gp->L, n, n, gp->inv, gp->alpha));
+      double logdet = 0.0, dot = 0.0;
+      DFH_TRY(logdet_and_dot(ctx, gp->L, n, n, dy, gp->alpha, &logdet, &dot));
+      if (lml) *lml = -0.5 * dot - logdet - 0.5 * (double)n * log(2.0 * M_PI);   // gp_core.py:224-226
+    }
+    return DFH_OK;
+  };
+  int rc = body();
+  if (rc != DFH_OK) { dfh_gp_free(gp); return rc; }
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  *out = gp;
+  return DFH_OK;
+}
+
+extern "C" int dfh_gp_get(dfh_gp* gp, int what, double* out) {
+  DFH_ARG(gp && out);
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int64_t n = gp->n;
+  if (what == DFH_GET_ALPHA) return from_device(ctx, out, gp->alpha, (size_t)n * 8);
+  if (what == DFH_GET_L) {
+    if (!gp->upper_zeroed) { DFH_TRY(zero_upper(ctx, gp->L, n, n)); gp->upper_zeroed = true; }
+    return from_device(ctx, out, gp->L, (size_t)n * n * 8);
+  }
+  if (what == DFH_GET_K) {
+    const bool dev_out = is_device_ptr(out);
+    double* Kd = out;
+    if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n * n * 8, (void**)&Kd));
+    DFH_TRY(kernmat_packed(ctx, gp->kd, 0, gp->kd.n_parts, true, gp->Xp, gp->Np, n, gp->Xp, gp->Np, n, true, 0.0, Kd, n));
+    if (!dev_out) DFH_TRY(from_device(ctx, out, Kd, (size_t)n * n * 8));
+    return DFH_OK;
+  }
+  dfh_set_error("dfh_gp_get: unknown selector %d", what);
+  return DFH_ERR_BAD_ARG;
+}
+
+// shared driver for predict / acquisition arg-max
+static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const double* Xs, int64_t m, int64_t ldxs,
+                          int part_lo, int part_hi, bool pre_gathered, double kxx, const double* Xh, int64_t q,
+                          double mean_const, const double* mean_vals, bool want_var, double* mu_out,
+                          double* sd_out, double* vals_out, double* best_val, int64_t* best_idx) {
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  Halluc h;
+  if (q > 0 && want_var) DFH_TRY(halluc_prepare(gp, Xh, q, &h));
+  const int64_t mc_max = pick_chunk(gp->n, m);
+  const bool xs_dev = is_device_ptr(Xs);
+  const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
+  double* vec = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 6, (void**)&vec));
+  double* mu_raw = vec; double* ss = vec + mc_max; double* ss2 = vec + 2 * mc_max;
+  double* mu_c = vec + 3 * mc_max; double* sd_c = vec + 4 * mc_max; double* val_c = vec + 5 * mc_max;
+  bool have = false; double bv = 0.0; int64_t bi = -1;
+  const double p0 = params ? params[0] : 0.0, p1 = params ? params[1] : 0.0;
+  for (int64_t i0 = 0; i0 < m; i0 += mc_max) {
+    const int64_t mc = std::min(mc_max, m - i0);
+    const double* xs_c = nullptr;
+    if (xs_dev) xs_c = Xs + i0 * ldxs;
+    else DFH_TRY(to_device(ctx, Xs + i0 * ldxs, (size_t)mc * ldxs * 8, SCR_STAGE_A, &xs_c));
+    const double* mv_c = nullptr;
+    if (mean_vals) {
+      if (mv_dev) mv_c = mean_vals + i0;
+      else DFH_TRY(to_device(ctx, mean_vals + i0, (size_t)mc * 8, SCR_STAGE_D, &mv_c));
+    }
+    DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, want_var, &h, nullptr, mu_raw, ss, ss2));
+    {
+      SectionTimer t(ctx, DFH_T_ACQ);
+      const bool need_val = vals_out || best_val || best_idx;
+      hipLaunchKernelGGL(k_posterior_acq, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, acq, p0, p1,
+                         kxx, mean_const, mv_c, mu_raw, want_var ? ss : nullptr,
+                         (want_var && h.q > 0) ? ss2 : nullptr, (long)mc, mu_out ? mu_c : nullptr,
+                         sd_out ? sd_c : nullptr, need_val ? val_c : nullptr);
+      DFH_LAUNCH_CHECK();
+      if (need_val && (best_val || best_idx)) DFH_TRY(argmax_update(ctx, val_c, mc, i0, &have, &bv, &bi));
+    }
+    if (mu_out) DFH_TRY(from_device(ctx, mu_out + i0, mu_c, (size_t)mc * 8));
+    if (sd_out) DFH_TRY(from_device(ctx, sd_out + i0, sd_c, (size_t)mc * 8));
+    if (vals_out) DFH_TRY(from_device(ctx, vals_out + i0, val_c, (size_t)mc * 8));
+  }
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  if (best_val) *best_val = bv;
+  if (best_idx) *best_idx = bi;
+  return DFH_OK;
+}
+
+extern "C" int dfh_gp_predict(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
+                              double* mu_out, double* sd_out) {
+  DFH_ARG(gp && m >= 0 && q >= 0);
+  if (m == 0) return DFH_OK;
+  DFH_ARG(Xs && mu_out && (q == 0 || Xh));
+  return gp_eval_driver(gp, DFH_ACQ_MEAN, nullptr, Xs, m, gp->d, 0, gp->kd.n_parts, false, gp->kd.kxx, Xh, q,
+                        0.0, nullptr, sd_out != nullptr, mu_out, sd_out, nullptr, nullptr, nullptr);
+}
+
+extern "C" int dfh_gp_acq_argmax(dfh_gp* gp, int acq, const double* params, const double* Xs, int64_t m,
+                                 const double* Xh, int64_t q, double mean_const, const double* mean_vals,
+                                 double* vals_out, double* best_val, int64_t* best_idx) {
+  DFH_ARG(gp && m >= 1 && Xs && q >= 0 && (q == 0 || Xh));
+  DFH_ARG(acq >= DFH_ACQ_MEAN && acq <= DFH_ACQ_STD);
+  DFH_ARG(params || acq == DFH_ACQ_MEAN || acq == DFH_ACQ_STD);
+  const bool want_var = acq != DFH_ACQ_MEAN;
+  return gp_eval_driver(gp, acq, params, Xs, m, gp->d, 0, gp->kd.n_parts, false, gp->kd.kxx, Xh, q, mean_const,
+                        mean_vals, want_var, nullptr, nullptr, vals_out, best_val, best_idx);
+}
+
+extern "C" int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, const double* Xg, int64_t m,
+                                    double* vals_out, double* best_val, int64_t* best_idx) {
+  DFH_ARG(gp && Xg && m >= 1);
+  DFH_ARG(gp->kd.multi && group >= 0 && group < gp->kd.n_parts);
+  const PartDev& pd = gp->kd.parts[group];
+  int gdim = 0;
+  for (int c = 0; c < pd.kc; ++c) gdim += gp->kd.cols[pd.poff + c] >= 0;
+  const double kxx = gp->kd.outer_scale * kerndev_part_kxx(gp->kd, group);   // kern_scale * kernel_j(x,x)
+  const double params[2] = {beta, 0.0};
+  return gp_eval_driver(gp, DFH_ACQ_UCB, params, Xg, m, gdim, group, group + 1, true, kxx, nullptr, 0, 0.0,
+                        nullptr, true, nullptr, nullptr, vals_out, best_val, best_idx);
+}
+
+extern "C" int dfh_gp_predict_covar(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
+                                    double* mu_out, double* cov_out) {
+  DFH_ARG(gp && m >= 0 && q >= 0);
+  if (m == 0) return DFH_OK;
+  DFH_ARG(Xs && mu_out && cov_out && (q == 0 || Xh));
+  DFH_ARG((double)m * (double)gp->n * 8.0 < 64e9);
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const KernDev& kd = gp->kd;
+  Halluc h;
+  if (q > 0) DFH_TRY(halluc_prepare(gp, Xh, q, &h));
+  const double* dXs = nullptr;
+  DFH_TRY(to_device(ctx, Xs, (size_t)m * gp->d * 8, SCR_STAGE_A, &dXs));
+  double* vec = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)m * 8 * 3, (void**)&vec));
+  double* Kct = nullptr;
+  DFH_TRY(posterior_chunk(gp, dXs, m, gp->d, 0, kd.n_parts, false, true, nullptr, &Kct, vec, vec + m, vec + 2 * m));
+  DFH_TRY(from_device(ctx, mu_out, vec, (size_t)m * 8));
+  // cov = K(Xs,Xs) - V^T V     (gp_core.py:179-181)
+  const bool dev_out = is_device_ptr(cov_out);
+  double* C = cov_out;
+  if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)m * m * 8, (void**)&C));
+  char* xs = reinterpret_cast<char*>(ctx->scratch[SCR_XS].p);      // packed Xs left by posterior_chunk
+  double* Xsp = reinterpret_cast<double*>(xs);
+  double* Nsp = reinterpret_cast<double*>(xs + ((size_t)m * kd.P * 8 + 255) / 256 * 256);
+  DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xsp, Nsp, m, Xsp, Nsp, m, true, 0.0, C, m));
+  DFH_TRY(gemm_f64(ctx, 0, m, m, gp->n, -1.0, Kct, gp->n, Kct, gp->n, 1.0, C, m, C, m));
+  if (q > 0) {
+    // second block row of the augmented solve: V2t = (k(Xs,Xh) - V1t Wt^T) Lh^-T ; cov -= V2t V2t^T
+    double* T = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_AUG2, (size_t)m * q * 8, (void**)&T));
+    DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xsp, Nsp, m, h.Xhp, h.Nhp, q, false, 0.0, T, q));
+    DFH_TRY(gemm_f64(ctx, 0, m, q, gp->n, -1.0, Kct, gp->n, h.Wt, gp->n, 1.0, T, q, T, q));
+    hipLaunchKernelGGL(k_halluc_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, T, (long)m, (int)q, h.Lh, vec + 2 * m);
+    DFH_LAUNCH_CHECK();
+    DFH_TRY(gemm_f64(ctx, 0, m, m, q, -1.0, T, q, T, q, 1.0, C, m, C, m));
+  }
+  if (!dev_out) DFH_TRY(from_device(ctx, cov_out, C, (size_t)m * m * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block, const double* U,
+                         double mean_const, const double* mean_vals, double* samples_out, double* best_val,
+                         int64_t* best_idx, int32_t* jitter_powers_out) {
+  DFH_ARG(gp && Xs && U && m >= 1 && block >= 1);
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const KernDev& kd = gp->kd;
+  const int64_t n = gp->n;
+  if (block > m) block = m;
+  DFH_ARG((double)block * (double)block * 8.0 < 32e9);
+  // several TS blocks share one posterior chunk so the TRSM runs on big GEMMs
+  int64_t bpc = std::max<int64_t>(1, pick_chunk(n, m) / block);
+  const int64_t mc_max = std::min(m, bpc * block);
+  const bool xs_dev = is_device_ptr(Xs), u_dev = is_device_ptr(U);
+  const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
+  double* vec = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 4, (void**)&vec));
+  double* mu_raw = vec; double* ss = vec + mc_max; double* samp = vec + 2 * mc_max;
+  double* Sig = nullptr; double* Lb = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)block * block * 8, (void**)&Sig));
+  DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)block * block * 8, (void**)&Lb));
+  bool have = false; double bv = 0.0; int64_t bi = -1;
+  int64_t blk_idx = 0;
+  for (int64_t i0 = 0; i0 < m; i0 += mc_max) {
+    const int64_t mc = std::min(mc_max, m - i0);
+    const double* xs_c = nullptr;
+    if (xs_dev) xs_c = Xs + i0 * gp->d;
+    else DFH_TRY(to_device(ctx, Xs + i0 * gp->d, (size_t)mc * gp->d * 8, SCR_STAGE_A, &xs_c));
+    const double* u_c = nullptr;
+    if (u_dev) u_c = U + i0;
+    else DFH_TRY(to_device(ctx, U + i0, (size_t)mc * 8, SCR_STAGE_C, &u_c));
+    const double* mv_c = nullptr;
+    if (mean_vals) {
+      if (mv_dev) mv_c = mean_vals + i0;
+      else DFH_TRY(to_device(ctx, mean_vals + i0, (size_t)mc * 8, SCR_STAGE_D, &mv_c));
+    }
+    double* Kct = nullptr;
+    DFH_TRY(posterior_chunk(gp, xs_c, mc, gp->d, 0, kd.n_parts, false, true, nullptr, &Kct, mu_raw, ss, nullptr));
+    // mean_vals = test_mean + K_tetr alpha
+    hipLaunchKernelGGL(k_add_vec, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, mu_raw, mv_c,
+                       mv_c ? 0.0 : mean_const, (long)mc);
+    DFH_LAUNCH_CHECK();
+    char* xs = reinterpret_cast<char*>(ctx->scratch[SCR_XS].p);
+    double* Xsp = reinterpret_cast<double*>(xs);
+    double* Nsp = reinterpret_cast<double*>(xs + ((size_t)mc * kd.P * 8 + 255) / 256 * 256);
+    for (int64_t b0 = 0; b0 < mc; b0 += block, ++blk_idx) {
+      const int64_t B = std::min(block, mc - b0);
+      SectionTimer t(ctx, DFH_T_TS);
+      const double* Vt = Kct + b0 * n;
+      auto build_sigma = [&]() -> int {
+        // Sigma = K(Xb,Xb) - V^T V     (gp_core.py:179-181) ; lower triangle is what chol reads
+        DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xsp + b0 * kd.P, Nsp + b0 * kd.n_parts, B,
+                               Xsp + b0 * kd.P, Nsp + b0 * kd.n_parts, B, true, 0.0, Lb, B));
+        return gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, Lb, B, Lb, B);
+      };
+      DFH_TRY(build_sigma());
+      int32_t jp = INT32_MIN;
+      DFH_TRY(stable_cholesky_device(ctx, Lb, B, nullptr, true, build_sigma, &jp, nullptr));   // general_utils.py:229
+      if (jitter_powers_out) jitter_powers_out[blk_idx] = jp;
+      // s = L u + mu        (general_utils.py:231)
+      DFH_TRY(gemv_rows(ctx, Lb, B, B, B, u_c + b0, 1.0, mu_raw + b0, 1.0, samp + b0, true));
+    }
+    DFH_TRY(argmax_update(ctx, samp, mc, i0, &have, &bv, &bi));
+    if (samples_out) DFH_TRY(from_device(ctx, samples_out + i0, samp, (size_t)mc * 8));
+  }
+  (void)Sig;
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  if (best_val) *best_val = bv;
+  if (best_idx) *best_idx = bi;
+  return DFH_OK;
+}

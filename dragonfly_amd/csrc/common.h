@@ -1,0 +1,212 @@
+// Internal declarations shared by the libdfhip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/dfhip.h"
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+void dfh_set_error(const char* fmt, ...);
+
+#define DFH_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      dfh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return DFH_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define DFH_TRY(call)                 \
+  do {                                \
+    int rc__ = (call);                \
+    if (rc__ != DFH_OK) return rc__;  \
+  } while (0)
+
+#define DFH_ARG(cond)                                                         \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      dfh_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond);    \
+      return DFH_ERR_BAD_ARG;                                                 \
+    }                                                                         \
+  } while (0)
+
+#define DFH_LAUNCH_CHECK() DFH_HIP(hipGetLastError())
+
+// A device allocation that is kept for the life of its owner (ctx scratch or gp state).
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct dfh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
+  // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
+  std::vector<DevBuf> scratch;
+  int64_t* d_info = nullptr;                         // device int64[8] status words
+  int64_t* h_info = nullptr;                         // pinned mirror
+  // section timing
+  bool timing = false;
+  double t_ms[DFH_T_COUNT] = {0};
+  hipEvent_t tev0[DFH_T_COUNT] = {nullptr}, tev1[DFH_T_COUNT] = {nullptr};   // one pair per section (nestable)
+  char name[256] = {0};
+  int n_cu = 256;
+};
+
+enum ScratchSlot {
+  SCR_STAGE_A = 0,  // host->device staging of inputs
+  SCR_STAGE_B,
+  SCR_STAGE_C,
+  SCR_STAGE_D,
+  SCR_XS,           // scaled / gathered copies
+  SCR_KCT,          // candidate-by-train cross kernel / V^T chunk
+  SCR_TMP,          // TRSM block temp
+  SCR_TMP2,
+  SCR_VEC,          // small vectors
+  SCR_VEC2,
+  SCR_VEC3,
+  SCR_RED,          // reduction partials
+  SCR_CHOLW,        // cholesky panel workspace
+  SCR_CHOLINV,      // cholesky diag-block inverses (transient use)
+  SCR_CHOLT,        // inverse-assembly temporaries
+  SCR_TSK,          // TS block covariance
+  SCR_TSL,          // TS block factor
+  SCR_AUG,          // hallucination: augmented rows
+  SCR_AUG2,
+  SCR_OUT,          // device result staging for host outputs
+  SCR_OUT2,
+  SCR_COUNT
+};
+
+// returns a device pointer with at least `bytes` capacity (contents undefined)
+int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out);
+
+// Resolve a user pointer: if it is a host pointer, copy `bytes` to scratch slot `slot` and
+// return the device copy; if it is a device pointer return it unchanged.
+int to_device(dfh_ctx* ctx, const void* p, size_t bytes, int slot, const double** out);
+bool is_device_ptr(const void* p);
+// Copy a device result to a user pointer that may be host or device.
+int from_device(dfh_ctx* ctx, void* user_dst, const void* dev_src, size_t bytes);
+
+struct SectionTimer {
+  dfh_ctx* ctx; int which; bool on;
+  SectionTimer(dfh_ctx* c, int w);
+  ~SectionTimer();
+};
+
+// ---------------------------------------------------------------------------------------
+// device-level building blocks (all asynchronous on ctx->stream, device pointers only)
+// ---------------------------------------------------------------------------------------
+#define GEMM_LOWER   1   // compute only tiles intersecting the lower triangle (row >= col)
+#define GEMM_KTRI_B  2   // B is [N x K] lower triangular (B[j][k]=0 for k>j): clip k-range
+#define GEMM_TRANSB  4   // B is [K x N]
+
+struct GemmBatch { int count = 1; int64_t sA = 0, sB = 0, sCin = 0, sCout = 0; };
+
+// Cout = beta*Cin + alpha * A * op(B).  Cin may equal Cout.  Cin may be null iff beta == 0.
+int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double alpha,
+             const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+             const double* Cin, int64_t ldcin, double* Cout, int64_t ldc,
+             const GemmBatch* batch = nullptr);
+
+// Flattened kernel description.  A "part" is one SE / Matern kernel over a subset of the input
+// columns: SE and Matern kernels have one part, an additive kernel one part per group
+// (dragonfly/gp/kernel.py:484-494).  Inputs are pre-scaled once into a packed layout
+//   Xp[n][P],  P = sum_parts pad4(|cols_part|),  Xp[i][poff+c] = X[i][cols[c]] / bw[c]
+// (get_scaled_repr, kernel.py:179-181,255-257) with zero padding, plus the per-part squared
+// row norms Np[n][n_parts] ((X**2).sum(axis=1), general_utils.py:66-67).
+#define DFH_KERNEL_DIST 3   // internal: clip(dist_sq) itself (dfh_dist_squared)
+struct PartDev {
+  int kind;        // DFH_KERNEL_SE | DFH_KERNEL_MATERN | DFH_KERNEL_DIST
+  int poff;        // first packed column
+  int kc;          // packed (padded to 4) column count
+  int p;           // Matern: int(nu)
+  double scale_c;  // SE: scale ; Matern: scale * norm_constant (kernel.py:298)
+  double s8, s2;   // Matern: sqrt(8 nu), sqrt(2 nu)
+  double gfac;     // Matern: Gamma(p+1)/Gamma(2p+1)
+  double coeff[8]; // Matern: (p+i)!/(i!(p-i)!)
+};
+struct KernDev {
+  int kind = 0, dim = 0, n_parts = 0, P = 0;
+  bool multi = false;          // additive: sum over parts then outer scale
+  double outer_scale = 1.0;
+  std::vector<PartDev> parts;
+  std::vector<int> cols;       // [P] source column per packed column (-1 = padding)
+  std::vector<int> lcols;      // [P] column index local to the part (for pre-gathered inputs)
+  std::vector<double> bw;      // [P]
+  PartDev* d_parts = nullptr;
+  int* d_cols = nullptr;
+  int* d_lcols = nullptr;
+  double* d_bw = nullptr;
+  double kxx = 0.0;            // prior variance k(x,x)
+};
+int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* out);
+int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* out);
+void kerndev_free(KernDev* kd);
+double kerndev_part_kxx(const KernDev& kd, int part);
+
+// Xp[n][P] / Np[n][n_parts] for parts [part_lo, part_hi) (other parts' columns untouched).
+// pre_gathered: X holds only the columns of part_lo (ldx >= |cols|), as in add-UCB group
+// candidates (gpb_acquisitions.py:164-166).
+int pack_scaled(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool pre_gathered,
+                const double* X, int64_t n, int64_t ldx, double* Xp, double* Np);
+
+// K[n1 x n2] (ldk) = sum over parts [part_lo,part_hi) of k_part (times outer scale if multi).
+// symmetric: Xp2/Np2 == Xp1/Np1 and diag_add is added on the diagonal.
+int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool apply_outer,
+                   const double* Xp1, const double* Np1, int64_t n1, const double* Xp2,
+                   const double* Np2, int64_t n2, bool symmetric, double diag_add, double* K,
+                   int64_t ldk);
+
+// Blocked Cholesky, in place on the lower triangle of the row-major matrix A (upper part of the
+// off-diagonal blocks is left untouched; the upper part of the 64x64 diagonal blocks is zeroed).
+// keep_inv (optional): receives the inverses of the CHOL_NB x CHOL_NB diagonal blocks of L,
+// block b at keep_inv + b*CHOL_NB*CHOL_NB, row-major with ld = CHOL_NB, zero upper part.
+// *info_pivot = 0 on success, else the 1-based index of the first non-positive pivot.
+constexpr int64_t CHOL_NB = 512;
+int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
+                    int64_t* info_pivot);
+
+// alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
+//   forward : x <- L^{-1} x          backward : x <- L^{-T} x
+int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
+                 double* x);
+int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
+                  double* x);
+// Rows-as-RHS solve used by the posterior:  Vt[m x n] <- Kct[m x n] * L^{-T}  (in place),
+// i.e. each row v of Vt satisfies L v = k  (solve_lower_triangular(L, K_tetr.T), gp_core.py:180)
+int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
+              double* Kct, int64_t m, int64_t ldk);
+// Xt[m x n] <- Bt[m x n] * L^{-1} (in place): each row x satisfies L^T x = b
+int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
+                       double* Bt, int64_t m, int64_t ldb);
+// inverses of the CHOL_NB diagonal blocks of an existing lower factor L (layout as keep_inv)
+int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, double* inv);
+
+// small helpers (elementwise / reductions)
+int fill_f64(dfh_ctx* ctx, double* p, int64_t n, double v);
+int zero_upper(dfh_ctx* ctx, double* A, int64_t n, int64_t lda);
+int diag_max(dfh_ctx* ctx, const double* A, int64_t n, int64_t lda, double* host_out);
+int add_diag(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double v);
+int copy_matrix(dfh_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd,
+                int64_t rows, int64_t cols);
+int transpose_matrix(dfh_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd,
+                     int64_t rows, int64_t cols);
+// yout[m] = beta*yin + alpha * A[m x n] x[n]   (yin may equal yout; may be null iff beta == 0)
+// tri_lower: row i only uses columns j <= i (lower-triangular A)
+int gemv_rows(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, const double* x,
+              double alpha, const double* yin, double beta, double* yout, bool tri_lower = false);
+// yout[n] = beta*yin + alpha * A[m x n]^T x[m]
+int gemv_cols(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, const double* x,
+              double alpha, const double* yin, double beta, double* yout);
+// out[m] = sum_j A[i][j]^2
+int row_sumsq(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, double* out);
+// host result: sum(log(diag(L))) and dot(a,b)
+int logdet_and_dot(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* a,
+                   const double* b, double* host_logdet, double* host_dot);

@@ -1,0 +1,261 @@
+// fp64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//   Cout[M x N] = beta * Cin + alpha * A[M x K] * op(B)
+//   op(B) = B^T with B[N x K]  ("NT", both operands K-contiguous: SYRK / TRSM-by-inverse)
+//         = B   with B[K x N]  ("NN")
+//
+// This is the one dense contraction on the GP hot path: it stands in for the dgemm /
+// dpotrf-trailing-update / dtrsm work NumPy+SciPy hand to OpenBLAS/LAPACK in the reference
+// (dragonfly/utils/general_utils.py:68,178,213; dragonfly/gp/gp_core.py:174,180,181).
+//
+// Tiling (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave
+// owns 64x64 = 4x4 MFMA tiles (16 accumulators x 4 f64 = 128 VGPRs).  K is consumed in
+// chunks of 16 through a double-buffered, padded LDS image (one barrier per chunk); global
+// loads of chunk c+1 are issued before the 64 MFMAs of chunk c and written to LDS after
+// them, so HBM/L2 latency hides under the matrix pipe.  2 workgroups per CU (73.7 KB LDS,
+// <=256 VGPRs) keep a second wave per SIMD ready while one sits at the barrier.
+//
+// MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3):
+//   A operand : lane l holds A[i = l&15][k = l>>4]
+//   B operand : lane l holds B[k = l>>4][j = l&15]
+//   C/D       : reg r of lane l holds D[i = (l>>4) + 4r][j = l&15]
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BKP = 18;    // row stride (doubles) of the K-contiguous LDS tiles: 2*(r*18+k) mod 64
+                           // is distinct over r<16,k<2 -> ds_read_b64 conflict free
+constexpr int BNP = 144;   // row stride of the NN B tile [BK][BN]: 2*144 mod 64 = 32
+constexpr int TILE_A = BM * BKP;                       // doubles per A stage
+constexpr int TILE_B = (BN * BKP > BK * BNP) ? BN * BKP : BK * BNP;
+constexpr int SMEM_BYTES = 2 * (TILE_A + TILE_B) * 8;  // 73728
+
+struct GemmArgs {
+  int M, N, K;
+  const double* A; long lda; long sA;
+  const double* B; long ldb; long sB;
+  const double* Cin; long ldcin; long sCin;
+  double* Cout; long ldc; long sCout;
+  double alpha, beta;
+  int flags;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
+  // XCD-aware remap: hardware places block b on XCD b%8; give each XCD a contiguous span of
+  // the linear tile order so neighbouring tiles (sharing A/B panels) share one L2.
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+  unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  if (p.flags & GEMM_LOWER) {
+    // row-by-row enumeration of the lower-triangular tile set
+    unsigned i = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+    while ((unsigned long long)i * (i + 1) / 2 > lin) --i;
+    while ((unsigned long long)(i + 1) * (i + 2) / 2 <= lin) ++i;
+    tm = (int)i;
+    tn = (int)(lin - (unsigned)((unsigned long long)i * (i + 1) / 2));
+  } else {
+    constexpr unsigned GROUP_M = 8;
+    const unsigned width = GROUP_M * (unsigned)p.tiles_n;
+    const unsigned group = lin / width;
+    const unsigned first_m = group * GROUP_M;
+    const unsigned gsz = min((unsigned)p.tiles_m - first_m, GROUP_M);
+    const unsigned in = lin % width;
+    tm = (int)(first_m + in % gsz);
+    tn = (int)(in / gsz);
+  }
+}
+
+template <bool TRANSB, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                  // [2][TILE_A]
+  double* Bs = smem + 2 * TILE_A;     // [2][TILE_B]
+
+  int tm, tn;
+  map_tile(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  const long bz = blockIdx.z;
+  const double* __restrict__ A = p.A + bz * p.sA;
+  const double* __restrict__ B = p.B + bz * p.sB;
+
+  int kend = p.K;
+  if (p.flags & GEMM_KTRI_B) kend = min(p.K, n0 + BN);   // B[j][k] = 0 for k > j
+  const int nchunks = (kend + BK - 1) / BK;
+
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  // staging registers: 4 x 16B for A and 4 x 16B for B per thread per chunk
+  double2_t ra[4], rb[4];
+
+  const int a_row = tid >> 3, a_col = (tid & 7) * 2;      // K-contiguous tiles: 8 lanes per row
+  const int b_krow = tid >> 6, b_ncol = (tid & 63) * 2;   // NN B tile: 64 lanes per k-row
+
+  auto load_chunk = [&](int kc) {
+    const int k0 = kc * BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = a_row + 32 * q;
+      if (!EDGE) {
+        ra[q] = *reinterpret_cast<const double2_t*>(A + (long)(m0 + row) * p.lda + k0 + a_col);
+      } else {
+        const int gr = m0 + row, gk = k0 + a_col;
+        const double* src = A + (long)gr * p.lda + gk;
+        ra[q].x = (gr < p.M && gk < kend) ? src[0] : 0.0;
+        ra[q].y = (gr < p.M && gk + 1 < kend) ? src[1] : 0.0;
+      }
+    }
+    if (!TRANSB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = a_row + 32 * q;
+        if (!EDGE) {
+          rb[q] = *reinterpret_cast<const double2_t*>(B + (long)(n0 + row) * p.ldb + k0 + a_col);
+        } else {
+          const int gr = n0 + row, gk = k0 + a_col;
+          const double* src = B + (long)gr * p.ldb + gk;
+          rb[q].x = (gr < p.N && gk < kend) ? src[0] : 0.0;
+          rb[q].y = (gr < p.N && gk + 1 < kend) ? src[1] : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int krow = b_krow + 4 * q;
+        if (!EDGE) {
+          rb[q] = *reinterpret_cast<const double2_t*>(B + (long)(k0 + krow) * p.ldb + n0 + b_ncol);
+        } else {
+          const int gk = k0 + krow, gn = n0 + b_ncol;
+          const double* src = B + (long)gk * p.ldb + gn;
+          rb[q].x = (gk < kend && gn < p.N) ? src[0] : 0.0;
+          rb[q].y = (gk < kend && gn + 1 < p.N) ? src[1] : 0.0;
+        }
+      }
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    double* as = As + buf * TILE_A;
+    double* bs = Bs + buf * TILE_B;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<double2_t*>(as + (a_row + 32 * q) * BKP + a_col) = ra[q];
+    if (!TRANSB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<double2_t*>(bs + (a_row + 32 * q) * BKP + a_col) = rb[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<double2_t*>(bs + (b_krow + 4 * q) * BNP + b_ncol) = rb[q];
+    }
+  };
+
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nchunks) load_chunk(kc + 1);
+
+    const double* as = As + buf * TILE_A + (wm * 64 + l15) * BKP + l4;
+    const double* bs = TRANSB ? (Bs + buf * TILE_B + l4 * BNP + wn * 64 + l15)
+                              : (Bs + buf * TILE_B + (wn * 64 + l15) * BKP + l4);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = as[t * 16 * BKP + kk * 4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = TRANSB ? bs[kk * 4 * BNP + t * 16] : bs[t * 16 * BKP + kk * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+
+    if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+  const double alpha = p.alpha, beta = p.beta;
+  const double* __restrict__ Cin = p.Cin ? p.Cin + bz * p.sCin : nullptr;
+  double* __restrict__ Cout = p.Cout + bz * p.sCout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + l15;
+        if (EDGE && (row >= p.M || col >= p.N)) continue;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * Cin[(long)row * p.ldcin + col];
+        Cout[(long)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <bool TRANSB, bool EDGE>
+int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
+  static bool attr_set = false;
+  auto kern = gemm_f64_kernel<TRANSB, EDGE>;
+  if (!attr_set) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), SMEM_BYTES, ctx->stream, p);
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
+
+}  // namespace
+
+int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double alpha,
+             const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+             const double* Cin, int64_t ldcin, double* Cout, int64_t ldc,
+             const GemmBatch* batch) {
+  if (M <= 0 || N <= 0) return DFH_OK;
+  DFH_ARG(M < (1LL << 30) && N < (1LL << 30) && K < (1LL << 30) && K >= 0);
+  DFH_ARG(beta == 0.0 || Cin != nullptr);
+  if (flags & GEMM_LOWER) DFH_ARG(M == N);
+  GemmArgs p;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
+  p.Cin = (beta == 0.0) ? nullptr : Cin; p.ldcin = ldcin; p.Cout = Cout; p.ldc = ldc;
+  p.sA = p.sB = p.sCin = p.sCout = 0;
+  int count = 1;
+  if (batch) { count = batch->count; p.sA = batch->sA; p.sB = batch->sB; p.sCin = batch->sCin; p.sCout = batch->sCout; }
+  p.alpha = alpha; p.beta = beta; p.flags = flags;
+  p.tiles_m = (int)((M + BM - 1) / BM);
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  long ntiles = (flags & GEMM_LOWER) ? (long)p.tiles_m * (p.tiles_m + 1) / 2 : (long)p.tiles_m * p.tiles_n;
+  dim3 grid((unsigned)ntiles, 1, (unsigned)count);
+  const bool transb = flags & GEMM_TRANSB;
+  auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  bool edge = (M % BM) || (N % BN) || (K % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) ||
+              !aligned16(B) || ((p.sA | p.sB) & 1);
+  if (transb) {
+    return edge ? launch<true, true>(ctx, p, grid) : launch<true, false>(ctx, p, grid);
+  } else {
+    return edge ? launch<false, true>(ctx, p, grid) : launch<false, false>(ctx, p, grid);
+  }
+}

@@ -1,0 +1,432 @@
+// Kernel-matrix construction: SE / Matern / additive Gram and cross matrices in fp64.
+//
+// Replaces, fused into one pass over the output,
+//   get_scaled_repr                 dragonfly/gp/kernel.py:179-181, 255-257   (pack_scaled)
+//   dist_squared (+ clip at 0)      dragonfly/utils/general_utils.py:58-70
+//   SEKernel._child_evaluate        dragonfly/gp/kernel.py:171-177
+//   MaternKernel._child_evaluate    dragonfly/gp/kernel.py:259-270, 292-299
+//   AdditiveKernel._child_evaluate  dragonfly/gp/kernel.py:484-494
+//   K + noise_var*np.eye(n)         dragonfly/gp/gp_core.py:843               (diag_add)
+//
+// The reference materialises three n1 x n2 temporaries plus the dgemm output; here each
+// 128 x 128 (128 x 64 for additive) output tile is produced in registers: the -2 X1 X2^T term
+// runs on the fp64 matrix cores (same expansion as the reference, so the same rounding
+// behaviour), the norms / clip / exp / Matern polynomial run on the VALU beside it, and the
+// only HBM traffic is the coalesced write of K (the pass is HBM-write bound:
+// 8*(n1*n2 + (n1+n2)*d) algorithmic bytes).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int KM_BM = 128;
+constexpr int KM_KC = 32;          // packed columns per LDS chunk
+constexpr int KM_KP = 34;          // LDS row stride (doubles); 34 = 2 mod 32 -> conflict-free b64 frag reads
+
+struct KmArgs {
+  const double* Xp1; const double* Np1;
+  const double* Xp2; const double* Np2;
+  int n1, n2, P, n_parts_total;
+  const PartDev* parts;
+  int part_lo, part_hi;
+  double outer;
+  int apply_outer, symmetric;
+  double diag_add;
+  double* K; long ldk;
+};
+
+__device__ __forceinline__ double ipow(double m, int k) {
+  double r = 1.0;                      // 0**0 == 1 as in numpy (kernel.py:266)
+  for (int i = 0; i < k; ++i) r *= m;
+  return r;
+}
+
+__device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq) {
+  if (pd.kind == DFH_KERNEL_SE) {
+    return pd.scale_c * exp(-dsq / 2);                     // kernel.py:176
+  } else if (pd.kind == DFH_KERNEL_MATERN) {
+    const double dist = sqrt(dsq);                         // kernel.py:296
+    const double mult = pd.s8 * dist;                      // kernel.py:265
+    double u = 0.0;
+    for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * ipow(mult, pd.p - i);   // kernel.py:266
+    u *= (pd.gfac * exp(-pd.s2 * dist));                   // kernel.py:268-269
+    return pd.scale_c * u;                                 // kernel.py:298
+  }
+  return dsq;                                              // DFH_KERNEL_DIST
+}
+
+template <int TJ, bool MULTI>
+__global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
+  constexpr int BN = 2 * TJ * 16;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                           // [128][KM_KP]
+  double* Bs = As + KM_BM * KM_KP;             // [BN][KM_KP]
+  double* na = Bs + BN * KM_KP;                // [128]
+  double* nb = na + KM_BM;                     // [BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long m0 = (long)blockIdx.y * KM_BM, n0 = (long)blockIdx.x * BN;
+
+  double4_t res[4][TJ];
+  if (MULTI) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) res[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  }
+
+  for (int part = p.part_lo; part < p.part_hi; ++part) {
+    const PartDev pd = p.parts[part];
+    double4_t acc[4][TJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    for (int k0 = 0; k0 < pd.kc; k0 += KM_KC) {
+      const int kc = min(KM_KC, pd.kc - k0);     // multiple of 4
+      const int kh = kc >> 1;                    // double2 per row
+      __syncthreads();                           // previous readers of As/Bs/na/nb are done
+      for (int idx = tid; idx < KM_BM * kh; idx += 256) {
+        const int r = idx / kh, c2 = (idx - r * kh) * 2;
+        const long row = m0 + r;
+        double2_t v = (double2_t){0.0, 0.0};
+        if (row < p.n1) v = *reinterpret_cast<const double2_t*>(p.Xp1 + row * p.P + pd.poff + k0 + c2);
+        *reinterpret_cast<double2_t*>(As + r * KM_KP + c2) = v;
+      }
+      for (int idx = tid; idx < BN * kh; idx += 256) {
+        const int r = idx / kh, c2 = (idx - r * kh) * 2;
+        const long row = n0 + r;
+        double2_t v = (double2_t){0.0, 0.0};
+        if (row < p.n2) v = *reinterpret_cast<const double2_t*>(p.Xp2 + row * p.P + pd.poff + k0 + c2);
+        *reinterpret_cast<double2_t*>(Bs + r * KM_KP + c2) = v;
+      }
+      if (k0 == 0) {
+        if (tid < KM_BM) {
+          const long row = m0 + tid;
+          na[tid] = row < p.n1 ? p.Np1[row * p.n_parts_total + part] : 0.0;
+        } else if (tid - KM_BM < BN) {
+          const long row = n0 + tid - KM_BM;
+          nb[tid - KM_BM] = row < p.n2 ? p.Np2[row * p.n_parts_total + part] : 0.0;
+        }
+      }
+      __syncthreads();
+      const double* as = As + (wm * 64 + l15) * KM_KP + l4;
+      const double* bs = Bs + (wn * TJ * 16 + l15) * KM_KP + l4;
+      for (int kk = 0; kk < kc; kk += 4) {
+        double a[4], b[TJ];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = as[t * 16 * KM_KP + kk];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) b[t] = bs[t * 16 * KM_KP + kk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    // distances -> kernel values for this part
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = wm * 64 + i * 16 + l4 + 4 * r;
+        const double nai = na[lr];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int lc = wn * TJ * 16 + j * 16 + l15;
+          double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];     // general_utils.py:66-68
+          dsq = dsq < 0.0 ? 0.0 : dsq;                           // np.clip(.,0,inf), NaN kept
+          const double kv = kern_eval(pd, dsq);
+          if (MULTI) res[i][j][r] += kv;                          // kernel.py:493
+          else acc[i][j][r] = kv;
+        }
+      }
+    }
+    if (!MULTI) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) res[i][j] = acc[i][j];
+    }
+  }
+
+  // store
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const long col = n0 + wn * TJ * 16 + j * 16 + l15;
+        if (row < p.n1 && col < p.n2) {
+          double v = res[i][j][r];
+          if (MULTI && p.apply_outer) v = p.outer * v;            // kernel.py:494
+          if (p.symmetric && row == col) v += p.diag_add;         // gp_core.py:843
+          p.K[row * p.ldk + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- packing -----------------------------------------------------------------------------
+__global__ void k_pack_cols(const double* __restrict__ X, long n, long ldx, int P, int c_lo, int c_hi,
+                            const int* __restrict__ cols, const double* __restrict__ bw,
+                            double* __restrict__ Xp) {
+  const int w = c_hi - c_lo;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = n * w;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long row = idx / w;
+    const int pc = c_lo + (int)(idx - row * w);
+    const int c = cols[pc];
+    Xp[row * P + pc] = c >= 0 ? X[row * ldx + c] / bw[pc] : 0.0;    // kernel.py:181
+  }
+}
+
+// (X**2).sum(axis=1) with numpy's pairwise-sum order for rows of <= 128 elements
+__device__ double np_sumsq(const double* a, int n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += a[i] * a[i];
+    return res;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j] * a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j] * a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i] * a[i];
+  return res;
+}
+
+__global__ void k_pack_norms(const double* __restrict__ Xp, long n, int P, int n_parts_total,
+                             const PartDev* __restrict__ parts, const int* __restrict__ cols,
+                             int part_lo, int part_hi, double* __restrict__ Np) {
+  const int np = part_hi - part_lo;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = n * np;
+  if (idx >= total) return;
+  const long row = idx / np;
+  const int part = part_lo + (int)(idx - row * np);
+  const PartDev pd = parts[part];
+  int nreal = 0;
+  for (int c = 0; c < pd.kc; ++c) nreal += cols[pd.poff + c] >= 0;   // padding is trailing
+  Np[row * n_parts_total + part] = np_sumsq(Xp + row * P + pd.poff, nreal);
+}
+
+double factorial_d(int n) {
+  double r = 1.0;
+  for (int i = 2; i <= n; ++i) r *= (double)i;
+  return r;
+}
+
+int fill_part(PartDev& pd, int kind, double scale, double nu) {
+  pd.kind = kind;
+  pd.p = 0; pd.s8 = pd.s2 = pd.gfac = 0.0;
+  for (int i = 0; i < 8; ++i) pd.coeff[i] = 0.0;
+  if (kind == DFH_KERNEL_SE || kind == DFH_KERNEL_DIST) {
+    pd.scale_c = scale;
+    return DFH_OK;
+  }
+  // Matern: kernel.py:242-253, 259-270
+  double frac = fmod(nu, 1.0);
+  if (!(frac == 0.5) || nu < 0.5) {
+    dfh_set_error("Matern kernel: nu has to be p + 0.5 where p is an integer (got %g)", nu);
+    return DFH_ERR_BAD_ARG;
+  }
+  const int p = (int)nu;
+  if (p > 7) {
+    dfh_set_error("Matern kernel: nu = %g not supported (p <= 7)", nu);
+    return DFH_ERR_BAD_ARG;
+  }
+  pd.p = p;
+  for (int i = 0; i <= p; ++i)
+    pd.coeff[i] = factorial_d(p + i) / (factorial_d(i) * factorial_d(p - i));
+  pd.s8 = sqrt(8.0 * nu);
+  pd.s2 = sqrt(2.0 * nu);
+  pd.gfac = tgamma((double)p + 1.0) / tgamma(2.0 * p + 1.0);
+  // norm_constant = 1 / _eval_kernel_values_unnormalised(0)   (kernel.py:253)
+  double u0 = 0.0;
+  const double mult0 = pd.s8 * 0.0;
+  for (int i = 0; i <= p; ++i) u0 += pd.coeff[i] * pow(mult0, (double)(p - i));
+  u0 *= (pd.gfac * exp(-pd.s2 * 0.0));
+  const double norm_constant = 1.0 / u0;
+  pd.scale_c = scale * norm_constant;
+  return DFH_OK;
+}
+
+double part_value_at_zero(const PartDev& pd) {
+  // k_part(x, x): distance 0
+  if (pd.kind == DFH_KERNEL_SE) return pd.scale_c * exp(-0.0 / 2);
+  if (pd.kind == DFH_KERNEL_MATERN) {
+    double u = 0.0;
+    for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * pow(0.0, (double)(pd.p - i));
+    u *= (pd.gfac * exp(-pd.s2 * 0.0));
+    return pd.scale_c * u;
+  }
+  return 0.0;
+}
+
+int upload(dfh_ctx* ctx, KernDev* kd) {
+  DFH_HIP(hipMalloc(&kd->d_parts, sizeof(PartDev) * kd->parts.size()));
+  DFH_HIP(hipMalloc(&kd->d_cols, sizeof(int) * (kd->P ? kd->P : 1)));
+  DFH_HIP(hipMalloc(&kd->d_lcols, sizeof(int) * (kd->P ? kd->P : 1)));
+  DFH_HIP(hipMalloc(&kd->d_bw, sizeof(double) * (kd->P ? kd->P : 1)));
+  DFH_HIP(hipMemcpyAsync(kd->d_parts, kd->parts.data(), sizeof(PartDev) * kd->parts.size(), hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(kd->d_cols, kd->cols.data(), sizeof(int) * kd->P, hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(kd->d_lcols, kd->lcols.data(), sizeof(int) * kd->P, hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(kd->d_bw, kd->bw.data(), sizeof(double) * kd->P, hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+void add_part_cols(KernDev* kd, PartDev& pd, const int* cols, const double* bw, int ncols) {
+  pd.poff = kd->P;
+  pd.kc = (ncols + 3) & ~3;
+  for (int c = 0; c < pd.kc; ++c) {
+    kd->cols.push_back(c < ncols ? cols[c] : -1);
+    kd->lcols.push_back(c < ncols ? c : -1);
+    kd->bw.push_back(c < ncols ? bw[c] : 1.0);
+  }
+  kd->P += pd.kc;
+}
+
+}  // namespace
+
+int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* kd) {
+  DFH_ARG(k != nullptr && kd != nullptr);
+  DFH_ARG(k->dim >= 1);
+  kd->kind = k->kind; kd->dim = k->dim; kd->P = 0;
+  kd->parts.clear(); kd->cols.clear(); kd->lcols.clear(); kd->bw.clear();
+  if (k->kind == DFH_KERNEL_SE || k->kind == DFH_KERNEL_MATERN) {
+    DFH_ARG(k->bw != nullptr);
+    PartDev pd;
+    DFH_TRY(fill_part(pd, k->kind, k->scale, k->nu));
+    std::vector<int> ident(k->dim);
+    for (int i = 0; i < k->dim; ++i) ident[i] = i;
+    add_part_cols(kd, pd, ident.data(), k->bw, k->dim);
+    kd->parts.push_back(pd);
+    kd->multi = false; kd->outer_scale = 1.0;
+    kd->kxx = part_value_at_zero(pd);
+  } else if (k->kind == DFH_KERNEL_ADDITIVE) {
+    DFH_ARG(k->n_groups >= 1 && k->group_off && k->group_dims && k->sub_kind && k->sub_scale && k->sub_bw);
+    double acc = 0.0;
+    for (int g = 0; g < k->n_groups; ++g) {
+      const int lo = k->group_off[g], hi = k->group_off[g + 1];
+      DFH_ARG(hi > lo);
+      for (int c = lo; c < hi; ++c) DFH_ARG(k->group_dims[c] >= 0 && k->group_dims[c] < k->dim);
+      DFH_ARG(k->sub_kind[g] == DFH_KERNEL_SE || k->sub_kind[g] == DFH_KERNEL_MATERN);
+      PartDev pd;
+      DFH_TRY(fill_part(pd, k->sub_kind[g], k->sub_scale[g], k->sub_nu ? k->sub_nu[g] : 0.0));
+      add_part_cols(kd, pd, k->group_dims + lo, k->sub_bw + lo, hi - lo);
+      kd->parts.push_back(pd);
+      acc += part_value_at_zero(pd);          // result += kernel(...)   kernel.py:493
+    }
+    kd->multi = true; kd->outer_scale = k->scale;
+    kd->kxx = k->scale * acc;                 // kernel.py:494
+  } else {
+    dfh_set_error("unknown kernel kind %d", k->kind);
+    return DFH_ERR_BAD_ARG;
+  }
+  kd->n_parts = (int)kd->parts.size();
+  return upload(ctx, kd);
+}
+
+int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* kd) {
+  DFH_ARG(dim >= 1);
+  kd->kind = DFH_KERNEL_DIST; kd->dim = dim; kd->P = 0;
+  kd->parts.clear(); kd->cols.clear(); kd->lcols.clear(); kd->bw.clear();
+  PartDev pd;
+  DFH_TRY(fill_part(pd, DFH_KERNEL_DIST, 1.0, 0.0));
+  std::vector<int> ident(dim);
+  std::vector<double> ones(dim, 1.0);
+  for (int i = 0; i < dim; ++i) ident[i] = i;
+  add_part_cols(kd, pd, ident.data(), ones.data(), dim);
+  kd->parts.push_back(pd);
+  kd->multi = false; kd->outer_scale = 1.0; kd->kxx = 0.0;
+  kd->n_parts = 1;
+  return upload(ctx, kd);
+}
+
+void kerndev_free(KernDev* kd) {
+  if (!kd) return;
+  if (kd->d_parts) (void)hipFree(kd->d_parts);
+  if (kd->d_cols) (void)hipFree(kd->d_cols);
+  if (kd->d_lcols) (void)hipFree(kd->d_lcols);
+  if (kd->d_bw) (void)hipFree(kd->d_bw);
+  kd->d_parts = nullptr; kd->d_cols = nullptr; kd->d_lcols = nullptr; kd->d_bw = nullptr;
+}
+
+double kerndev_part_kxx(const KernDev& kd, int part) { return part_value_at_zero(kd.parts[part]); }
+
+int pack_scaled(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool pre_gathered,
+                const double* X, int64_t n, int64_t ldx, double* Xp, double* Np) {
+  if (n <= 0) return DFH_OK;
+  DFH_ARG(part_lo >= 0 && part_hi <= kd.n_parts && part_lo < part_hi);
+  DFH_ARG(!pre_gathered || part_hi == part_lo + 1);
+  const int c_lo = kd.parts[part_lo].poff;
+  const int c_hi = kd.parts[part_hi - 1].poff + kd.parts[part_hi - 1].kc;
+  const int64_t total = n * (c_hi - c_lo);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  // pre-gathered input: local column index c - poff ; d_lcols holds that mapping
+  hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, (long)n,
+                     (long)ldx, kd.P, c_lo, c_hi, pre_gathered ? kd.d_lcols : kd.d_cols, kd.d_bw, Xp);
+  DFH_LAUNCH_CHECK();
+  const int64_t tn = n * (part_hi - part_lo);
+  hipLaunchKernelGGL(k_pack_norms, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, ctx->stream,
+                     Xp, (long)n, kd.P, kd.n_parts, kd.d_parts, kd.d_cols, part_lo, part_hi, Np);
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
+
+int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool apply_outer,
+                   const double* Xp1, const double* Np1, int64_t n1, const double* Xp2,
+                   const double* Np2, int64_t n2, bool symmetric, double diag_add, double* K,
+                   int64_t ldk) {
+  if (n1 <= 0 || n2 <= 0) return DFH_OK;
+  DFH_ARG(n1 < (1LL << 31) && n2 < (1LL << 31));
+  KmArgs a;
+  a.Xp1 = Xp1; a.Np1 = Np1; a.Xp2 = Xp2; a.Np2 = Np2;
+  a.n1 = (int)n1; a.n2 = (int)n2; a.P = kd.P; a.n_parts_total = kd.n_parts;
+  a.parts = kd.d_parts; a.part_lo = part_lo; a.part_hi = part_hi;
+  a.outer = kd.outer_scale; a.apply_outer = apply_outer ? 1 : 0;
+  a.symmetric = symmetric ? 1 : 0; a.diag_add = diag_add;
+  a.K = K; a.ldk = ldk;
+  const bool multi = kd.multi;
+  static bool attr_set = false;
+  constexpr int SM4 = ((KM_BM + 128) * KM_KP + KM_BM + 128) * 8;
+  constexpr int SM2 = ((KM_BM + 64) * KM_KP + KM_BM + 64) * 8;
+  if (!attr_set) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<4, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SM4));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
+    attr_set = true;
+  }
+  const int64_t rows_per_launch = 65535LL * KM_BM;
+  for (int64_t r0 = 0; r0 < n1; r0 += rows_per_launch) {
+    const int64_t rr = n1 - r0 < rows_per_launch ? n1 - r0 : rows_per_launch;
+    KmArgs b = a;
+    b.Xp1 = Xp1 + r0 * kd.P; b.Np1 = Np1 + r0 * kd.n_parts; b.n1 = (int)rr; b.K = K + r0 * ldk;
+    if (r0 != 0) b.symmetric = 0;    // only reachable for n1 > 8M rows; diagonal handled in slab 0
+    if (multi) {
+      dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((rr + KM_BM - 1) / KM_BM));
+      hipLaunchKernelGGL((kernmat_kernel<2, true>), grid, dim3(256), SM2, ctx->stream, b);
+    } else {
+      dim3 grid((unsigned)((n2 + 127) / 128), (unsigned)((rr + KM_BM - 1) / KM_BM));
+      hipLaunchKernelGGL((kernmat_kernel<4, false>), grid, dim3(256), SM4, ctx->stream, b);
+    }
+    DFH_LAUNCH_CHECK();
+  }
+  return DFH_OK;
+}

@@ -1,0 +1,408 @@
+"""Thin Python layer over the C-ABI: one Engine per GPU (dfh_ctx) and the fitted-GP handle.
+
+Everything numeric happens in libdfhip.so; this module only marshals NumPy arrays and maps
+status codes to the exceptions the reference raises at the same point.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ACQ_EI, ACQ_MEAN, ACQ_PI, ACQ_STD, ACQ_TTEI, ACQ_UCB, GET_ALPHA, GET_K, GET_L,
+                   INT32_MIN, KERNEL_ADDITIVE, KERNEL_MATERN, KERNEL_SE, KernelDesc, check)
+
+ACQ_IDS = {'mean': ACQ_MEAN, 'ucb': ACQ_UCB, 'ei': ACQ_EI, 'pi': ACQ_PI, 'ttei': ACQ_TTEI,
+           'std': ACQ_STD}
+
+
+def _f64(a):
+  return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+  """ void* of a NumPy array, a DeviceArray, or None. """
+  if a is None:
+    return None
+  if isinstance(a, DeviceArray):
+    return a.ptr
+  return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceArray(object):
+  """ A float64 buffer resident in HBM (dfh_malloc). Passed to the C-ABI by pointer. """
+
+  def __init__(self, engine, shape):
+    self.engine = engine
+    self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+    self.size = int(np.prod(self.shape))
+    p = C.c_void_p()
+    check(engine.lib.dfh_malloc(engine.ctx, self.size * 8, C.byref(p)))
+    self.ptr = p
+
+  def upload(self, host):
+    host = _f64(host)
+    assert host.size == self.size
+    check(self.engine.lib.dfh_memcpy_h2d(self.engine.ctx, self.ptr, _ptr(host), self.size * 8))
+    return self
+
+  def download(self):
+    out = np.empty(self.shape, dtype=np.float64)
+    check(self.engine.lib.dfh_memcpy_d2h(self.engine.ctx, _ptr(out), self.ptr, self.size * 8))
+    return out
+
+  def offset(self, n_elems):
+    """ A raw pointer n_elems doubles into the buffer (no ownership). """
+    return C.c_void_p(self.ptr.value + 8 * int(n_elems))
+
+  def free(self):
+    if self.ptr is not None and self.engine.ctx is not None:
+      self.engine.lib.dfh_free(self.engine.ctx, self.ptr)
+    self.ptr = None
+
+  def __del__(self):
+    try:
+      self.free()
+    except Exception:     # pylint: disable=broad-except
+      pass
+
+
+class KernelSpec(object):
+  """ Host-side description of a Euclidean kernel, convertible to struct dfh_kernel_desc.
+      kind: 'se' | 'matern' | 'additive'. """
+
+  def __init__(self, kind, dim, scale, bandwidths=None, nu=0.0, groups=None, sub_kinds=None,
+               sub_scales=None, sub_nus=None, sub_bandwidths=None):
+    self.kind = kind
+    self.dim = int(dim)
+    self.scale = float(scale)
+    self.nu = float(nu) if nu is not None else 0.0
+    self.bandwidths = None if bandwidths is None else _f64(np.ravel(bandwidths))
+    self.groups = groups
+    self.sub_kinds = sub_kinds
+    self.sub_scales = sub_scales
+    self.sub_nus = sub_nus
+    self.sub_bandwidths = sub_bandwidths
+    self._keep = []
+
+  def to_desc(self):
+    """ Builds the ctypes struct (keeps the backing arrays alive on self). """
+    d = KernelDesc()
+    self._keep = []
+    if self.kind in ('se', 'matern'):
+      d.kind = KERNEL_SE if self.kind == 'se' else KERNEL_MATERN
+      d.dim = self.dim
+      d.scale = self.scale
+      d.nu = self.nu
+      if self.bandwidths is None or self.bandwidths.size != self.dim:
+        raise ValueError('Dimension of dim_bandwidths should be the same as dimension.')
+      bw = _f64(self.bandwidths)
+      self._keep.append(bw)
+      d.bw = bw.ctypes.data_as(_lib.c_double_p)
+      d.n_groups = 0
+    elif self.kind == 'additive':
+      d.kind = KERNEL_ADDITIVE
+      d.dim = self.dim
+      d.scale = self.scale
+      ng = len(self.groups)
+      off = np.zeros(ng + 1, dtype=np.int32)
+      off[1:] = np.cumsum([len(g) for g in self.groups])
+      dims = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int32).ravel()
+                                                  for g in self.groups]), dtype=np.int32)
+      kinds = np.ascontiguousarray([KERNEL_SE if k == 'se' else KERNEL_MATERN
+                                    for k in self.sub_kinds], dtype=np.int32)
+      scales = _f64(self.sub_scales)
+      nus = _f64(self.sub_nus if self.sub_nus is not None else np.zeros(ng))
+      bws = _f64(np.concatenate([_f64(np.ravel(b)) for b in self.sub_bandwidths]))
+      if bws.size != dims.size:
+        raise ValueError('Group bandwidths do not match the group dimensions.')
+      self._keep += [off, dims, kinds, scales, nus, bws]
+      d.n_groups = ng
+      d.group_off = off.ctypes.data_as(_lib.c_int32_p)
+      d.group_dims = dims.ctypes.data_as(_lib.c_int32_p)
+      d.sub_kind = kinds.ctypes.data_as(_lib.c_int32_p)
+      d.sub_scale = scales.ctypes.data_as(_lib.c_double_p)
+      d.sub_nu = nus.ctypes.data_as(_lib.c_double_p)
+      d.sub_bw = bws.ctypes.data_as(_lib.c_double_p)
+    else:
+      raise ValueError('Unidentified kernel type %s.' % (self.kind))
+    return d
+
+
+class Engine(object):
+  """ One MI355X: a dfh_ctx (stream + workspaces). """
+
+  def __init__(self, device=None):
+    self.lib = _lib.load()
+    self.ctx = None
+    if device is None:
+      device = int(os.environ.get('DFH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    if _lib.device_count() == 0:
+      raise _lib.DfhipError('No HIP device visible: dragonfly_amd needs an MI355X (gfx950); '
+                            'there is no CPU fallback.')
+    ctx = C.c_void_p()
+    check(self.lib.dfh_ctx_create(int(device), C.byref(ctx)))
+    self.ctx = ctx
+    self.device = int(device)
+
+  def close(self):
+    if self.ctx is not None:
+      self.lib.dfh_ctx_destroy(self.ctx)
+      self.ctx = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:     # pylint: disable=broad-except
+      pass
+
+  # -- plumbing --------------------------------------------------------------------------
+  def name(self):
+    buf = C.create_string_buffer(256)
+    check(self.lib.dfh_device_name(self.ctx, buf, 256))
+    return buf.value.decode()
+
+  def sync(self):
+    check(self.lib.dfh_sync(self.ctx))
+
+  def to_device(self, host):
+    host = _f64(host)
+    return DeviceArray(self, host.shape).upload(host)
+
+  def empty(self, shape):
+    return DeviceArray(self, shape)
+
+  def timer_begin(self):
+    check(self.lib.dfh_timer_begin(self.ctx))
+
+  def timer_end(self):
+    ms = C.c_double(0)
+    check(self.lib.dfh_timer_end(self.ctx, C.byref(ms)))
+    return ms.value
+
+  def timings(self, enable=True):
+    """ Returns the section timings (ms) accumulated since the last call and resets them. """
+    arr = (C.c_double * 8)()
+    check(self.lib.dfh_ctx_timings(self.ctx, 1 if enable else 0, arr))
+    return dict(zip(_lib.T_NAMES, list(arr)))
+
+  # -- building blocks ---------------------------------------------------------------------
+  def kernel_matrix(self, spec, X1, X2=None, diag_add=0.0, out=None):
+    X1h = X1 if isinstance(X1, DeviceArray) else _f64(X1)
+    n1 = X1h.shape[0]
+    if X2 is None:
+      X2h, n2 = None, n1
+    else:
+      X2h = X2 if isinstance(X2, DeviceArray) else _f64(X2)
+      n2 = X2h.shape[0]
+    if out is None:
+      out = np.zeros((n1, n2), dtype=np.float64)
+    if n1 == 0 or n2 == 0:
+      return out
+    desc = spec.to_desc()
+    check(self.lib.dfh_kernel_matrix(self.ctx, C.byref(desc), _ptr(X1h), n1, _ptr(X2h), n2,
+                                     float(diag_add), _ptr(out)))
+    return out
+
+  def dist_squared(self, X1, X2):
+    X1 = _f64(X1)
+    X2 = _f64(X2)
+    n1, d1 = X1.shape
+    n2, d2 = X2.shape
+    if d1 != d2:
+      raise ValueError('Second dimension of X1 and X2 should be equal.')
+    out = np.zeros((n1, n2), dtype=np.float64)
+    if n1 == 0 or n2 == 0:
+      return out
+    check(self.lib.dfh_dist_squared(self.ctx, _ptr(X1), n1, _ptr(X2), n2, d1, _ptr(out)))
+    return out
+
+  def gemm(self, A, B, C_in=None, alpha=1.0, beta=0.0, transb=False, lower_only=False,
+           shape=None, out=None):
+    """ out = beta*C + alpha*A*op(B). Host arrays or (with shape=(M,N,K)) DeviceArrays. """
+    if shape is None:
+      A = _f64(A)
+      B = _f64(B)
+      M, K = A.shape
+      N = B.shape[1] if transb else B.shape[0]
+      if out is None:
+        out = np.zeros((M, N)) if C_in is None else _f64(C_in).copy()
+      lda, ldb, ldc = K, (N if transb else K), N
+    else:
+      M, N, K = shape
+      lda, ldb, ldc = K, (N if transb else K), N
+      assert out is not None
+    check(self.lib.dfh_gemm(self.ctx, 1 if transb else 0, M, N, K, float(alpha), _ptr(A), lda,
+                            _ptr(B), ldb, float(beta), _ptr(out), ldc, 1 if lower_only else 0))
+    return out
+
+  def cholesky(self, M):
+    """ numpy.linalg.cholesky semantics (raises LinAlgError when not positive definite). """
+    if isinstance(M, DeviceArray):
+      n = M.shape[0]
+      piv = C.c_int64(0)
+      check(self.lib.dfh_cholesky(self.ctx, M.ptr, n, C.byref(piv)))
+      return M
+    L = _f64(M).copy()
+    n = L.shape[0]
+    piv = C.c_int64(0)
+    check(self.lib.dfh_cholesky(self.ctx, _ptr(L), n, C.byref(piv)))
+    return L
+
+  def stable_cholesky(self, M, return_power=False):
+    M = _f64(M)
+    n = M.shape[0]
+    L = np.empty_like(M)
+    jp = C.c_int32(INT32_MIN)
+    check(self.lib.dfh_stable_cholesky(self.ctx, _ptr(M), n, _ptr(L), C.byref(jp)))
+    if return_power:
+      return L, (None if jp.value == INT32_MIN else jp.value)
+    return L
+
+  def solve_triangular(self, L_lower, b, upper=False):
+    """ Solves L x = b (upper=False) or L^T x = b (upper=True) for lower-triangular L. """
+    L_lower = _f64(L_lower)
+    b = _f64(b)
+    n = L_lower.shape[0]
+    nrhs = 1 if b.ndim == 1 else b.shape[1]
+    x = np.empty_like(b)
+    check(self.lib.dfh_solve_triangular(self.ctx, _ptr(L_lower), n, 1 if upper else 0, _ptr(b),
+                                        nrhs, _ptr(x)))
+    return x
+
+  # -- GP ----------------------------------------------------------------------------------
+  def gp_fit(self, spec, X, y_centred, noise_var, allow_jitter=True):
+    """ Returns a FittedGP (posterior resident in HBM). """
+    return FittedGP(self, spec, X, y_centred, noise_var, allow_jitter)
+
+
+class FittedGP(object):
+  """ Handle of a dfh_gp: K, L, alpha live on the device. """
+
+  def __init__(self, engine, spec, X, y_centred, noise_var, allow_jitter=True):
+    self.engine = engine
+    self.handle = None
+    self.spec = spec
+    Xh = X if isinstance(X, DeviceArray) else _f64(X)
+    yh = y_centred if isinstance(y_centred, DeviceArray) else _f64(y_centred)
+    n, d = Xh.shape
+    self.n, self.d = int(n), int(d)
+    desc = spec.to_desc()
+    h = C.c_void_p()
+    lml = C.c_double(0)
+    jp = C.c_int32(INT32_MIN)
+    check(engine.lib.dfh_gp_fit(engine.ctx, C.byref(desc), _ptr(Xh), n, d, _ptr(yh),
+                                float(noise_var), 0 if allow_jitter else _lib.FIT_NO_JITTER,
+                                C.byref(h), C.byref(lml), C.byref(jp)))
+    self.handle = h
+    self.lml = lml.value
+    self.jitter_power = None if jp.value == INT32_MIN else jp.value
+
+  def free(self):
+    if self.handle is not None:
+      self.engine.lib.dfh_gp_free(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.free()
+    except Exception:     # pylint: disable=broad-except
+      pass
+
+  def _get(self, what, shape):
+    out = np.empty(shape, dtype=np.float64)
+    check(self.engine.lib.dfh_gp_get(self.handle, what, _ptr(out)))
+    return out
+
+  def get_L(self):
+    return self._get(GET_L, (self.n, self.n))
+
+  def get_alpha(self):
+    return self._get(GET_ALPHA, (self.n,))
+
+  def get_K(self):
+    return self._get(GET_K, (self.n, self.n))
+
+  @staticmethod
+  def _rows(Xs):
+    if isinstance(Xs, DeviceArray):
+      return Xs, Xs.shape[0]
+    Xs = _f64(Xs)
+    return Xs, Xs.shape[0]
+
+  def predict(self, Xs, want_std=True, X_halluc=None):
+    """ (K(Xs,X) alpha, posterior std) -- the caller adds the mean function. """
+    Xs, m = self._rows(Xs)
+    mu = np.empty(m)
+    sd = np.empty(m) if want_std else None
+    Xh, q = (None, 0) if X_halluc is None or len(X_halluc) == 0 else self._rows(X_halluc)
+    check(self.engine.lib.dfh_gp_predict(self.handle, _ptr(Xs), m, _ptr(Xh), q, _ptr(mu), _ptr(sd)))
+    return mu, sd
+
+  def predict_covar(self, Xs, X_halluc=None):
+    Xs, m = self._rows(Xs)
+    mu = np.empty(m)
+    cov = np.empty((m, m))
+    Xh, q = (None, 0) if X_halluc is None or len(X_halluc) == 0 else self._rows(X_halluc)
+    check(self.engine.lib.dfh_gp_predict_covar(self.handle, _ptr(Xs), m, _ptr(Xh), q, _ptr(mu),
+                                               _ptr(cov)))
+    return mu, cov
+
+  def acq_argmax(self, acq, Xs, params=(0.0, 0.0), mean_const=0.0, mean_vals=None, X_halluc=None,
+                 return_vals=False):
+    """ Fused posterior + acquisition + arg-max. Returns (best_val, best_idx[, vals]). """
+    Xs, m = self._rows(Xs)
+    p = (C.c_double * 2)(float(params[0]), float(params[1]) if len(params) > 1 else 0.0)
+    vals = np.empty(m) if return_vals else None
+    mv = None if mean_vals is None else (mean_vals if isinstance(mean_vals, DeviceArray)
+                                         else _f64(mean_vals))
+    Xh, q = (None, 0) if X_halluc is None or len(X_halluc) == 0 else self._rows(X_halluc)
+    bv = C.c_double(0)
+    bi = C.c_int64(-1)
+    check(self.engine.lib.dfh_gp_acq_argmax(self.handle, ACQ_IDS[acq], p, _ptr(Xs), m, _ptr(Xh), q,
+                                            float(mean_const), _ptr(mv), _ptr(vals), C.byref(bv),
+                                            C.byref(bi)))
+    if return_vals:
+      return bv.value, bi.value, vals
+    return bv.value, bi.value
+
+  def thompson(self, Xs, U, block=4096, mean_const=0.0, mean_vals=None, return_samples=False):
+    """ Blocked-joint Thompson sample over the candidates. Returns (best_val, best_idx[, samples,
+        jitter_powers]). """
+    Xs, m = self._rows(Xs)
+    Uh = U if isinstance(U, DeviceArray) else _f64(np.ravel(U))
+    block = int(min(block, m))
+    nblk = (m + block - 1) // block
+    samples = np.empty(m) if return_samples else None
+    jps = (C.c_int32 * nblk)()
+    mv = None if mean_vals is None else (mean_vals if isinstance(mean_vals, DeviceArray)
+                                         else _f64(mean_vals))
+    bv = C.c_double(0)
+    bi = C.c_int64(-1)
+    check(self.engine.lib.dfh_gp_ts(self.handle, _ptr(Xs), m, block, _ptr(Uh), float(mean_const),
+                                    _ptr(mv), _ptr(samples), C.byref(bv), C.byref(bi), jps))
+    if return_samples:
+      return bv.value, bi.value, samples, [None if j == INT32_MIN else j for j in jps]
+    return bv.value, bi.value
+
+  def add_ucb_group(self, group, beta, Xg, return_vals=False):
+    Xg, m = self._rows(Xg)
+    vals = np.empty(m) if return_vals else None
+    bv = C.c_double(0)
+    bi = C.c_int64(-1)
+    check(self.engine.lib.dfh_gp_add_ucb_group(self.handle, int(group), float(beta), _ptr(Xg), m,
+                                               _ptr(vals), C.byref(bv), C.byref(bi)))
+    if return_vals:
+      return bv.value, bi.value, vals
+    return bv.value, bi.value
+
+
+_default_engine = None
+
+
+def get_engine():
+  """ The process-wide engine (one process per GPU; device = LOCAL_RANK / DFH_DEVICE). """
+  global _default_engine
+  if _default_engine is None:
+    _default_engine = Engine()
+  return _default_engine

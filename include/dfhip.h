@@ -1,0 +1,214 @@
+/*
+ * dfhip.h -- C-ABI of libdfhip.so, the MI355X (gfx950) GP-surrogate + acquisition engine
+ * that sits under Dragonfly's GP hot path.
+ *
+ * The reference (dragonfly 0.1.7, /root/reference) is pure Python/NumPy/SciPy and has no
+ * FFI of its own; the seams are Python class boundaries.  Every entry
+ * point below names the reference function(s) it replaces (paths relative to the
+ * reference root).  The Python host side in dragonfly_amd/ binds these with ctypes
+ * (dragonfly_amd/_lib.py); INTEGRATION.md shows the stub a Dragonfly maintainer would add.
+ *
+ * Conventions
+ *   - All matrices are row-major (NumPy C order) float64; indices are int64.
+ *   - Every `const double*` / `double*` data argument may be a HOST pointer or a DEVICE
+ *     pointer obtained from dfh_malloc(); the library detects which (hipPointerGetAttributes)
+ *     and stages host buffers itself.  Scalars returned through pointers are host memory.
+ *   - Return value: DFH_OK, or an error code; dfh_last_error() gives the text (thread local).
+ *   - Calls on one dfh_ctx are serialised by the caller (the reference is single threaded).
+ *   - No callbacks into the host language.  Not fork-safe after the first dfh_ctx_create().
+ */
+#ifndef DFHIP_H
+#define DFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFH_ABI_VERSION 1
+
+/* ---- status codes --------------------------------------------------------------------- */
+#define DFH_OK            0
+#define DFH_ERR_NOT_PD    1  /* Cholesky met a non-positive pivot (numpy LinAlgError analogue;
+                                dragonfly/utils/general_utils.py:178,190)                    */
+#define DFH_ERR_BAD_ARG   2  /* ValueError analogue                                          */
+#define DFH_ERR_HIP       3  /* HIP runtime error, see dfh_last_error()                      */
+#define DFH_ERR_JITTER    4  /* jitter ladder exhausted (ValueError at general_utils.py:200) */
+
+/* ---- kernel description ---------------------------------------------------------------- */
+#define DFH_KERNEL_SE       0 /* dragonfly/gp/kernel.py:132 SEKernel                         */
+#define DFH_KERNEL_MATERN   1 /* dragonfly/gp/kernel.py:225 MaternKernel, nu in {.5,1.5,2.5} */
+#define DFH_KERNEL_ADDITIVE 2 /* dragonfly/gp/kernel.py:461 AdditiveKernel over SE/Matern    */
+
+/* One Euclidean kernel.  For SE / MATERN: `dim`, `scale`, `nu`, `bw[dim]` (dim_bandwidths).
+ * For ADDITIVE: `scale` is the outer scale, and the n_groups sub-kernels are described by the
+ * flattened arrays: group g covers input columns group_dims[group_off[g] .. group_off[g+1])
+ * with bandwidths sub_bw[group_off[g] .. group_off[g+1]) , kind sub_kind[g], scale
+ * sub_scale[g], smoothness sub_nu[g].  All pointers are HOST pointers, read during the call. */
+typedef struct dfh_kernel_desc {
+  int32_t kind;
+  int32_t dim;            /* input dimension d (number of columns of X)                      */
+  double  scale;
+  double  nu;             /* MATERN only                                                     */
+  const double*  bw;      /* [dim]   (SE / MATERN)                                           */
+  int32_t n_groups;       /* ADDITIVE only                                                   */
+  const int32_t* group_off;   /* [n_groups+1]                                                */
+  const int32_t* group_dims;  /* [group_off[n_groups]] column indices                        */
+  const int32_t* sub_kind;    /* [n_groups] DFH_KERNEL_SE | DFH_KERNEL_MATERN                */
+  const double*  sub_scale;   /* [n_groups]                                                  */
+  const double*  sub_nu;      /* [n_groups]                                                  */
+  const double*  sub_bw;      /* [group_off[n_groups]]                                       */
+} dfh_kernel_desc;
+
+/* ---- acquisitions ---------------------------------------------------------------------- */
+#define DFH_ACQ_MEAN  0 /* mu                                                                */
+#define DFH_ACQ_UCB   1 /* mu + p0*sd            p0 = beta_th   (gpb_acquisitions.py:211-223)*/
+#define DFH_ACQ_EI    2 /* sd*(z*Phi(z)+phi(z)), z=(mu-p0)/sd, p0 = curr_best   (:247-261)   */
+#define DFH_ACQ_PI    3 /* Phi((mu-p0)/sd)                                      (:230-239)   */
+#define DFH_ACQ_TTEI  4 /* c*(z*Phi(z)+phi(z)), c=sqrt(p1^2+sd^2), z=(mu-p0)/c  (:269-280)   */
+#define DFH_ACQ_STD   5 /* sd                                                                */
+
+typedef struct dfh_ctx dfh_ctx;   /* one per device: stream, workspaces                      */
+typedef struct dfh_gp  dfh_gp;    /* a fitted GP resident in HBM                              */
+
+/* ---- context / memory ------------------------------------------------------------------ */
+int  dfh_abi_version(void);
+int  dfh_device_count(int* count);
+int  dfh_ctx_create(int device, dfh_ctx** out);
+void dfh_ctx_destroy(dfh_ctx* ctx);
+int  dfh_sync(dfh_ctx* ctx);
+const char* dfh_last_error(void);
+int  dfh_device_name(dfh_ctx* ctx, char* buf, size_t buflen);
+
+int  dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);
+int  dfh_free(dfh_ctx* ctx, void* dptr);
+int  dfh_memcpy_h2d(dfh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  dfh_memcpy_d2h(dfh_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* HIP-event timing on the context's stream (the stream every kernel is launched on).
+ * dfh_timer_begin records an event; dfh_timer_end records a second one, waits for it and
+ * returns the elapsed milliseconds.  Used by bench.py for the roofline numbers.            */
+int  dfh_timer_begin(dfh_ctx* ctx);
+int  dfh_timer_end(dfh_ctx* ctx, double* ms);
+
+/* ---- linear-algebra building blocks (exposed for tests and for the drop-in utils) ------- */
+
+/* K_out[n1 x n2] = kernel(X1[n1 x d], X2[n2 x d]).  X2 == NULL means X2 = X1.
+ * Replaces Kernel.evaluate -> _child_evaluate (dragonfly/gp/kernel.py:76-89,171-181,292-299,
+ * 484-494) including dist_squared's clip at 0 (dragonfly/utils/general_utils.py:58-70).
+ * diag_add is added to K_out[i][i] (only meaningful when X2 == NULL; fuses
+ * `K + noise_var*np.eye(n)`, dragonfly/gp/gp_core.py:843).                                  */
+int dfh_kernel_matrix(dfh_ctx* ctx, const dfh_kernel_desc* k,
+                      const double* X1, int64_t n1, const double* X2, int64_t n2,
+                      double diag_add, double* K_out);
+
+/* Squared Euclidean distances, dragonfly/utils/general_utils.py:58-70 (dist_squared).      */
+int dfh_dist_squared(dfh_ctx* ctx, const double* X1, int64_t n1, const double* X2,
+                     int64_t n2, int64_t d, double* D_out);
+
+/* C[M x N] = beta*C + alpha * A[M x K] * op(B), op(B) = B^T with B[N x K] (transb = 0) or
+ * B[K x N] (transb = 1); fp64 MFMA tiles.  The dense contraction np.dot / dgemm stands for
+ * at general_utils.py:68, gp_core.py:174,181.  lower_only != 0 computes only tiles that
+ * intersect the lower triangle (SYRK use).                                                   */
+int dfh_gemm(dfh_ctx* ctx, int transb, int64_t M, int64_t N, int64_t K, double alpha,
+             const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+             double* C, int64_t ldc, int lower_only);
+
+/* In-place lower Cholesky of the row-major n x n matrix A (lda = n); the strict upper
+ * triangle is zeroed (numpy.linalg.cholesky semantics, general_utils.py:178).
+ * Returns DFH_ERR_NOT_PD if a pivot is <= 0 or NaN; *info_pivot = 1-based index (0 if ok).   */
+int dfh_cholesky(dfh_ctx* ctx, double* A, int64_t n, int64_t* info_pivot);
+
+/* stable_cholesky (general_utils.py:166-204): factor M; on failure retry M + 10^p*max(diag M)
+ * for p = -11..4.  M_in is preserved, L_out (n x n) receives the factor.
+ * *jitter_power = INT32_MIN when no jitter was needed.  DFH_ERR_JITTER if p reaches 5.       */
+int dfh_stable_cholesky(dfh_ctx* ctx, const double* M_in, int64_t n, double* L_out,
+                        int32_t* jitter_power);
+
+/* Solve L x = b (upper = 0) or L^T x = b (upper = 1) with L lower-triangular n x n row major;
+ * b is n x nrhs row-major (nrhs >= 1).  Replaces solve_lower_triangular /
+ * solve_upper_triangular (general_utils.py:208-221) as used at gp_core.py:162-163,180.       */
+int dfh_solve_triangular(dfh_ctx* ctx, const double* L, int64_t n, int upper,
+                         const double* b, int64_t nrhs, double* x_out);
+
+/* ---- GP fit / posterior ----------------------------------------------------------------- */
+#define DFH_FIT_NO_JITTER 1  /* report DFH_ERR_NOT_PD instead of running the jitter ladder    */
+
+/* GP.build_posterior (gp_core.py:155-163) + _get_cholesky_decomp 'guaranteed_psd'
+ * (gp_core.py:841-844) + compute_log_marginal_likelihood (gp_core.py:222-227):
+ *   K = kernel(X,X); L = stable_cholesky(K + noise_var I); alpha = L^T \ (L \ y_centred);
+ *   lml = -1/2 y^T alpha - sum log L_ii - n/2 log 2 pi.
+ * X[n x d], y_centred[n] = Y - mean_func(X) (the mean function is a host callable in the
+ * reference, gp_core.py:161, so it is evaluated by the caller).                             */
+int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* X, int64_t n, int64_t d,
+               const double* y_centred, double noise_var, int flags, dfh_gp** out,
+               double* lml, int32_t* jitter_power);
+int dfh_gp_free(dfh_gp* gp);
+
+#define DFH_GET_L        0   /* n x n lower factor (GP.L)                                     */
+#define DFH_GET_ALPHA    1   /* n (GP.alpha)                                                  */
+#define DFH_GET_K        2   /* n x n kernel matrix without noise (GP.K_trtr_wo_noise)        */
+int dfh_gp_get(dfh_gp* gp, int what, double* out);
+int64_t dfh_gp_n(dfh_gp* gp);
+
+/* GP.eval(X_test, 'std') without the mean function (gp_core.py:165-190):
+ *   mu_out[m]  = K(Xs, X) alpha           (caller adds mean_func(Xs))
+ *   sd_out[m]  = sqrt(k(x,x) - ||L \ k(X,x)||^2), no clipping -> NaN for negative variance
+ * sd_out may be NULL (uncert_form='none').  Only the diagonal of the posterior covariance
+ * is formed (the reference forms the m x m matrix and takes its diagonal).
+ * If Xh != NULL (q rows) the variance is that of the GP augmented with q hallucinated
+ * observations at Xh (eval_with_hallucinated_observations, gp_core.py:192-220); the mean
+ * is unchanged.                                                                             */
+int dfh_gp_predict(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
+                   double* mu_out, double* sd_out);
+
+/* Full posterior covariance GP.eval(X_test,'covar') (gp_core.py:179-184): cov_out[m x m].  */
+int dfh_gp_predict_covar(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
+                         double* mu_out, double* cov_out);
+
+/* Fused posterior + acquisition + arg-max over m candidates (gpb_acquisitions.py:215-280
+ * closures + oper_utils.random_maximise's `obj_vals.argmax()`, oper_utils.py:73).
+ *   mean_const : constant prior mean added to mu (fitter GPs use a constant mean,
+ *                gp_core.py:527-530); if mean_vals (optional, [m]) is given it is used instead
+ *                (arbitrary mean functions are host callables evaluated by the caller).
+ *   params     : acquisition parameters p0, p1 (see DFH_ACQ_*).
+ *   vals_out   : optional [m] acquisition values.
+ *   best_val / best_idx : numpy argmax semantics -- first NaN wins, else first maximum.     */
+int dfh_gp_acq_argmax(dfh_gp* gp, int acq, const double* params, const double* Xs, int64_t m,
+                      const double* Xh, int64_t q, double mean_const, const double* mean_vals,
+                      double* vals_out, double* best_val, int64_t* best_idx);
+
+/* Blocked-joint Thompson sampling (asy_ts -> GP.draw_samples -> draw_gaussian_samples,
+ * gpb_acquisitions.py:119-127, gp_core.py:250-254, general_utils.py:224-232).
+ * Candidates are processed in blocks of `block` rows; inside a block the draw is the exact
+ * joint draw  s = mu + stable_cholesky(Sigma_block) u ; blocks are independent.  With
+ * block >= m this is literally gp.draw_samples(1, Xs).  U[m] are the standard normals
+ * (np.random.normal in the reference) supplied by the caller.
+ * samples_out optional [m]; jitter_powers_out optional [ceil(m/block)].                     */
+int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block, const double* U,
+              double mean_const, const double* mean_vals, double* samples_out,
+              double* best_val, int64_t* best_idx, int32_t* jitter_powers_out);
+
+/* add-UCB per-group posterior (gpb_acquisitions.py:139-189): for additive-kernel GPs,
+ * group g's acquisition over its own candidate set Xg[m x |g|]:
+ *   mu_g = scale*k_g(Xg, X[:,g]) alpha ; sd_g from the shared L ; val = mu_g + beta*sd_g.   */
+int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, const double* Xg, int64_t m,
+                         double* vals_out, double* best_val, int64_t* best_idx);
+
+/* ---- timing of the last call's dominant kernels (HIP events, ms) ------------------------- */
+#define DFH_T_KERNMAT  0   /* training kernel-matrix build                                   */
+#define DFH_T_CHOL     1   /* blocked Cholesky (all launches)                                */
+#define DFH_T_SOLVE    2   /* alpha solves + lml                                             */
+#define DFH_T_CROSS    3   /* cross kernel matrices                                          */
+#define DFH_T_TRSM     4   /* posterior triangular solves                                    */
+#define DFH_T_ACQ      5   /* variance + acquisition + arg-max                               */
+#define DFH_T_TS       6   /* TS block covariance + cholesky + sample                        */
+#define DFH_T_COUNT    8
+int dfh_ctx_timings(dfh_ctx* ctx, int enable, double* ms_out /* [DFH_T_COUNT] or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFHIP_H */

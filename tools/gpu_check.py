@@ -1,0 +1,344 @@
+"""Bring-up checks on a real MI355X: each stage runs in its own process (a faulting kernel must
+not hide the later stages).  Usage:  python tools/gpu_check.py [stage ...]   (no args = all)
+Writes a log per stage under gpurun_out/check/.
+"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def relerr(a, b):
+  a = np.asarray(a, dtype=float)
+  b = np.asarray(b, dtype=float)
+  den = np.max(np.abs(b))
+  return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def stage_gemm():
+  from dragonfly_amd.engine import Engine
+  eng = Engine()
+  print(eng.name())
+  rs = np.random.RandomState(0)
+  ok = True
+  for (M, N, K) in [(16, 16, 4), (128, 128, 16), (128, 128, 64), (256, 384, 48), (130, 70, 33),
+                    (64, 64, 64), (1, 5, 3), (300, 129, 17), (512, 512, 512)]:
+    A = rs.randn(M, K)
+    B = rs.randn(N, K)
+    C0 = rs.randn(M, N)
+    ref = 0.5 * C0 + 1.5 * A.dot(B.T)
+    got = eng.gemm(A, B, C0, alpha=1.5, beta=0.5)
+    e = relerr(got, ref)
+    Bn = rs.randn(K, N)
+    ref2 = -A.dot(Bn)
+    got2 = eng.gemm(A, Bn, None, alpha=-1.0, beta=0.0, transb=True)
+    e2 = relerr(got2, ref2)
+    print('gemm NT %s err %.2e | NN err %.2e' % ((M, N, K), e, e2))
+    ok &= e < 1e-13 and e2 < 1e-13
+  # lower-only: tiles above the diagonal must be untouched
+  M = 384
+  A = rs.randn(M, 40)
+  C0 = rs.randn(M, M)
+  got = eng.gemm(A, A, C0, alpha=-1.0, beta=1.0, lower_only=True)
+  ref = C0 - A.dot(A.T)
+  low = np.tril_indices(M)
+  e = relerr(got[low], ref[low])
+  untouched = np.array_equal(got[:128, 128:], C0[:128, 128:]) and np.array_equal(got[128:256, 256:], C0[128:256, 256:])
+  print('gemm lower err %.2e untouched-upper-tiles %s' % (e, untouched))
+  ok &= e < 1e-13 and untouched
+  print('STAGE gemm', 'PASS' if ok else 'FAIL')
+
+
+def _specs():
+  from dragonfly_amd.engine import KernelSpec
+  from oracle import ref_numpy as O
+  rs = np.random.RandomState(5)
+  out = []
+  for d in (1, 2, 6, 32, 45):
+    bw = 0.3 + rs.rand(d)
+    out.append(('se-d%d' % d, KernelSpec('se', d, 2.3, bw), O.KernelSpec('se', d, 2.3, bw)))
+    for nu in (0.5, 1.5, 2.5):
+      out.append(('matern%.1f-d%d' % (nu, d), KernelSpec('matern', d, 1.7, bw, nu=nu),
+                  O.KernelSpec('matern', d, 1.7, bw, nu=nu)))
+  d = 23
+  perm = rs.permutation(d)
+  groups = [list(perm[0:5]), list(perm[5:8]), list(perm[8:16]), list(perm[16:23])]
+  bws = [0.4 + rs.rand(len(g)) for g in groups]
+  kinds = ['se', 'matern', 'se', 'matern']
+  nus = [0.0, 2.5, 0.0, 1.5]
+  scales = [1.0, 1.0, 0.7, 1.3]
+  spec = KernelSpec('additive', d, 3.1, groups=groups, sub_kinds=kinds, sub_scales=scales,
+                    sub_nus=nus, sub_bandwidths=bws)
+  subs = [O.KernelSpec(k, len(g), s, b, nu=(n if k == 'matern' else None))
+          for k, g, s, b, n in zip(kinds, groups, scales, bws, nus)]
+  out.append(('additive-d23', spec, O.KernelSpec('additive', d, 3.1, groups=groups, subs=subs)))
+  return out
+
+
+def stage_kernmat():
+  from dragonfly_amd.engine import Engine
+  from oracle import ref_numpy as O
+  eng = Engine()
+  rs = np.random.RandomState(1)
+  ok = True
+  for name, spec, ospec in _specs():
+    d = spec.dim
+    for (n1, n2) in [(7, 5), (128, 128), (200, 333)]:
+      X1 = rs.rand(n1, d)
+      X2 = rs.rand(n2, d)
+      K = eng.kernel_matrix(spec, X1, X2)
+      Kr = ospec(X1, X2)
+      e = relerr(K, Kr)
+      Ks = eng.kernel_matrix(spec, X1, None, diag_add=0.25)
+      Ksr = ospec(X1, X1) + 0.25 * np.eye(n1)
+      es = relerr(Ks, Ksr)
+      sym = np.array_equal(Ks, Ks.T)
+      tol = 1e-7 if 'matern0.5' in name else 1e-12     # sqrt near 0 amplifies rounding of dist_sq
+      good = e < 1e-12 and es < tol and sym
+      ok &= good
+      if not good or (n1, n2) == (200, 333):
+        print('%-16s (%d,%d) cross err %.2e sym err %.2e bitwise-symmetric %s' % (name, n1, n2, e, es, sym))
+  X1 = rs.rand(50, 3)
+  X2 = rs.rand(40, 3)
+  e = relerr(eng.dist_squared(X1, X2), O.dist_squared(X1, X2))
+  print('dist_squared err %.2e' % e)
+  ok &= e < 1e-13
+  print('STAGE kernmat', 'PASS' if ok else 'FAIL')
+
+
+def _spd(n, rs, cond_noise=0.05):
+  from oracle import ref_numpy as O
+  d = 4
+  X = rs.rand(n, d)
+  K = O.se_kernel(X, X, 1.0, np.full(d, 0.4)) + cond_noise * np.eye(n)
+  return K
+
+
+def stage_chol():
+  from dragonfly_amd.engine import Engine
+  eng = Engine()
+  rs = np.random.RandomState(2)
+  ok = True
+  for n in (1, 5, 64, 65, 100, 128, 200, 512, 513, 700, 1024, 1500, 2048):
+    M = _spd(n, rs)
+    L = eng.cholesky(M)
+    Lr = np.linalg.cholesky(M)
+    e = relerr(L, Lr)
+    rec = relerr(L.dot(L.T), M)
+    up = float(np.abs(np.triu(L, 1)).max()) if n > 1 else 0.0
+    print('chol n=%d err-vs-lapack %.2e recon %.2e upper-max %.1e' % (n, e, rec, up))
+    ok &= e < 1e-11 and rec < 1e-13 and up == 0.0
+  # not PD
+  M = _spd(300, rs)
+  M[150, 150] = -1.0
+  try:
+    eng.cholesky(M)
+    print('non-PD: no exception  FAIL')
+    ok = False
+  except np.linalg.LinAlgError as ex:
+    print('non-PD raised LinAlgError:', ex)
+  # stable cholesky ladder: rank-deficient PSD matrix
+  A = rs.randn(200, 20)
+  M = A.dot(A.T)
+  from oracle import ref_numpy as O
+  try:
+    Lr, pr = O.stable_cholesky(M, return_power=True)
+  except Exception as ex:   # pylint: disable=broad-except
+    Lr, pr = None, repr(ex)
+  L, p = eng.stable_cholesky(M, return_power=True)
+  print('stable_cholesky power device %s oracle %s recon %.2e' % (p, pr, relerr(L.dot(L.T), M)))
+  # triangular solves
+  for n, nrhs in ((300, 1), (700, 1), (1100, 37), (600, 600)):
+    M = _spd(n, rs)
+    Lr = np.linalg.cholesky(M)
+    b = rs.randn(n) if nrhs == 1 else rs.randn(n, nrhs)
+    from scipy.linalg import solve_triangular
+    for upper in (False, True):
+      x = eng.solve_triangular(Lr, b, upper=upper)
+      xr = solve_triangular(Lr.T if upper else Lr, b, lower=not upper)
+      e = relerr(x, xr)
+      print('solve_triangular n=%d nrhs=%d upper=%s err %.2e' % (n, nrhs, upper, e))
+      ok &= e < 1e-10
+  print('STAGE chol', 'PASS' if ok else 'FAIL')
+
+
+def stage_gp():
+  from dragonfly_amd.engine import Engine
+  from oracle import ref_numpy as O
+  eng = Engine()
+  rs = np.random.RandomState(3)
+  ok = True
+  for name, spec, ospec in _specs():
+    if name not in ('se-d6', 'matern2.5-d6', 'se-d32', 'additive-d23', 'matern1.5-d2'):
+      continue
+    d = spec.dim
+    for n in (60, 700, 1500):
+      X = rs.rand(n, d)
+      Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+      mean_c = float(np.median(Y))
+      noise = float(Y.var() / 20)
+      og = O.GPOracle(X, Y, ospec, mean_c, noise)
+      gp = eng.gp_fit(spec, X, Y - mean_c, noise)
+      e_alpha = relerr(gp.get_alpha(), og.alpha)
+      e_L = relerr(gp.get_L(), og.L)
+      e_lml = abs(gp.lml - og.lml()) / abs(og.lml())
+      Xs = rs.rand(777, d)
+      mu, sd = gp.predict(Xs)
+      mur, sdr = og.eval(Xs, 'std')
+      e_mu = relerr(mu + mean_c, mur)
+      e_sd = relerr(sd, sdr)
+      best = float(Y.max())
+      line = '%-14s n=%d alpha %.1e L %.1e lml %.1e mu %.1e sd %.1e' % (name, n, e_alpha, e_L, e_lml, e_mu, e_sd)
+      good = max(e_alpha, e_L, e_lml, e_mu, e_sd) < 1e-10
+      for acq, params in (('ucb', (2.0, 0.0)), ('ei', (best, 0.0)), ('pi', (best, 0.0)), ('ttei', (best, 0.3))):
+        bv, bi, vals = gp.acq_argmax(acq, Xs, params=params, mean_const=mean_c, return_vals=True)
+        vr = O.acq_values(acq, mur, sdr, *params)
+        rv, ri = O.argmax_first(vr)
+        ev = relerr(vals, vr)
+        line += ' %s %.1e%s' % (acq, ev, '' if bi == ri else ' ARGMAX-MISMATCH(%d,%d)' % (bi, ri))
+        good &= ev < 1e-9 and bi == ri
+      # hallucinated
+      Xh = rs.rand(3, d)
+      mu2, sd2 = gp.predict(Xs, X_halluc=Xh)
+      _, sd2r = og.eval_with_hallucinated_observations(Xs, Xh, 'std')
+      e_h = relerr(sd2, sd2r)
+      line += ' halluc-sd %.1e' % e_h
+      good &= e_h < 1e-10 and np.array_equal(mu2, mu)
+      # TS (one block and several blocks)
+      U = rs.randn(len(Xs))
+      for blk in (len(Xs), 256):
+        bv, bi, samp, jps = gp.thompson(Xs, U, block=blk, mean_const=mean_c, return_samples=True)
+        sr = og.draw_samples_blocked(Xs, U, blk)
+        e_ts = relerr(samp, sr)
+        line += ' ts[%d] %.1e%s' % (blk, e_ts, '' if bi == int(np.argmax(sr)) else ' TS-ARGMAX-MISMATCH')
+        good &= e_ts < 1e-7
+      print(line, '' if good else '  <-- FAIL')
+      ok &= good
+      gp.free()
+  print('STAGE gp', 'PASS' if ok else 'FAIL')
+
+
+def stage_perf():
+  from dragonfly_amd.engine import Engine, KernelSpec
+  eng = Engine()
+  rs = np.random.RandomState(4)
+  # GEMM throughput
+  for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 512, 16384), (15872, 15872, 512)]:
+    A = eng.to_device(rs.rand(M, K) - 0.5)
+    B = eng.to_device(rs.rand(N, K) - 0.5)
+    Cd = eng.empty((M, N))
+    eng.gemm(A, B, shape=(M, N, K), out=Cd)
+    eng.sync()
+    reps = 3
+    eng.timer_begin()
+    for _ in range(reps):
+      eng.gemm(A, B, shape=(M, N, K), out=Cd)
+    ms = eng.timer_end() / reps
+    print('gemm NT %dx%dx%d: %.3f ms  %.1f TF/s' % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+    if M == N:
+      eng.timer_begin()
+      for _ in range(reps):
+        eng.gemm(A, A, alpha=-1.0, beta=1.0, shape=(M, M, K), out=Cd, lower_only=True)
+      ms = eng.timer_end() / reps
+      print('  syrk-lower %dx%dx%d: %.3f ms  %.1f TF/s (useful flops M*M*K)' % (M, M, K, ms, 1.0 * M * M * K / ms / 1e9))
+    A.free(); B.free(); Cd.free()
+  # kernel matrix
+  n, d = 16384, 32
+  X = eng.to_device(rs.rand(n, d))
+  Kd = eng.empty((n, n))
+  for kind, nu in (('se', 0.0), ('matern', 2.5)):
+    spec = KernelSpec(kind, d, 1.3, 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0), nu=nu)
+    eng.kernel_matrix(spec, X, None, out=Kd)
+    eng.timings(True)
+    for _ in range(3):
+      eng.kernel_matrix(spec, X, None, out=Kd)
+    t = eng.timings(True)
+    ms = t['kernmat'] / 3
+    gb = 8.0 * (n * n + 2 * n * d) / 1e9
+    print('kernmat %s n=%d d=%d: %.3f ms  %.2f TB/s (algorithmic %.3f GB)' % (kind, n, d, ms, gb / ms, gb))
+  # cholesky
+  for n in (4096, 8192, 16384):
+    spec = KernelSpec('se', d, 1.0, 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0))
+    Xn = eng.to_device(rs.rand(n, d))
+    Kn = eng.empty((n, n))
+    for rep in range(2):
+      eng.kernel_matrix(spec, Xn, None, diag_add=0.05, out=Kn)
+      eng.sync()
+      t0 = time.time()
+      eng.timings(True)
+      eng.cholesky(Kn)
+      eng.sync()
+      wall = (time.time() - t0) * 1e3
+      t = eng.timings(True)
+    print('cholesky n=%d: %.2f ms (wall %.2f)  %.1f TF/s' % (n, t['chol'], wall, n ** 3 / 3.0 / t['chol'] / 1e9))
+    Xn.free(); Kn.free()
+  X.free(); Kd.free()
+  print('STAGE perf DONE')
+
+
+def stage_fit16k():
+  """ C3-sized end-to-end: fit + posterior, with section timings. """
+  from dragonfly_amd.engine import Engine, KernelSpec
+  eng = Engine()
+  n, d, m = 16384, 32, 65536
+  rs = np.random.RandomState(103)
+  X = rs.random_sample((n, d))
+  w = (np.arange(d) + 1.0) / d
+  Y = (X ** 2).dot(w) + 0.01 * rs.randn(n)
+  bw = 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0)
+  spec = KernelSpec('se', d, float(Y.var()), bw)
+  mean_c = float(np.median(Y))
+  noise = float(Y.var() / 20)
+  Xc = np.random.RandomState(203).random_sample((m, d))
+  Xd = eng.to_device(X)
+  yd = eng.to_device(Y - mean_c)
+  Xcd = eng.to_device(Xc)
+  for rep in range(2):
+    eng.timings(True)
+    t0 = time.time()
+    gp = eng.gp_fit(spec, Xd, yd, noise)
+    t1 = time.time()
+    bv, bi = gp.acq_argmax('ucb', Xcd, params=(3.0, 0.0), mean_const=mean_c)
+    t2 = time.time()
+    t = eng.timings(True)
+    print('rep %d fit %.1f ms acq(m=%d) %.1f ms lml %.6f best %.6f idx %d  sections %s' % (
+        rep, (t1 - t0) * 1e3, m, (t2 - t1) * 1e3, gp.lml, bv, bi,
+        {k: round(v, 2) for k, v in t.items()}))
+    if rep == 0:
+      gp.free()
+  eng.timings(False)
+  t0 = time.time()
+  gp2 = eng.gp_fit(spec, Xd, yd, noise)
+  t1 = time.time()
+  bv, bi = gp2.acq_argmax('ucb', Xcd, params=(3.0, 0.0), mean_const=mean_c)
+  t2 = time.time()
+  print('untimed-sections: fit %.1f ms acq %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+  print('STAGE fit16k DONE')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k']
+
+if __name__ == '__main__':
+  if len(sys.argv) == 3 and sys.argv[1] == '--run':
+    globals()['stage_' + sys.argv[2]]()
+    sys.exit(0)
+  stages = sys.argv[1:] or STAGES
+  outdir = os.path.join(ROOT, 'gpurun_out', 'check')
+  os.makedirs(outdir, exist_ok=True)
+  for st in stages:
+    t0 = time.time()
+    with open(os.path.join(outdir, st + '.log'), 'w') as f:
+      try:
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), '--run', st], stdout=f,
+                             stderr=subprocess.STDOUT, timeout=900)
+      except subprocess.TimeoutExpired:
+        rc = 'TIMEOUT'
+    print('== stage %s rc=%s (%.1fs)' % (st, rc, time.time() - t0), flush=True)
+    with open(os.path.join(outdir, st + '.log')) as f:
+      txt = f.read()
+    print(txt[-6000:], flush=True)
