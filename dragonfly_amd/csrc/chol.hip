@@ -6,10 +6,10 @@
 //
 // Structure (row-major lower, n x n):
 //   outer panels of CHOL_NB = 512 columns; inside a panel the 512 x 512 diagonal block is
-//   factored with 64-wide steps: a single-workgroup LDS kernel factors the 64 x 64 pivot block
-//   and inverts it (potf2_inv64), the 64-wide column below it is solved by multiplying with
-//   that inverse (MFMA GEMM) and the rest of the diagonal block is updated by an MFMA SYRK.
-//   The eight 64-block inverses are then merged into the inverse of the 512 block by three
+//   factored with 64-wide steps: one launch (diag_step64) factors the 64 x 64 pivot block in
+//   registers and solves the 64-wide column below it by substitution, then the rest of the
+//   diagonal block is updated by an MFMA SYRK.  The eight 64-block inverses (trtri64, one
+//   launch) are then merged into the inverse of the 512 block by three
 //   levels of batched GEMMs ([[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]]), so the panel
 //   solve  L21 = A21 L11^-T  and the trailing update  A22 -= L21 L21^T  are two large MFMA_F64
 //   GEMMs -- where n^3/3 of the flops are.  The 512-block inverses are kept: the posterior
@@ -23,53 +23,228 @@ namespace {
 constexpr int PB = 64;       // pivot block
 constexpr int PBP = 65;      // LDS row stride
 
-// One workgroup: factor the nb x nb (nb <= 64) block at A in place (upper part zeroed) and
-// write its inverse (row-major, upper part zero) to inv.  info[0] <- pivot_base + j + 1 for the
-// first non-positive / NaN pivot (only the first failure of a factorisation is recorded).
-__global__ __launch_bounds__(256) void potf2_inv64_kernel(double* __restrict__ A, long lda, int nb,
-                                                          double* __restrict__ inv, long ldinv,
-                                                          long pivot_base, long long* info,
-                                                          int do_factor) {
-  __shared__ double S[PB * PBP];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < PB * PB; idx += 256) {
-    const int i = idx >> 6, k = idx & 63;
+// ---------------------------------------------------------------------------------------------
+// 64 x 64 pivot-block kernels.
+//
+// factor64(): the block lives in registers, thread (w = tid>>6, k = tid&63) owns column k of rows
+// w, w+4, ..., w+60.  Step j: the four owners of column j publish it (unscaled) through a
+// double-buffered 64-double LDS vector, one barrier, then every thread of a column k > j applies
+// a[i][k] -= a[i][j] * (a[k][j] / d_j) to its 16 rows.  Columns are divided by sqrt(d_k) once,
+// after the loop.  Returns false (uniformly) on a non-positive / NaN pivot.
+// (A single-wave v_readlane formulation with no barriers at all was measured slower on gfx950:
+//  ~29 cycles per readlane-pair + FMA; see profiles/r01_notes.md.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_block64(const double* __restrict__ A, long lda, int nb, int w,
+                                              int k, double (&a)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = w + 4 * r;
     double v = (i == k) ? 1.0 : 0.0;                  // identity padding beyond nb
     if (i < nb && k < nb) v = (k <= i) ? A[i * lda + k] : 0.0;
-    S[i * PBP + k] = v;
+    a[r] = v;
+  }
+}
+
+// 1/d for a positive normal d: hardware reciprocal + two Newton steps (what the compiler's own
+// division sequence does before its final correction).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+// q ~= n/d with one residual correction (<= 1 ulp from the correctly rounded quotient)
+__device__ __forceinline__ double fast_div(double n, double d, double r) {
+  const double q = n * r;
+  return fma(fma(-d, q, n), r, q);
+}
+
+// LDS image of a published column: element i sits at perm16(i) so that the 16 rows a thread owns
+// (w, w+4, ..., w+60) are 16 consecutive doubles -> ds_read_b128 instead of 16 scalar reads.
+__device__ __forceinline__ int perm16(int i) { return (i & 3) * 16 + (i >> 2); }
+
+#define LDS_FENCE() asm volatile("" ::: "memory")   // keeps every LDS load above it, every use below
+
+__device__ __forceinline__ bool factor64(double (&a)[16], int nb, int w, int k, double (*colbuf)[PB],
+                                         int* fail_j, double* diag_out) {
+  double my_d = 1.0;
+  const int pk = perm16(k);
+  for (int j = 0; j < nb; ++j) {
+    double* cb = colbuf[j & 1];
+    if (k == j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[w * 16 + r] = a[r];
+    }
+    __syncthreads();
+    // issue every LDS read of the step together (one latency, not sixteen)
+    const double d = cb[perm16(j)];
+    const double cbk = cb[pk];
+    double ci[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ci[r] = cb[w * 16 + r];
+    LDS_FENCE();
+    if (!(d > 0.0)) {                                  // uniform: every thread reads the same d
+      *fail_j = j;
+      return false;
+    }
+    if (k == j) my_d = d;
+    if (k > j) {
+      const double ck = fast_div(cbk, d, fast_rcp(d));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = w + 4 * r;
+        const double upd = fma(-ci[r], ck, a[r]);
+        a[r] = (i > j) ? upd : a[r];
+      }
+    }
+  }
+  const double sd = sqrt(my_d);
+  *diag_out = sd;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = w + 4 * r;
+    if (k < nb) a[r] = (i > k) ? a[r] / sd : ((i == k) ? sd : 0.0);
+  }
+  return true;
+}
+
+// sum over the four lanes of a quad, in every lane (DPP quad_perm, no LDS crossbar)
+__device__ __forceinline__ double quad_sum(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo1 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  int hi1 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  v += __hiloint2double(hi1, lo1);
+  lo = __double2loint(v); hi = __double2hiint(v);
+  lo1 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+  hi1 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+  return v + __hiloint2double(hi1, lo1);
+}
+
+// One 64-wide step of the diagonal-block factorisation, one launch:
+//   workgroup 0     : factors the nb x nb pivot block at D in place (upper part zeroed);
+//   workgroup b >= 1: factors the same block redundantly (bit-identical, no inter-workgroup
+//                     hand-off needed) and solves 64 rows of the column below it,
+//                     P[r,:] <- P[r,:] L^-T, by forward substitution with four lanes per row.
+// info[0] <- pivot_base + j + 1 for the first non-positive / NaN pivot.
+constexpr int SPP = 66;      // row stride of the column-permuted factor image (16-byte aligned rows)
+__global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D, long lda, int nb,
+                                                          int rows_below, long pivot_base,
+                                                          long long* info) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* Sp = dsm;                       // [64][SPP] factor, columns permuted by perm16
+  double* R = dsm + PB * SPP;             // [64][65] panel rows
+  double(*colbuf)[PB] = reinterpret_cast<double(*)[PB]>(dsm + PB * SPP + PB * PBP);
+  const int tid = threadIdx.x;
+  const int k = tid & 63, w = tid >> 6;
+
+  double a[16];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  load_block64(D, lda, nb, w, k, a);
+  int fail_j = 0;
+  double my_diag = 1.0;
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const bool fok = factor64(a, nb, w, k, colbuf, &fail_j, &my_diag);
+  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+  if (info[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1) { info[2] = (long long)(t1 - t0); info[3] = (long long)(t2 - t1); }
+  if (!fok) {
+    if (blockIdx.x == 0 && tid == 0 && info[0] == 0) info[0] = pivot_base + fail_j + 1;
+    return;
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = w + 4 * r;
+      if (i < nb && k < nb) D[i * lda + k] = a[r];
+    }
+    return;
+  }
+  {
+    const int pk = perm16(k);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sp[(w + 4 * r) * SPP + pk] = a[r];
+  }
+  double* rdiag = colbuf[0];                       // 1 / L[c][c]  (colbuf is free after factor64)
+  __syncthreads();                                 // every thread is done reading colbuf
+  if (w == 0) rdiag[k] = fast_div(1.0, my_diag, fast_rcp(my_diag));
+  // stage this workgroup's 64 panel rows (coalesced along k)
+  const int r0 = (blockIdx.x - 1) * PB;
+  double* Pn = D + (long)(nb + r0) * lda;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = w + 4 * r;
+    R[i * PBP + k] = (r0 + i < rows_below && k < nb) ? Pn[i * lda + k] : 0.0;
   }
   __syncthreads();
-
-  for (int j = 0; do_factor && j < nb; ++j) {
-    const double d = S[j * PBP + j];
-    if (!(d > 0.0)) {                                  // uniform: every thread reads the same d
-      if (tid == 0) {
-        if (info[0] == 0) info[0] = pivot_base + j + 1;
+  {
+    // forward substitution x L^T = p, four lanes per row: lane q of a quad accumulates the terms
+    // kk = q (mod 4) (its 16 values of row c of L are contiguous in Sp), two quad shuffles combine
+    // them, x[c] = s * (1 / L[c][c]).  Terms with kk >= c vanish on their own: L is lower
+    // triangular and x[kk] is still zero when row c is processed.
+    const int row = tid >> 2, q = tid & 3;
+    double xq[16], rq[16];                         // x[4t + q], p[4t + q]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { xq[t] = 0.0; rq[t] = R[row * PBP + 4 * t + q]; }
+    double sv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sv[t] = 0.0;
+    sv[0] = Sp[0 * SPP + q * 16];
+    double rd = rdiag[0];
+    LDS_FENCE();
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      // prefetch row c+1 of L (this lane's residue class) while row c is being reduced
+      double sn[16];
+      double rdn = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) sn[t] = 0.0;
+      if (c + 1 < PB) {
+#pragma unroll
+        for (int t = 0; t <= (c + 1) / 4; ++t) sn[t] = Sp[(c + 1) * SPP + q * 16 + t];
+        rdn = rdiag[c + 1];
       }
-      return;
+      LDS_FENCE();
+      double s = ((c & 3) == q) ? rq[c / 4] : 0.0;
+#pragma unroll
+      for (int t = 0; t <= c / 4; ++t) s = fma(-xq[t], sv[t], s);
+      s = quad_sum(s);
+      const double xc = s * rd;
+      if ((c & 3) == q) xq[c / 4] = xc;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) sv[t] = sn[t];
+      rd = rdn;
     }
-    const double sd = sqrt(d);
-    __syncthreads();                                   // everyone has read S[j][j]
-    if (tid > j && tid < nb) S[tid * PBP + j] = S[tid * PBP + j] / sd;
-    if (tid == 0) S[j * PBP + j] = sd;
-    __syncthreads();
-    // rank-1 update of the trailing lower triangle
-    const int k = j + 1 + (tid & 63);
-    for (int i = j + 1 + (tid >> 6); i < nb; i += 4) {
-      if (k <= i) S[i * PBP + k] = fma(-S[i * PBP + j], S[k * PBP + j], S[i * PBP + k]);
-    }
-    __syncthreads();
+    __syncthreads();                               // all reads of R done before it is overwritten
+#pragma unroll
+    for (int t = 0; t < 16; ++t) R[row * PBP + 4 * t + q] = xq[t];
   }
-
-  if (do_factor) {
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-      const int i = idx / nb, k = idx - i * nb;
-      A[i * lda + k] = (k <= i) ? S[i * PBP + k] : 0.0;
-    }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = w + 4 * r;
+    if (r0 + i < rows_below && k < nb) Pn[i * lda + k] = R[i * PBP + k];
   }
+  if (info[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1) info[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
+}
+constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 2 * PB) * 8;
 
-  // inverse by back substitution on rows:  x_r L = e_r ; lane r owns row r, L entries are
-  // wave-uniform LDS broadcasts.  Padded rows/cols are identity so the full 64-loop is safe.
+// Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
+// workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
+// Padded rows/cols are identity so the full 64-loop is safe.
+__global__ __launch_bounds__(256) void trtri64_kernel(const double* __restrict__ D, long lda, int nbk,
+                                                      double* __restrict__ inv, long ldinv) {
+  __shared__ double S[PB * PBP];
+  const int tid = threadIdx.x;
+  const int k = tid & 63, w = tid >> 6;
+  const int j0 = blockIdx.x * PB;
+  const int nb = min(PB, nbk - j0);
+  const double* A = D + (long)j0 * lda + j0;
+  double a[16];
+  load_block64(A, lda, nb, w, k, a);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[(w + 4 * r) * PBP + k] = a[r];
+  __syncthreads();
   if (tid < 64) {
     const int r = tid;
     double x[PB];
@@ -80,10 +255,11 @@ __global__ __launch_bounds__(256) void potf2_inv64_kernel(double* __restrict__ A
       for (int kk = c + 1; kk < PB; ++kk) s = fma(-x[kk], S[kk * PBP + c], s);
       x[c] = s / S[c * PBP + c];
     }
+    double* out = inv + (long)j0 * ldinv + j0;
     if (r < nb) {
 #pragma unroll
       for (int c = 0; c < PB; ++c)
-        if (c < nb) inv[r * ldinv + c] = (c <= r) ? x[c] : 0.0;
+        if (c < nb) out[r * ldinv + c] = (c <= r) ? x[c] : 0.0;
     }
   }
 }
@@ -123,13 +299,22 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
 
 }  // namespace
 
+// Look-ahead schedule.  Two streams: P (high priority, "panel") and M (the context's main
+// stream, "trailing").  For panel k
+//   P: factor the 512 diagonal block, invert it, solve the panel L21(k), then update ONLY block
+//      column k+1 with it (after M's trailing update k-1, which also wrote that column);
+//   M: once L21(k) is ready, update the rest of the trailing matrix (columns >= k+2, lower).
+// P therefore factors panel k+1 while M is still busy with the big SYRK of panel k: the
+// latency-bound diagonal work leaves the critical path while the trailing update is long enough
+// to cover it.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
                     int64_t* info_pivot) {
   if (info_pivot) *info_pivot = 0;
   if (n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
   long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
-  DFH_HIP(hipMemsetAsync(d_info, 0, 8, ctx->stream));
+  hipStream_t M = ctx->stream, P = ctx->side;
+  DFH_HIP(hipMemsetAsync(d_info, 0, 8, M));
 
   double* inv_scratch = nullptr;
   if (!keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)NB * NB * 8, (void**)&inv_scratch));
@@ -138,46 +323,80 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   double* W = nullptr;
   if (n > NB) DFH_TRY(scratch_get(ctx, SCR_CHOLW, (size_t)(n - NB) * NB * 8, (void**)&W));
 
-  for (int64_t k0 = 0; k0 < n; k0 += NB) {
-    const int64_t nbk = (n - k0 < NB) ? n - k0 : NB;
-    double* Linv = keep_inv ? keep_inv + (k0 / NB) * NB * NB : inv_scratch;
-    DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, ctx->stream));
-    double* D = A + k0 * lda + k0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(diag_step64_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));
+    attr_set = true;
+  }
+  const int64_t nblk = (n + NB - 1) / NB;
+  hipEvent_t ev_start, ev_done;
+  DFH_TRY(ctx_event(ctx, 0, &ev_start));
+  DFH_TRY(ctx_event(ctx, 1, &ev_done));
+  DFH_HIP(hipEventRecord(ev_start, M));
+  DFH_HIP(hipStreamWaitEvent(P, ev_start, 0));
 
-    // ---- factor the diagonal block with 64-wide steps -------------------------------------
-    for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
-      const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
-      double* Djj = D + j0 * lda + j0;
-      double* Ijj = Linv + j0 * NB + j0;
-      hipLaunchKernelGGL(potf2_inv64_kernel, dim3(1), dim3(256), 0, ctx->stream, Djj, (long)lda, w,
-                         Ijj, (long)NB, (long)(k0 + j0), d_info, 1);
+  for (int64_t kb = 0; kb < nblk; ++kb) {
+    const int64_t k0 = kb * NB;
+    const int64_t nbk = (n - k0 < NB) ? n - k0 : NB;
+    double* Linv = keep_inv ? keep_inv + kb * NB * NB : inv_scratch;
+    double* D = A + k0 * lda + k0;
+    const int64_t rem = n - k0 - nbk;
+    hipEvent_t e_trsm, e_trail, e_trail_prev = nullptr;
+    DFH_TRY(ctx_event(ctx, 2 + 2 * kb, &e_trsm));
+    DFH_TRY(ctx_event(ctx, 3 + 2 * kb, &e_trail));
+    if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 2 * (kb - 1), &e_trail_prev));
+    {
+      StreamSwap on_p(ctx, P);
+      DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, P));
+      // ---- factor the diagonal block with 64-wide steps -----------------------------------
+      for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
+        const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
+        double* Djj = D + j0 * lda + j0;
+        const int64_t rows = nbk - j0 - w;
+        const unsigned nwg = 1 + (unsigned)((rows + PB - 1) / PB);
+        hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, P, Djj, (long)lda, w,
+                           (int)rows, (long)(k0 + j0), d_info);
+        DFH_LAUNCH_CHECK();
+        if (rows > 0) {
+          double* Pn = D + (j0 + w) * lda + j0;                      // rows x w, already solved
+          double* D22 = D + (j0 + w) * lda + (j0 + w);
+          DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rows, rows, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda));
+        }
+      }
+      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, P, D, (long)lda,
+                         (int)nbk, Linv, (long)NB);
       DFH_LAUNCH_CHECK();
-      const int64_t rows = nbk - j0 - w;
-      if (rows > 0) {
-        double* P = D + (j0 + w) * lda + j0;                       // rows x w
-        // P <- P * Ljj^-T   (single column tile: in-place safe)
-        DFH_TRY(gemm_f64(ctx, 0, rows, w, w, 1.0, P, lda, Ijj, NB, 0.0, nullptr, 0, P, lda));
-        // D22 <- D22 - P P^T (lower)
-        double* D22 = D + (j0 + w) * lda + (j0 + w);
-        DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rows, rows, w, -1.0, P, lda, P, lda, 1.0, D22, lda, D22, lda));
+      DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T));
+      // ---- panel solve, then the next block column --------------------------------------
+      if (rem > 0) {
+        double* A21 = A + (k0 + nbk) * lda + k0;          // rem x nbk
+        DFH_TRY(copy_matrix(ctx, A21, lda, W, NB, rem, nbk));
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, rem, nbk, nbk, 1.0, W, NB, Linv, NB, 0.0, nullptr, 0, A21, lda));
+        DFH_HIP(hipEventRecord(e_trsm, P));
+        if (e_trail_prev) DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
+        const int64_t nb1 = rem < NB ? rem : NB;
+        double* C1 = A + (k0 + nbk) * lda + (k0 + nbk);   // rows k+1.., block column k+1
+        DFH_TRY(gemm_f64(ctx, 0, rem, nb1, nbk, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda));
       }
     }
-
-    DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T));
-
-    // ---- panel solve and trailing update --------------------------------------------------
-    const int64_t rem = n - k0 - nbk;
-    if (rem > 0) {
-      double* A21 = A + (k0 + nbk) * lda + k0;          // rem x nbk
-      DFH_TRY(copy_matrix(ctx, A21, lda, W, NB, rem, nbk));
-      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, rem, nbk, nbk, 1.0, W, NB, Linv, NB, 0.0, nullptr, 0, A21, lda));
-      double* A22 = A + (k0 + nbk) * lda + (k0 + nbk);
-      DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rem, rem, nbk, -1.0, A21, lda, A21, lda, 1.0, A22, lda, A22, lda));
+    if (rem > NB) {
+      const int64_t rem2 = rem - NB;
+      const double* A31 = A + (k0 + nbk + NB) * lda + k0;                // rows k+2.. of the panel
+      double* A33 = A + (k0 + nbk + NB) * lda + (k0 + nbk + NB);
+      DFH_HIP(hipStreamWaitEvent(M, e_trsm, 0));
+      DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rem2, rem2, nbk, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda));
+      DFH_HIP(hipEventRecord(e_trail, M));
+    } else {
+      // nothing for M to do: keep the event chain well-formed for the next panel's wait
+      DFH_HIP(hipEventRecord(e_trail, M));
     }
   }
+  DFH_HIP(hipEventRecord(ev_done, P));
+  DFH_HIP(hipStreamWaitEvent(M, ev_done, 0));
 
-  DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8, hipMemcpyDeviceToHost, ctx->stream));
-  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8, hipMemcpyDeviceToHost, M));
+  DFH_HIP(hipStreamSynchronize(M));
   const int64_t piv = ctx->h_info[0];
   if (info_pivot) *info_pivot = piv;
   if (piv != 0) {
@@ -187,6 +406,9 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   return DFH_OK;
 }
 
+// Right-looking block substitution: once x_i is final it is pushed into every remaining row
+// (wide, short GEMVs -> thousands of independent rows per launch instead of one long dependent
+// chain).  The pass is HBM-bound: the lower triangle of L is read once per solve.
 int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
                  double* x) {
   const int64_t NB = CHOL_NB;
@@ -194,11 +416,13 @@ int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const do
   DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)NB * 8, (void**)&tmp));
   for (int64_t c0 = 0; c0 < n; c0 += NB) {
     const int64_t w = (n - c0 < NB) ? n - c0 : NB;
-    // x_i <- x_i - L[i, 0:c0] x[0:c0]
-    if (c0 > 0) DFH_TRY(gemv_rows(ctx, L + c0 * ldl, w, c0, ldl, x, -1.0, x + c0, 1.0, x + c0));
     // x_i <- Linv_ii x_i
     DFH_TRY(gemv_rows(ctx, inv + (c0 / NB) * NB * NB, w, w, NB, x + c0, 1.0, nullptr, 0.0, tmp));
     DFH_HIP(hipMemcpyAsync(x + c0, tmp, (size_t)w * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    // x[i+1:] <- x[i+1:] - L[i+1:, i] x_i
+    const int64_t below = n - c0 - w;
+    if (below > 0)
+      DFH_TRY(gemv_rows(ctx, L + (c0 + w) * ldl + c0, below, w, ldl, x + c0, -1.0, x + c0 + w, 1.0, x + c0 + w));
   }
   return DFH_OK;
 }
@@ -212,13 +436,11 @@ int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const d
   for (int64_t b = nblk - 1; b >= 0; --b) {
     const int64_t c0 = b * NB;
     const int64_t w = (n - c0 < NB) ? n - c0 : NB;
-    const int64_t below = n - c0 - w;
-    // x_i <- x_i - L[i+1:, i]^T x[i+1:]
-    if (below > 0)
-      DFH_TRY(gemv_cols(ctx, L + (c0 + w) * ldl + c0, below, w, ldl, x + c0 + w, -1.0, x + c0, 1.0, x + c0));
     // x_i <- Linv_ii^T x_i
     DFH_TRY(gemv_cols(ctx, inv + b * NB * NB, w, w, NB, x + c0, 1.0, nullptr, 0.0, tmp));
     DFH_HIP(hipMemcpyAsync(x + c0, tmp, (size_t)w * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    // x[:i] <- x[:i] - L[i, :i]^T x_i
+    if (c0 > 0) DFH_TRY(gemv_cols(ctx, L + c0 * ldl, w, c0, ldl, x + c0, -1.0, x, 1.0, x));
   }
   return DFH_OK;
 }
@@ -244,19 +466,14 @@ int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, do
   const int64_t NB = CHOL_NB;
   double* T = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)NB * NB * 8, (void**)&T));
-  long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int64_t nbk = (n - k0 < NB) ? n - k0 : NB;
     double* Linv = inv + (k0 / NB) * NB * NB;
     DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, ctx->stream));
     const double* D = L + k0 * ldl + k0;
-    for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
-      const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
-      hipLaunchKernelGGL(potf2_inv64_kernel, dim3(1), dim3(256), 0, ctx->stream,
-                         const_cast<double*>(D + j0 * ldl + j0), (long)ldl, w, Linv + j0 * NB + j0,
-                         (long)NB, (long)(k0 + j0), d_info, 0);
-      DFH_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, ctx->stream, D,
+                       (long)ldl, (int)nbk, Linv, (long)NB);
+    DFH_LAUNCH_CHECK();
     DFH_TRY(assemble_block_inverse(ctx, D, ldl, nbk, Linv, T));
   }
   return DFH_OK;
@@ -280,5 +497,46 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
     DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, T, NB, inv + b * NB * NB, NB, 0.0, nullptr, 0,
                      Bt + c0, ldb));
   }
+  return DFH_OK;
+}
+
+// Diagnostics hook (not part of the product path): times `reps` back-to-back launches of the
+// 64-wide diagonal step on a synthetic SPD block and returns in-kernel cycle stamps.
+extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, double* ms_per_launch,
+                                   long long* cycles_out /* [3]: load, factor, trsm */) {
+  DFH_ARG(ctx && reps > 0 && rows_below >= 0 && rows_below <= 448);
+  DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(diag_step64_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));
+  const int64_t nn = 512;
+  double* A = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)nn * nn * 8, (void**)&A));
+  std::vector<double> h((size_t)nn * nn, 0.01);
+  for (int64_t i = 0; i < nn; ++i) h[i * nn + i] = 10.0 + (double)(i % 7);
+  DFH_HIP(hipMemcpyAsync(A, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
+  long long init[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+  DFH_HIP(hipMemcpyAsync(d_info, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  const unsigned nwg = 1 + (unsigned)((rows_below + PB - 1) / PB);
+  hipEvent_t e0, e1;
+  DFH_HIP(hipEventCreate(&e0));
+  DFH_HIP(hipEventCreate(&e1));
+  DFH_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < reps; ++r) {
+    // the block is re-factored from its own output (still SPD: L has a dominant diagonal)
+    hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, ctx->stream, A, (long)nn, 64,
+                       rows_below, 0L, d_info);
+  }
+  DFH_HIP(hipEventRecord(e1, ctx->stream));
+  DFH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  DFH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  long long out[8];
+  DFH_HIP(hipMemcpy(out, d_info, sizeof(out), hipMemcpyDeviceToHost));
+  if (ms_per_launch) *ms_per_launch = ms / reps;
+  if (cycles_out) { cycles_out[0] = out[2]; cycles_out[1] = out[3]; cycles_out[2] = out[4]; }
+  long long zero[8] = {0};
+  DFH_HIP(hipMemcpy(d_info, zero, sizeof(zero), hipMemcpyHostToDevice));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return DFH_OK;
 }

@@ -45,7 +45,10 @@ struct DevBuf {
 
 struct dfh_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // every kernel is launched on this stream ...
+  hipStream_t main_stream = nullptr; // (== stream except inside StreamSwap scopes)
+  hipStream_t side = nullptr;        // high-priority panel stream of the look-ahead Cholesky
+  std::vector<hipEvent_t> evpool;    // untimed events for cross-stream ordering
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
   std::vector<DevBuf> scratch;
@@ -93,6 +96,14 @@ int to_device(dfh_ctx* ctx, const void* p, size_t bytes, int slot, const double*
 bool is_device_ptr(const void* p);
 // Copy a device result to a user pointer that may be host or device.
 int from_device(dfh_ctx* ctx, void* user_dst, const void* dev_src, size_t bytes);
+
+// Temporarily route launches to another stream of the same context.
+struct StreamSwap {
+  dfh_ctx* c; hipStream_t old;
+  StreamSwap(dfh_ctx* ctx, hipStream_t s) : c(ctx), old(ctx->stream) { c->stream = s; }
+  ~StreamSwap() { c->stream = old; }
+};
+int ctx_event(dfh_ctx* ctx, size_t idx, hipEvent_t* out);   // lazily created, untimed
 
 struct SectionTimer {
   dfh_ctx* ctx; int which; bool on;

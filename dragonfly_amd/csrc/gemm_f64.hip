@@ -23,13 +23,22 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BK = 16;
 constexpr int BKP = 18;    // row stride (doubles) of the K-contiguous LDS tiles: 2*(r*18+k) mod 64
                            // is distinct over r<16,k<2 -> ds_read_b64 conflict free
-constexpr int BNP = 144;   // row stride of the NN B tile [BK][BN]: 2*144 mod 64 = 32
-constexpr int TILE_A = BM * BKP;                       // doubles per A stage
-constexpr int TILE_B = (BN * BKP > BK * BNP) ? BN * BKP : BK * BNP;
-constexpr int SMEM_BYTES = 2 * (TILE_A + TILE_B) * 8;  // 73728
+// Tile geometry, WT = MFMA tiles per wave per dimension: WT=4 -> 128x128 block tile (the
+// throughput configuration), WT=2 -> 64x64 (small / latency-bound problems: 4x more workgroups).
+template <int WT> struct Geo {
+  static constexpr int BM = 32 * WT, BN = 32 * WT;
+  static constexpr int BNP = BN + 16;                  // NN B tile [BK][BN] row stride: 2*BNP mod 64 = 32
+  static constexpr int TILE_A = BM * BKP;              // doubles per A stage
+  static constexpr int TILE_B = (BN * BKP > BK * BNP) ? BN * BKP : BK * BNP;
+  static constexpr int SMEM_BYTES = 2 * (TILE_A + TILE_B) * 8;   // 73728 (WT=4), 36864 (WT=2)
+  static constexpr int PA = BM / 32;                   // 32-row load passes per operand tile
+  static constexpr int NN_LANES = BN / 2;              // lanes per k-row of the NN B tile
+  static constexpr int NN_ROWS = 256 / NN_LANES;       // k-rows per pass
+  static constexpr int NN_PASSES = BK / NN_ROWS;
+};
 
 struct GemmArgs {
   int M, N, K;
@@ -40,6 +49,7 @@ struct GemmArgs {
   double alpha, beta;
   int flags;
   int tiles_m, tiles_n;
+  int bm, bn;
 };
 
 __device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
@@ -67,8 +77,11 @@ __device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
   }
 }
 
-template <bool TRANSB, bool EDGE>
+template <bool TRANSB, bool EDGE, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+  using G = Geo<WT>;
+  constexpr int BM = G::BM, BN = G::BN, BNP = G::BNP, TILE_A = G::TILE_A, TILE_B = G::TILE_B;
+  constexpr int WS = WT * 16;                          // wave tile edge
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                  // [2][TILE_A]
   double* Bs = smem + 2 * TILE_A;     // [2][TILE_B]
@@ -89,22 +102,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   if (p.flags & GEMM_KTRI_B) kend = min(p.K, n0 + BN);   // B[j][k] = 0 for k > j
   const int nchunks = (kend + BK - 1) / BK;
 
-  double4_t acc[4][4];
+  double4_t acc[WT][WT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   // staging registers: 4 x 16B for A and 4 x 16B for B per thread per chunk
-  double2_t ra[4], rb[4];
+  double2_t ra[G::PA], rb[(G::PA > G::NN_PASSES) ? G::PA : G::NN_PASSES];
 
   const int a_row = tid >> 3, a_col = (tid & 7) * 2;      // K-contiguous tiles: 8 lanes per row
-  const int b_krow = tid >> 6, b_ncol = (tid & 63) * 2;   // NN B tile: 64 lanes per k-row
+  const int b_krow = tid / G::NN_LANES, b_ncol = (tid % G::NN_LANES) * 2;   // NN B tile
 
   auto load_chunk = [&](int kc) {
     const int k0 = kc * BK;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < G::PA; ++q) {
       const int row = a_row + 32 * q;
       if (!EDGE) {
         ra[q] = *reinterpret_cast<const double2_t*>(A + (long)(m0 + row) * p.lda + k0 + a_col);
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     }
     if (!TRANSB) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < G::PA; ++q) {
         const int row = a_row + 32 * q;
         if (!EDGE) {
           rb[q] = *reinterpret_cast<const double2_t*>(B + (long)(n0 + row) * p.ldb + k0 + a_col);
@@ -130,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int krow = b_krow + 4 * q;
+      for (int q = 0; q < G::NN_PASSES; ++q) {
+        const int krow = b_krow + G::NN_ROWS * q;
         if (!EDGE) {
           rb[q] = *reinterpret_cast<const double2_t*>(B + (long)(k0 + krow) * p.ldb + n0 + b_ncol);
         } else {
@@ -148,16 +161,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     double* as = As + buf * TILE_A;
     double* bs = Bs + buf * TILE_B;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < G::PA; ++q)
       *reinterpret_cast<double2_t*>(as + (a_row + 32 * q) * BKP + a_col) = ra[q];
     if (!TRANSB) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < G::PA; ++q)
         *reinterpret_cast<double2_t*>(bs + (a_row + 32 * q) * BKP + a_col) = rb[q];
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<double2_t*>(bs + (b_krow + 4 * q) * BNP + b_ncol) = rb[q];
+      for (int q = 0; q < G::NN_PASSES; ++q)
+        *reinterpret_cast<double2_t*>(bs + (b_krow + G::NN_ROWS * q) * BNP + b_ncol) = rb[q];
     }
   };
 
@@ -171,20 +184,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     const int buf = kc & 1;
     if (kc + 1 < nchunks) load_chunk(kc + 1);
 
-    const double* as = As + buf * TILE_A + (wm * 64 + l15) * BKP + l4;
-    const double* bs = TRANSB ? (Bs + buf * TILE_B + l4 * BNP + wn * 64 + l15)
-                              : (Bs + buf * TILE_B + (wn * 64 + l15) * BKP + l4);
+    const double* as = As + buf * TILE_A + (wm * WS + l15) * BKP + l4;
+    const double* bs = TRANSB ? (Bs + buf * TILE_B + l4 * BNP + wn * WS + l15)
+                              : (Bs + buf * TILE_B + (wn * WS + l15) * BKP + l4);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[4], b[4];
+      double a[WT], b[WT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = as[t * 16 * BKP + kk * 4];
+      for (int t = 0; t < WT; ++t) a[t] = as[t * 16 * BKP + kk * 4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) b[t] = TRANSB ? bs[kk * 4 * BNP + t * 16] : bs[t * 16 * BKP + kk * 4];
+      for (int t = 0; t < WT; ++t) b[t] = TRANSB ? bs[kk * 4 * BNP + t * 16] : bs[t * 16 * BKP + kk * 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < WT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 
@@ -197,13 +210,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   const double* __restrict__ Cin = p.Cin ? p.Cin + bz * p.sCin : nullptr;
   double* __restrict__ Cout = p.Cout + bz * p.sCout;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < WT; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+      const int row = m0 + wm * WS + i * 16 + l4 + 4 * r;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + l15;
+      for (int j = 0; j < WT; ++j) {
+        const int col = n0 + wn * WS + j * 16 + l15;
         if (EDGE && (row >= p.M || col >= p.N)) continue;
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * Cin[(long)row * p.ldcin + col];
@@ -213,18 +226,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   }
 }
 
-template <bool TRANSB, bool EDGE>
+template <bool TRANSB, bool EDGE, int WT>
 int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
   static bool attr_set = false;
-  auto kern = gemm_f64_kernel<TRANSB, EDGE>;
+  auto kern = gemm_f64_kernel<TRANSB, EDGE, WT>;
   if (!attr_set) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WT>::SMEM_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), SMEM_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), Geo<WT>::SMEM_BYTES, ctx->stream, p);
   DFH_LAUNCH_CHECK();
   return DFH_OK;
+}
+
+template <int WT>
+int dispatch(dfh_ctx* ctx, GemmArgs& p, int count, bool edge) {
+  constexpr int BM = Geo<WT>::BM, BN = Geo<WT>::BN;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const long ntiles = (p.flags & GEMM_LOWER) ? (long)p.tiles_m * (p.tiles_m + 1) / 2 : (long)p.tiles_m * p.tiles_n;
+  dim3 grid((unsigned)ntiles, 1, (unsigned)count);
+  edge = edge || (p.M % BM) || (p.N % BN);
+  if (p.flags & GEMM_TRANSB)
+    return edge ? launch<true, true, WT>(ctx, p, grid) : launch<true, false, WT>(ctx, p, grid);
+  return edge ? launch<false, true, WT>(ctx, p, grid) : launch<false, false, WT>(ctx, p, grid);
 }
 
 }  // namespace
@@ -245,17 +271,12 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
   int count = 1;
   if (batch) { count = batch->count; p.sA = batch->sA; p.sB = batch->sB; p.sCin = batch->sCin; p.sCout = batch->sCout; }
   p.alpha = alpha; p.beta = beta; p.flags = flags;
-  p.tiles_m = (int)((M + BM - 1) / BM);
-  p.tiles_n = (int)((N + BN - 1) / BN);
-  long ntiles = (flags & GEMM_LOWER) ? (long)p.tiles_m * (p.tiles_m + 1) / 2 : (long)p.tiles_m * p.tiles_n;
-  dim3 grid((unsigned)ntiles, 1, (unsigned)count);
-  const bool transb = flags & GEMM_TRANSB;
   auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  bool edge = (M % BM) || (N % BN) || (K % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) ||
-              !aligned16(B) || ((p.sA | p.sB) & 1);
-  if (transb) {
-    return edge ? launch<true, true>(ctx, p, grid) : launch<true, false>(ctx, p, grid);
-  } else {
-    return edge ? launch<false, true>(ctx, p, grid) : launch<false, false>(ctx, p, grid);
-  }
+  const bool edge = (K % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B) ||
+                    ((p.sA | p.sB) & 1);
+  // Small problems are latency-bound on a single 128x128 tile per CU: use 64x64 tiles when the
+  // 128-tiling would leave most of the 256 CUs idle.
+  const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * (long)count;
+  if (t128 < 192) return dispatch<2>(ctx, p, count, edge);
+  return dispatch<4>(ctx, p, count, edge);
 }

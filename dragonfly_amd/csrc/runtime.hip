@@ -53,6 +53,12 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
   snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
            prop.multiProcessorCount);
   DFH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->main_stream = ctx->stream;
+  {
+    int least = 0, greatest = 0;
+    DFH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    DFH_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
+  }
   DFH_HIP(hipEventCreate(&ctx->ev0));
   DFH_HIP(hipEventCreate(&ctx->ev1));
   for (int i = 0; i < DFH_T_COUNT; ++i) {
@@ -61,6 +67,7 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
   }
   ctx->scratch.resize(SCR_COUNT);
   DFH_HIP(hipMalloc(&ctx->d_info, 8 * sizeof(int64_t)));
+  DFH_HIP(hipMemset(ctx->d_info, 0, 8 * sizeof(int64_t)));
   DFH_HIP(hipHostMalloc(&ctx->h_info, 8 * sizeof(int64_t)));
   *out = ctx;
   return DFH_OK;
@@ -80,7 +87,9 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
     (void)hipEventDestroy(ctx->tev0[i]);
     (void)hipEventDestroy(ctx->tev1[i]);
   }
-  (void)hipStreamDestroy(ctx->stream);
+  for (auto e : ctx->evpool) (void)hipEventDestroy(e);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
 }
 
@@ -162,11 +171,22 @@ SectionTimer::~SectionTimer() {
   if (hipEventElapsedTime(&f, ctx->tev0[which], ctx->tev1[which]) == hipSuccess) ctx->t_ms[which] += f;
 }
 
+int ctx_event(dfh_ctx* ctx, size_t idx, hipEvent_t* out) {
+  while (ctx->evpool.size() <= idx) {
+    hipEvent_t e;
+    DFH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->evpool.push_back(e);
+  }
+  *out = ctx->evpool[idx];
+  return DFH_OK;
+}
+
 int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out) {
   DevBuf& b = ctx->scratch[slot];
   if (b.bytes < bytes || !b.p) {
     if (b.p) {
-      DFH_HIP(hipStreamSynchronize(ctx->stream));
+      DFH_HIP(hipStreamSynchronize(ctx->main_stream));
+      DFH_HIP(hipStreamSynchronize(ctx->side));
       DFH_HIP(hipFree(b.p));
       b.p = nullptr; b.bytes = 0;
     }
@@ -387,9 +407,47 @@ __global__ void k_gemv_rows(const double* __restrict__ A, int64_t n, int64_t lda
     yout[row] = v;
   }
 }
+// short rows: one wave per row, four rows per workgroup
+__global__ void k_gemv_rows_wave(const double* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                                 const double* __restrict__ x, double alpha, const double* yin,
+                                 double beta, double* yout) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const int lane = threadIdx.x & 63;
+  const double* a = A + row * lda;
+  double s0 = 0.0, s1 = 0.0;
+  const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec) {
+    const int64_t n2 = n >> 1;
+    for (int64_t j = lane; j < n2; j += 64) {
+      double2_t av = reinterpret_cast<const double2_t*>(a)[j];
+      double2_t xv = reinterpret_cast<const double2_t*>(x)[j];
+      s0 = fma(av.x, xv.x, s0);
+      s1 = fma(av.y, xv.y, s1);
+    }
+    if ((n & 1) && lane == 0) s0 = fma(a[n - 1], x[n - 1], s0);
+  } else {
+    for (int64_t j = lane; j < n; j += 64) s0 = fma(a[j], x[j], s0);
+  }
+  double s = s0 + s1;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) {
+    double v = alpha * s;
+    if (beta != 0.0) v += beta * yin[row];
+    yout[row] = v;
+  }
+}
+
 int gemv_rows(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, const double* x,
               double alpha, const double* yin, double beta, double* yout, bool tri_lower) {
   if (m <= 0) return DFH_OK;
+  if (!tri_lower && n <= 1024) {
+    hipLaunchKernelGGL(k_gemv_rows_wave, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, A, m,
+                       n, lda, x, alpha, yin, beta, yout);
+    DFH_LAUNCH_CHECK();
+    return DFH_OK;
+  }
   hipLaunchKernelGGL(k_gemv_rows, dim3((unsigned)m), dim3(256), 0, ctx->stream, A, n, lda, x,
                      alpha, yin, beta, yout, tri_lower ? 1 : 0);
   DFH_LAUNCH_CHECK();
@@ -398,7 +456,7 @@ int gemv_rows(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, 
 
 // A^T x : stage 1, each block owns a slab of GC_ROWS rows and 512 columns (2 per thread) and
 // writes one partial per column; stage 2 adds the slab partials in slab order (deterministic).
-#define GC_ROWS 128
+#define GC_ROWS 32
 __global__ void k_gemv_cols_partial(const double* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                                     const double* __restrict__ x, double* __restrict__ part) {
   const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
