@@ -76,6 +76,7 @@ SIGNATURES = {
   'dfh_gp_add_ucb_group': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int64,
                                      C.c_void_p, c_double_p, c_int64_p]),
   'dfh_ctx_timings': (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+  'dfh_ctx_gemm_profile': (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
 }
 
 _lib = None

@@ -60,6 +60,11 @@ struct dfh_ctx {
   hipEvent_t tev0[DFH_T_COUNT] = {nullptr}, tev1[DFH_T_COUNT] = {nullptr};   // one pair per section (nestable)
   char name[256] = {0};
   int n_cu = 256;
+  // per-launch HIP-event profile of the GEMM kernel (bench.py roofline numbers)
+  bool gemm_prof = false;
+  struct GemmRec { hipEvent_t e0, e1; double flops; int variant; };
+  std::vector<GemmRec> gemm_recs;
+  size_t gemm_used = 0;
 };
 
 enum ScratchSlot {

@@ -235,8 +235,27 @@ int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WT>::SMEM_BYTES));
     attr_set = true;
   }
+  dfh_ctx::GemmRec* rec = nullptr;
+  if (ctx->gemm_prof) {
+    if (ctx->gemm_used == ctx->gemm_recs.size()) {
+      dfh_ctx::GemmRec r;
+      DFH_HIP(hipEventCreate(&r.e0));
+      DFH_HIP(hipEventCreate(&r.e1));
+      r.flops = 0.0; r.variant = 0;
+      ctx->gemm_recs.push_back(r);
+    }
+    rec = &ctx->gemm_recs[ctx->gemm_used++];
+    // algorithmic flops: only the triangle LOWER asks for, only the k-range a triangular B has
+    double f = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    if (p.flags & GEMM_LOWER) f = (double)p.M * ((double)p.M + 1.0) * (double)p.K;
+    if (p.flags & GEMM_KTRI_B) f = (double)p.M * (double)p.N * ((double)p.N + 1.0);
+    rec->flops = f * (double)grid.z;
+    rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);
+    DFH_HIP(hipEventRecord(rec->e0, ctx->stream));
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), Geo<WT>::SMEM_BYTES, ctx->stream, p);
   DFH_LAUNCH_CHECK();
+  if (rec) DFH_HIP(hipEventRecord(rec->e1, ctx->stream));
   return DFH_OK;
 }
 
@@ -279,4 +298,27 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * (long)count;
   if (t128 < 192) return dispatch<2>(ctx, p, count, edge);
   return dispatch<4>(ctx, p, count, edge);
+}
+
+// Enable / disable per-launch event timing of the GEMM kernel and fetch the totals.
+// stats_out[8][3]: per kernel variant (bit2 = NN, bit1 = edge path, bit0 = 64x64 tiles; variant 0
+// is the 128x128 NT throughput configuration) {launches, total ms, algorithmic flop}.
+extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out) {
+  DFH_ARG(ctx != nullptr);
+  if (stats_out) {
+    for (int i = 0; i < 24; ++i) stats_out[i] = 0.0;
+    DFH_HIP(hipStreamSynchronize(ctx->main_stream));
+    DFH_HIP(hipStreamSynchronize(ctx->side));
+    for (size_t i = 0; i < ctx->gemm_used; ++i) {
+      float ms = 0.f;
+      DFH_HIP(hipEventElapsedTime(&ms, ctx->gemm_recs[i].e0, ctx->gemm_recs[i].e1));
+      const int v = ctx->gemm_recs[i].variant;
+      stats_out[v * 3 + 0] += 1.0;
+      stats_out[v * 3 + 1] += (double)ms;
+      stats_out[v * 3 + 2] += ctx->gemm_recs[i].flops;
+    }
+  }
+  ctx->gemm_used = 0;
+  ctx->gemm_prof = enable != 0;
+  return DFH_OK;
 }

@@ -88,6 +88,7 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
     (void)hipEventDestroy(ctx->tev1[i]);
   }
   for (auto e : ctx->evpool) (void)hipEventDestroy(e);
+  for (auto& r : ctx->gemm_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;

@@ -186,6 +186,12 @@ class Engine(object):
     check(self.lib.dfh_ctx_timings(self.ctx, 1 if enable else 0, arr))
     return dict(zip(_lib.T_NAMES, list(arr)))
 
+  def gemm_profile(self, enable=True, fetch=True):
+    """ Per-variant {launches, ms, flop} of the GEMM kernel since the last call (HIP events). """
+    arr = (C.c_double * 24)()
+    check(self.lib.dfh_ctx_gemm_profile(self.ctx, 1 if enable else 0, arr if fetch else None))
+    return [dict(launches=int(arr[3 * v]), ms=arr[3 * v + 1], flop=arr[3 * v + 2]) for v in range(8)]
+
   # -- building blocks ---------------------------------------------------------------------
   def kernel_matrix(self, spec, X1, X2=None, diag_add=0.0, out=None):
     X1h = X1 if isinstance(X1, DeviceArray) else _f64(X1)

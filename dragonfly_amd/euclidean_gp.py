@@ -1,0 +1,475 @@
+"""GPs on Euclidean spaces -- host-side mirror of dragonfly/gp/euclidean_gp.py:134-340,718-900
+(EuclideanGP, EuclideanGPFitter, the kernel factory) and of the parts of GPFitter
+(dragonfly/gp/gp_core.py:306-821) the maximum-likelihood route needs.
+
+Every GP the fitter builds, and every log-marginal-likelihood it evaluates while tuning
+hyper-parameters, is one dfh_gp_fit call on the MI355X (the training inputs are uploaded once per
+fitter and stay in HBM: SURVEY.md section 8f item 1).  Hyper-parameter *search* strategies that
+are serial host-side tree searches / MCMC in the reference (DIRECT, PDOO, slice / NUTS posterior
+sampling: out of scope) are available only when this package
+is installed under a real Dragonfly (dragonfly_amd.install); stand-alone the fitter offers the
+two data-parallel strategies of the reference, 'rand' and 'rand_exp_sampling'.
+"""
+from argparse import Namespace
+from itertools import product as itertools_product
+
+import numpy as np
+
+from . import kernel as gp_kernel
+from .engine import get_engine
+from .general_utils import map_to_bounds
+from .gp_core import GP
+from .kernel import _as_2d_array
+from .oper_utils import random_maximise, random_sample_cts_dscr
+from .option_handler import get_option_specs, load_options
+
+_DFLT_KERNEL_TYPE = 'matern'
+
+# gp_core.py:31-68 (mandatory_gp_args)
+mandatory_gp_args = [
+  get_option_specs('hp_tune_criterion', False, 'ml', 'ml | post_sampling'),
+  get_option_specs('hp_tune_probs', False, 'uniform', ''),
+  get_option_specs('ml_hp_tune_opt', False, 'default', 'rand | rand_exp_sampling | direct | pdoo'),
+  get_option_specs('hp_tune_max_evals', False, -1, ''),
+  get_option_specs('handle_non_psd_kernels', False, 'guaranteed_psd', ''),
+  get_option_specs('mean_func', False, None, ''),
+  get_option_specs('mean_func_type', False, 'tune', 'mean | median | const | zero | tune'),
+  get_option_specs('mean_func_const', False, 0.0, ''),
+  get_option_specs('noise_var_type', False, 'tune', 'tune | label | value'),
+  get_option_specs('noise_var_label', False, 0.05, ''),
+  get_option_specs('noise_var_value', False, 0.1, ''),
+  get_option_specs('post_hp_tune_method', False, 'slice', ''),
+  get_option_specs('post_hp_tune_burn', False, -1, ''),
+  get_option_specs('post_hp_tune_offset', False, 25, ''),
+  get_option_specs('rand_exp_sampling_replace', False, False, ''),
+]
+# euclidean_gp.py:27-73
+basic_euc_gp_args = [
+  get_option_specs('kernel_type', False, 'default', 'se | matern'),
+  get_option_specs('use_same_bandwidth', False, False, ''),
+]
+matern_gp_args = [get_option_specs('matern_nu', False, 2.5, '')]
+add_gp_args = [
+  get_option_specs('use_additive_gp', False, False, ''),
+  get_option_specs('add_max_group_size', False, 6, ''),
+  get_option_specs('add_grouping_criterion', False, 'randomised_ml', ''),
+  get_option_specs('num_groups_per_group_size', False, -1, ''),
+  get_option_specs('add_group_size_criterion', False, 'sampled', ''),
+]
+euclidean_gp_args = mandatory_gp_args + basic_euc_gp_args + matern_gp_args + add_gp_args
+
+
+class EuclideanGP(GP):
+  """ euclidean_gp.py:134-202 """
+
+  def __init__(self, X, Y, kernel, mean_func, noise_var,
+               kernel_hyperparams=None, build_posterior=True, reporter=None):
+    if isinstance(kernel, str):
+      kernel = self._get_kernel_from_type(kernel, kernel_hyperparams)
+    super(EuclideanGP, self).__init__(X, Y, kernel, mean_func, noise_var,
+                                      build_posterior, reporter)
+
+  @classmethod
+  def _get_kernel_from_type(cls, kernel_type, kernel_hyperparams):
+    """ euclidean_gp.py:154-175 (se and matern run on the device) """
+    if kernel_type in ['se']:
+      return gp_kernel.SEKernel(kernel_hyperparams['dim'], kernel_hyperparams['scale'],
+                                kernel_hyperparams['dim_bandwidths'])
+    elif kernel_type in ['matern']:
+      return gp_kernel.MaternKernel(kernel_hyperparams['dim'],
+                                    kernel_hyperparams['nu'], kernel_hyperparams['scale'],
+                                    kernel_hyperparams['dim_bandwidths'])
+    else:
+      raise ValueError('Cannot construct kernel from kernel_type %s.' % (kernel_type))
+
+  def _child_str(self):
+    """ euclidean_gp.py:177-183 """
+    ke_str = self._get_kernel_str(self.kernel)
+    dim = 0 if len(self.X) == 0 else len(self.X[0])
+    mean_str = 'mu(0)=%0.3f'%(self.mean_func([np.zeros(dim,)])[0])
+    ret = 'scale: %0.3f, %s, %s' % (self.kernel.hyperparams['scale'], ke_str, mean_str)
+    return ret
+
+  @classmethod
+  def _get_kernel_str(cls, kern):
+    """ euclidean_gp.py:185-202 """
+    if isinstance(kern, gp_kernel.AdditiveKernel):
+      return str(kern)
+    if isinstance(kern, (gp_kernel.SEKernel, gp_kernel.MaternKernel)):
+      kern_name = 'se' if isinstance(kern, gp_kernel.SEKernel) else \
+        'matern(%0.1f)' % (kern.hyperparams['nu'])
+      bws = kern.hyperparams['dim_bandwidths']
+      if kern.dim > 6:
+        ret = '%0.4f(avg)' % (bws.mean())
+      else:
+        ret = '[' + ', '.join(['%0.3f'%(b) for b in np.ravel(bws)]) + ']'
+      return kern_name + '-' + ret
+    return ''
+
+
+# Kernel factory ---------------------------------------------------------------------------------
+def get_sublist_from_indices(orig_list, idxs):
+  """ general_utils.py:30-33 """
+  return [orig_list[idx] for idx in idxs]
+
+
+def prep_euclidean_integral_kernel_hyperparams(kernel_type, gp_fitter_options, domain_dim):
+  """ euclidean_gp.py:777-792 """
+  hyperparams = {}
+  hyperparams['dim'] = domain_dim
+  if kernel_type == 'matern' and gp_fitter_options.matern_nu > 0:
+    hyperparams['nu'] = gp_fitter_options.matern_nu
+  return hyperparams
+
+
+def get_euclidean_integral_gp_kernel(kernel_type, kernel_hyperparams, gp_cts_hps,
+                                     gp_dscr_hps, use_same_bandwidth,
+                                     add_gp_groupings=None, esp_kernel_type=None):
+  """ euclidean_gp.py:796-805: the scale is the first continuous hyper-parameter. """
+  scale = np.exp(gp_cts_hps[0])
+  gp_cts_hps = gp_cts_hps[1:]
+  return get_euclidean_integral_gp_kernel_with_scale(kernel_type, scale, \
+    kernel_hyperparams, gp_cts_hps, gp_dscr_hps, use_same_bandwidth, add_gp_groupings, \
+    esp_kernel_type)
+
+
+def get_euclidean_integral_gp_kernel_with_scale(kernel_type, scale, kernel_hyperparams,
+                                                gp_cts_hps, gp_dscr_hps,
+                                                use_same_bandwidth, add_gp_groupings=None,
+                                                esp_kernel_type=None):
+  """ euclidean_gp.py:808-900 for the se / matern (and additive) kernels. """
+  # pylint: disable=unused-argument
+  dim = kernel_hyperparams['dim']
+  is_additive = False
+  if add_gp_groupings is None:
+    add_gp_groupings = [list(range(dim))]
+    grp_scale = scale
+  else:
+    is_additive = True
+    grp_scale = 1.0
+  if kernel_type not in ['se', 'matern']:
+    raise Exception('Unknown kernel type %s!'%(kernel_type))
+  if use_same_bandwidth:
+    ke_dim_bandwidths = [np.exp(gp_cts_hps[0])] * dim
+    gp_cts_hps = gp_cts_hps[1:]
+  else:
+    ke_dim_bandwidths = np.exp(gp_cts_hps[0:dim])
+    gp_cts_hps = gp_cts_hps[dim:]
+  if kernel_type == 'se':
+    grp_kernels = [gp_kernel.SEKernel(dim=len(grp), scale=grp_scale, \
+                     dim_bandwidths=get_sublist_from_indices(ke_dim_bandwidths, grp))
+                   for grp in add_gp_groupings]
+  else:
+    if 'nu' not in kernel_hyperparams or kernel_hyperparams['nu'] < 0:
+      matern_nu = gp_dscr_hps[0]
+      gp_dscr_hps = gp_dscr_hps[1:]
+    else:
+      matern_nu = kernel_hyperparams['nu']
+    grp_kernels = [gp_kernel.MaternKernel(dim=len(grp), nu=matern_nu, scale=grp_scale, \
+                     dim_bandwidths=get_sublist_from_indices(ke_dim_bandwidths, grp))
+                   for grp in add_gp_groupings]
+  if is_additive:
+    euc_kernel = gp_kernel.AdditiveKernel(scale=scale, kernel_list=grp_kernels,
+                                          groupings=add_gp_groupings)
+  else:
+    euc_kernel = grp_kernels[0]
+  return euc_kernel, gp_cts_hps, gp_dscr_hps
+
+
+# Additive-model helpers (euclidean_gp.py:718-774) -------------------------------------------------
+def optimise_cts_hps_for_given_dscr_hps_in_add_model(given_dscr_hps, \
+    num_groups_per_group_size, dim, hp_tune_max_evals, cts_hp_optimise, \
+    tuning_objective):
+  """ euclidean_gp.py:718-746 """
+  group_size = given_dscr_hps[-1]
+  if num_groups_per_group_size < 0:
+    if group_size == 1:
+      num_groups_per_group_size = 1
+    else:
+      num_groups_per_group_size = max(5, min(2 * dim, 25))
+  grp_best_hps = None
+  grp_best_val = -np.inf
+  grp_best_other_params = None
+  for _ in range(num_groups_per_group_size):
+    rand_perm = list(np.random.permutation(dim))
+    groupings = [rand_perm[i:i+group_size]
+                 for i in range(0, dim, group_size)]
+    other_gp_params = Namespace(add_gp_groupings=groupings)
+    cts_tuning_objective = lambda arg: tuning_objective(arg, given_dscr_hps[:],
+                                                        other_gp_params=other_gp_params)
+    max_evals = int(max(500, hp_tune_max_evals/num_groups_per_group_size))
+    opt_cts_val, opt_cts_hps, _ = cts_hp_optimise(cts_tuning_objective, max_evals)
+    if opt_cts_val > grp_best_val:
+      grp_best_val = opt_cts_val
+      grp_best_hps = opt_cts_hps
+      grp_best_other_params = other_gp_params
+  return grp_best_val, grp_best_hps, grp_best_other_params
+
+
+class EuclideanGPFitter(object):
+  """ Fits a GP by tuning the kernel hyper-parameters (euclidean_gp.py:205-340 on top of
+      gp_core.py:306-821).  Hyper-parameter vector order (euclidean_gp.py:217-219): continuous =
+      [mean value (if tuned), log noise variance (if tuned), log scale, log bandwidths...],
+      discrete = [matern nu (if tuned), additive group size (if additive)]. """
+  # pylint: disable=too-many-instance-attributes
+
+  def __init__(self, X, Y, options=None, reporter=None):
+    assert len(X) == len(Y)
+    self.dim = len(X[0])
+    self.reporter = reporter
+    self.options = load_options(euclidean_gp_args, partial_options=options)
+    self.X = X
+    self.Y = np.asarray(Y, dtype=np.float64)
+    self.num_data = len(X)
+    self._X_dev = None
+    self._set_up()
+
+  # -- set up (gp_core.py:323-356, 393-416; euclidean_gp.py:215-276) -------------------------------
+  def _set_up(self):
+    self.cts_hp_bounds = []
+    self.dscr_hp_vals = []
+    self.param_order = []
+    epsilon = 0.0001
+    self.Y_var = np.array(self.Y).std() ** 2 + epsilon if len(self.Y) > 0 else epsilon
+    self._set_up_mean_and_noise_variance_bounds()
+    self._child_set_up()
+    self.methods_to_use = [elem.lower() for elem in self.options.hp_tune_criterion.split('-')]
+    for method in self.methods_to_use:
+      if method not in ['ml', 'post_sampling', 'post_mean']:
+        raise ValueError('hp_tune_criterion should be ml or post_sampling.')
+      if method != 'ml':
+        raise NotImplementedError(
+            'hp_tune_criterion=%s is a serial host-side MCMC in the reference and is not part of '
+            'the device engine; use dragonfly_amd.install under Dragonfly for it.' % (method))
+    self.cts_hp_bounds = np.array(self.cts_hp_bounds)
+    self.num_hps = len(self.cts_hp_bounds) + len(self.dscr_hp_vals)
+    self._set_up_ml_hp_tune()
+
+  def _set_up_mean_and_noise_variance_bounds(self):
+    """ gp_core.py:393-416 """
+    if not (hasattr(self.options, 'mean_func') and self.options.mean_func is not None) \
+      and self.options.mean_func_type == 'tune':
+      Y_std = np.sqrt(self.Y_var)
+      if len(self.Y) > 0:
+        Y_median = np.median(self.Y)
+        Y_half_range = 0.5 * (max(self.Y) - min(self.Y))
+      else:
+        Y_median = 0.0
+        Y_half_range = 1.0
+      Y_width = 0.5 * (Y_half_range + Y_std)
+      self.mean_func_bounds = [Y_median - 3 * Y_width, Y_median + 3 * Y_width]
+      self.cts_hp_bounds.append(self.mean_func_bounds)
+      self.param_order.append(["noise_mean", "cts"])
+    if self.options.noise_var_type == 'tune':
+      self.noise_var_log_bounds = [np.log(0.005 * self.Y_var), np.log(0.2 * self.Y_var)]
+      self.cts_hp_bounds.append(self.noise_var_log_bounds)
+      self.param_order.append(["noise_var", "cts"])
+
+  def _child_set_up(self):
+    """ euclidean_gp.py:215-252 """
+    if self.options.kernel_type not in ['se', 'matern', 'default']:
+      raise ValueError('Unknown kernel_type. Should be either se, matern or poly.')
+    if self.options.noise_var_type not in ['tune', 'label', 'value']:
+      raise ValueError('Unknown noise_var_type. Should be either tune, label or value.')
+    if self.options.mean_func_type not in ['mean', 'median', 'const', 'zero', 'tune']:
+      raise ValueError('Unknown mean_func_type. Should be mean/median/const/zero/tune.')
+    self.kernel_type = _DFLT_KERNEL_TYPE if self.options.kernel_type == 'default' else \
+                       self.options.kernel_type
+    # scale and bandwidths (euclidean_gp.py:254-268)
+    self.scale_log_bounds = [np.log(0.1 * self.Y_var), np.log(10 * self.Y_var)]
+    self.param_order.append(["scale", "cts"])
+    X_std_norm = np.linalg.norm(_as_2d_array(self.X), 'fro') + 1e-4
+    single_bandwidth_log_bounds = [np.log(0.01 * X_std_norm), np.log(10 * X_std_norm)]
+    if self.options.use_same_bandwidth:
+      self.bandwidth_log_bounds = [single_bandwidth_log_bounds]
+      self.param_order.append(["same_dim_bandwidths", "cts"])
+    else:
+      self.bandwidth_log_bounds = [single_bandwidth_log_bounds] * self.dim
+      for _ in range(self.dim):
+        self.param_order.append(["dim_bandwidths", "cts"])
+    self.cts_hp_bounds += [self.scale_log_bounds] + self.bandwidth_log_bounds
+    if self.kernel_type == 'matern' and self.options.matern_nu < 0:
+      self.dscr_hp_vals.append([0.5, 1.5, 2.5])
+      self.param_order.append(["nu", "dscr"])
+    if self.options.use_additive_gp:
+      self.add_group_size_idx_in_dscr_hp_vals = len(self.dscr_hp_vals)
+      self.add_max_group_size = min(self.options.add_max_group_size, self.dim)
+      self.dscr_hp_vals.append([x+1 for x in range(self.add_max_group_size)])
+      self.param_order.append(["additive_grp", "dscr"])
+
+  def _set_up_ml_hp_tune(self):
+    """ gp_core.py:423-474, restricted to the batchable optimisers. """
+    method = self.options.ml_hp_tune_opt
+    if method == 'default':
+      method = 'rand'
+    if method not in ['rand', 'rand_exp_sampling']:
+      raise NotImplementedError(
+          'ml_hp_tune_opt=%s (a serial tree search in the reference) is not part of the device '
+          'engine; use "rand" / "rand_exp_sampling", or dragonfly_amd.install under Dragonfly.'
+          % (method))
+    self.ml_hp_tune_opt_method = method
+    if self.options.hp_tune_max_evals is not None and self.options.hp_tune_max_evals > 0:
+      self.hp_tune_max_evals = self.options.hp_tune_max_evals
+    elif method == 'rand':
+      self.hp_tune_max_evals = min(1e4, max(500, self.num_hps * 200))
+    else:
+      self.hp_tune_max_evals = min(1e5, max(500, self.num_hps * 400))
+    def _rand_wrap(obj, max_evals):
+      opt_val, opt_pt, _ = random_maximise(obj, self.cts_hp_bounds, max_evals, vectorised=False)
+      return opt_val, opt_pt, None
+    def _rand_exp_sampling_wrap(obj, max_evals):
+      sample_cts_hps, sample_dscr_hps, lml_vals = \
+        random_sample_cts_dscr(obj, self.cts_hp_bounds, self.dscr_hp_vals, max_evals,
+                               vectorised=False)
+      sample_probs = np.exp(lml_vals - max(lml_vals))
+      sample_probs = sample_probs / sample_probs.sum()
+      return sample_cts_hps, sample_dscr_hps, sample_probs
+    self.cts_hp_optimise = _rand_wrap
+    self.hp_sampler = _rand_exp_sampling_wrap
+
+  # -- building GPs (gp_core.py:501-543; euclidean_gp.py:325-339) ----------------------------------
+  def _device_X(self):
+    """ The training inputs are uploaded once and reused by every candidate GP. """
+    if self._X_dev is None:
+      self._X_dev = get_engine().to_device(_as_2d_array(self.X))
+    return self._X_dev
+
+  def build_gp(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None, *args, **kwargs):
+    """ gp_core.py:501-543 """
+    if self.num_hps != len(gp_cts_hps) + len(gp_dscr_hps):
+      raise ValueError('gp_hyperparams should be of length %d. Given length: %d.'%(
+          self.num_hps, len(gp_cts_hps) + len(gp_dscr_hps)))
+    if hasattr(self.options, 'mean_func') and self.options.mean_func is not None:
+      mean_func = self.options.mean_func
+    else:
+      if self.options.mean_func_type == 'mean':
+        mean_func_const_value = np.mean(self.Y)
+      elif self.options.mean_func_type == 'median':
+        mean_func_const_value = np.median(self.Y)
+      elif self.options.mean_func_type == 'upper_bound':
+        mean_func_const_value = np.mean(self.Y) + 3 * np.std(self.Y)
+      elif self.options.mean_func_type == 'const':
+        mean_func_const_value = self.options.mean_func_const
+      elif self.options.mean_func_type == 'tune':
+        mean_func_const_value = np.asarray(gp_cts_hps[0]).item()
+        gp_cts_hps = gp_cts_hps[1:]
+      else:
+        mean_func_const_value = 0
+      def _get_mean_func(_mean_func_const_value):
+        return lambda x: np.array([_mean_func_const_value] * len(x))
+      mean_func = _get_mean_func(mean_func_const_value)
+    if self.options.noise_var_type == 'tune':
+      noise_var = np.exp(gp_cts_hps[0])
+      gp_cts_hps = gp_cts_hps[1:]
+    elif self.options.noise_var_type == 'label':
+      noise_var = self.options.noise_var_label * (self.Y.std() ** 2)
+    else:
+      noise_var = self.options.noise_var_value
+    ret_gp, ret_cts_hps, ret_dscr_hps = self._child_build_gp(mean_func, noise_var, \
+       gp_cts_hps, gp_dscr_hps, other_gp_params=other_gp_params, *args, **kwargs)
+    assert len(ret_cts_hps) == 0
+    assert len(ret_dscr_hps) == 0
+    return ret_gp
+
+  def _child_build_gp(self, mean_func, noise_var, gp_cts_hps, gp_dscr_hps,
+                      other_gp_params=None, *args, **kwargs):
+    """ euclidean_gp.py:325-339 """
+    kernel_hyperparams = prep_euclidean_integral_kernel_hyperparams(self.kernel_type,
+                                                                    self.options, self.dim)
+    add_gp_groupings = None
+    if self.options.use_additive_gp:
+      gp_dscr_hps = gp_dscr_hps[:-1]
+      add_gp_groupings = other_gp_params.add_gp_groupings
+    kernel, gp_cts_hps, gp_dscr_hps = \
+      get_euclidean_integral_gp_kernel(self.kernel_type, kernel_hyperparams, gp_cts_hps,
+                                       gp_dscr_hps, self.options.use_same_bandwidth,
+                                       add_gp_groupings)
+    build_posterior = kwargs.pop('build_posterior', True)
+    ret_gp = EuclideanGP(self.X, self.Y, kernel, mean_func, noise_var, *args,
+                         build_posterior=False, **kwargs)
+    ret_gp._X_dev_hint = self._device_X()     # pylint: disable=protected-access
+    if build_posterior:
+      ret_gp.build_posterior()
+    return ret_gp, gp_cts_hps, gp_dscr_hps
+
+  def _tuning_objective(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None, *args, **kwargs):
+    """ gp_core.py:551-564: log marginal likelihood of the GP with these hyper-parameters. The
+        candidate is fitted on the device and released at once (only its lml is kept). """
+    built_gp = self.build_gp(gp_cts_hps, gp_dscr_hps, other_gp_params=other_gp_params,
+                             *args, **kwargs)
+    ret = built_gp.compute_log_marginal_likelihood()
+    built_gp._invalidate()     # pylint: disable=protected-access
+    return ret
+
+  def _optimise_cts_hps_for_given_dscr_hps(self, given_dscr_hps):
+    """ gp_core.py:576-583 / euclidean_gp.py:303-313 """
+    if self.options.use_additive_gp:
+      return optimise_cts_hps_for_given_dscr_hps_in_add_model(list(given_dscr_hps), \
+        self.options.num_groups_per_group_size, self.dim, self.hp_tune_max_evals, \
+        self.cts_hp_optimise, self._tuning_objective)
+    cts_tuning_obj = lambda arg: self._tuning_objective(arg, list(given_dscr_hps))
+    opt_cts_val, opt_cts_hps, _ = self.cts_hp_optimise(cts_tuning_obj, self.hp_tune_max_evals)
+    return opt_cts_val, opt_cts_hps, None
+
+  def fit_gp(self, num_samples=1, hp_tune_criterion=None):
+    """ gp_core.py:783-821 ('ml' branch). Returns ('fitted_gp', gp, (cts_hps, dscr_hps)) or, for
+        rand_exp_sampling, ('sample_hps_with_probs', cts, dscr, other_params, probs). """
+    # pylint: disable=unused-argument
+    if hp_tune_criterion is None:
+      hp_tune_criterion = self.options.hp_tune_criterion
+    if hp_tune_criterion != 'ml':
+      raise NotImplementedError('Only hp_tune_criterion="ml" runs on the device engine.')
+    if self.ml_hp_tune_opt_method == 'rand':
+      best_cts_hps = None
+      best_dscr_hps = None
+      best_other_params = None
+      best_hps_val = -np.inf
+      for dscr_hps in itertools_product(*self.dscr_hp_vals):
+        opt_cts_val, opt_cts_hps, opt_other_params = \
+           self._optimise_cts_hps_for_given_dscr_hps(dscr_hps)
+        if opt_cts_val > best_hps_val:
+          best_cts_hps = list(opt_cts_hps)
+          best_dscr_hps = list(dscr_hps)
+          best_other_params = opt_other_params
+          best_hps_val = opt_cts_val
+      opt_gp = self.build_gp(best_cts_hps, best_dscr_hps, other_gp_params=best_other_params)
+      opt_hps = (best_cts_hps, best_dscr_hps)
+      return 'fitted_gp', opt_gp, opt_hps
+    if self.options.use_additive_gp:
+      raise NotImplementedError('rand_exp_sampling with additive GPs: use ml_hp_tune_opt="rand".')
+    sample_cts_hps, sample_dscr_hps, sample_probs = \
+      self.hp_sampler(self._tuning_objective, self.hp_tune_max_evals)
+    sample_other_gp_params = [None] * len(sample_cts_hps)
+    return ('sample_hps_with_probs', sample_cts_hps, sample_dscr_hps,
+            sample_other_gp_params, sample_probs)
+
+  def fit_gp_for_gp_bandit(self, num_samples=1):
+    """ gp_core.py:748-781 """
+    self.hp_tune_results = {}
+    for method in self.methods_to_use:
+      ret = self.fit_gp(num_samples, method)
+      if ret[0] == 'fitted_gp':
+        self.hp_tune_results[method] = (ret[0], ret[1])
+      else:
+        sample_hps = list(zip(ret[1], ret[2], ret[3]))
+        sample_probs = ret[-1]
+        if sum(sample_probs > 0) >= num_samples:
+          to_replace = self.options.rand_exp_sampling_replace
+        else:
+          to_replace = True
+        use_hps_idxs = np.random.choice(len(sample_hps), size=(num_samples,),
+                                        replace=to_replace, p=sample_probs)
+        self.hp_tune_results[method] = (ret[0], [sample_hps[idx] for idx in use_hps_idxs])
+
+  def get_next_gp(self):
+    """ gp_core.py:728-741 """
+    method = np.random.choice(self.methods_to_use)
+    fit_type = self.hp_tune_results[method][0]
+    if fit_type == 'fitted_gp':
+      gp = self.hp_tune_results[method][1]
+    else:
+      next_gp_hps = self.hp_tune_results[method][1].pop(0)
+      self.hp_tune_results[method][1].append(next_gp_hps)
+      gp = self.build_gp(next_gp_hps[0], next_gp_hps[1], other_gp_params=next_gp_hps[2],
+                         build_posterior=False)
+    return (fit_type, method, gp)

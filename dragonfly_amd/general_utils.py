@@ -1,0 +1,84 @@
+"""Device-backed versions of the linear-algebra helpers of dragonfly/utils/general_utils.py that
+sit on the GP hot path: dist_squared (:58-70), stable_cholesky (:166-204),
+solve_lower/upper_triangular (:208-221), draw_gaussian_samples (:224-232), plus the two
+one-line domain maps (:20-27).  Same names, arguments and error behaviour as the reference.
+"""
+import numpy as np
+
+from .engine import get_engine
+
+
+def map_to_cube(pts, bounds):
+  """ general_utils.py:20-22 """
+  return (pts - bounds[:, 0])/(bounds[:, 1] - bounds[:, 0])
+
+
+def map_to_bounds(pts, bounds):
+  """ general_utils.py:25-27 """
+  return pts * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+
+
+def dist_squared(X1, X2):
+  """ n1 x n2 matrix of squared distances, clipped at zero (general_utils.py:58-70). """
+  X1 = np.asarray(X1, dtype=np.float64)
+  X2 = np.asarray(X2, dtype=np.float64)
+  _, dim1 = X1.shape
+  _, dim2 = X2.shape
+  if dim1 != dim2:
+    raise ValueError('Second dimension of X1 and X2 should be equal.')
+  return get_engine().dist_squared(X1, X2)
+
+
+def stable_cholesky(M, add_to_diag_till_psd=True):
+  """ L with L L' = M; if M is numerically not psd, 10^p * max(diag(M)) is added to the diagonal
+      for p = -11..4 (general_utils.py:166-204).  Raises np.linalg.LinAlgError when
+      add_to_diag_till_psd is False and the plain factorisation fails, ValueError when the
+      ladder is exhausted. """
+  M = np.asarray(M, dtype=np.float64)
+  if M.size == 0:
+    return M
+  eng = get_engine()
+  if not add_to_diag_till_psd:
+    return eng.cholesky(M)
+  L, power = eng.stable_cholesky(M, return_power=True)
+  if power is not None and power >= -7:
+    # the reference warns once, at the first failed attempt with power > -9 (i.e. -8)
+    from warnings import warn
+    warn(('Could not compute Cholesky decomposition despite adding %0.4f to the '
+          'diagonal. This is likely because the M is not positive semi-definite.')%(
+              (10**-8) * np.diag(M).max()))
+  return L
+
+
+def _solve_triangular_common(A, b, lower):
+  """ general_utils.py:208-213 """
+  A = np.asarray(A, dtype=np.float64)
+  b = np.asarray(b, dtype=np.float64)
+  if A.size == 0 and b.shape[0] == 0:
+    return np.zeros((b.shape))
+  eng = get_engine()
+  if lower:
+    return eng.solve_triangular(A, b, upper=False)
+  # A is upper triangular: A = L^T with L = A^T lower triangular
+  return eng.solve_triangular(np.ascontiguousarray(A.T), b, upper=True)
+
+
+def solve_lower_triangular(A, b):
+  """ Solves Ax=b when A is lower triangular (general_utils.py:215-217). """
+  return _solve_triangular_common(A, b, lower=True)
+
+
+def solve_upper_triangular(A, b):
+  """ Solves Ax=b when A is upper triangular (general_utils.py:219-221). """
+  return _solve_triangular_common(A, b, lower=False)
+
+
+def draw_gaussian_samples(num_samples, mu, K):
+  """ num_samples draws from N(mu, K) (general_utils.py:224-232); the normals come from the
+      global np.random state with the reference's call, the factor and the product from the
+      device. """
+  num_pts = len(mu)
+  L = stable_cholesky(K)
+  U = np.random.normal(size=(num_pts, num_samples))
+  V = get_engine().gemm(L, U, transb=True).T + mu
+  return V

@@ -1,0 +1,222 @@
+"""GP posterior on the MI355X -- host-side mirror of dragonfly/gp/gp_core.py:86-303 (class GP).
+
+Same constructor, attributes and methods as the reference's GP, so it is a drop-in for the code
+that consumes a GP (gp_bandit, the acquisitions, user code).  The kernel matrix, its Cholesky
+factor, alpha, the log marginal likelihood, the posterior mean / std / covariance and the
+Gaussian draws are all computed by libdfhip.so and stay resident in HBM; `L`, `alpha` and
+`K_trtr_wo_noise` are materialised as NumPy arrays only when something reads them
+(gpb_acquisitions.py:169,171 and gp_core.py:203 do).  There is no NumPy compute path.
+"""
+import sys
+
+import numpy as np
+
+from .engine import get_engine
+from .general_utils import draw_gaussian_samples
+from .kernel import _as_2d_array
+
+
+def _check_feature_label_lengths_and_format(X, Y):
+  """ gp_core.py:72-76 """
+  if len(X) != len(Y):
+    raise ValueError('Length of X (' + str(len(X)) + ') and Y (' + \
+      str(len(Y)) + ') do not match.')
+
+
+class GP(object):
+  """ Base class for Gaussian processes (gp_core.py:86). """
+  # pylint: disable=attribute-defined-outside-init
+  # pylint: disable=too-many-instance-attributes
+
+  def __init__(self, X, Y, kernel, mean_func, noise_var, build_posterior=True,
+               reporter=None, handle_non_psd_kernels='guaranteed_psd'):
+    super(GP, self).__init__()
+    _check_feature_label_lengths_and_format(X, Y)
+    self._fitted = None
+    self._cache = {}
+    self.set_data(X, Y, build_posterior=False)
+    self.kernel = kernel
+    self.mean_func = mean_func
+    self.noise_var = noise_var
+    self.reporter = reporter
+    self.handle_non_psd_kernels = handle_non_psd_kernels
+    self.num_tr_data = len(self.Y)
+    self._set_up()
+    if build_posterior:
+      self.build_posterior()
+
+  def _set_up(self):
+    """ gp_core.py:112-118: only guaranteed-psd (Euclidean) kernels run on the device. """
+    if not self.kernel.is_guaranteed_psd() or self.handle_non_psd_kernels != 'guaranteed_psd':
+      raise NotImplementedError('dragonfly_amd.GP handles guaranteed-psd Euclidean kernels '
+                                '(handle_non_psd_kernels="guaranteed_psd") only.')
+    if not hasattr(self.kernel, 'to_spec'):
+      raise TypeError('dragonfly_amd.GP needs a dragonfly_amd.kernel kernel (SE, Matern or '
+                      'Additive); got %s. There is no CPU fallback.' % (type(self.kernel)))
+
+  def _write_message(self, msg):
+    if self.reporter:
+      self.reporter.write(msg)
+    else:
+      sys.stdout.write(msg)
+
+  # -- data ----------------------------------------------------------------------------------
+  def set_data(self, X, Y, build_posterior=True):
+    """ gp_core.py:127-133 """
+    self.X = list(X)
+    self.Y = list(Y)
+    self.num_tr_data = len(self.Y)
+    self._X_dev_hint = None
+    self._invalidate()
+    if build_posterior:
+      self.build_posterior()
+
+  def add_data_single(self, x_new, y_new, *args, **kwargs):
+    """ gp_core.py:135-137 """
+    self.add_data_multiple([x_new], [y_new], *args, **kwargs)
+
+  def add_data_multiple(self, X_new, Y_new, build_posterior=True):
+    """ gp_core.py:139-146 """
+    _check_feature_label_lengths_and_format(X_new, Y_new)
+    self.X.extend(X_new)
+    self.Y.extend(Y_new)
+    self.num_tr_data = len(self.Y)
+    self._X_dev_hint = None
+    self._invalidate()
+    if build_posterior:
+      self.build_posterior()
+
+  def _invalidate(self):
+    # drop (not free): shallow copies made by the synchronous acquisitions share the handle;
+    # the HBM buffers are released when the last reference to the FittedGP goes away.
+    self._fitted = None
+    self._cache = {}
+
+  # -- posterior -------------------------------------------------------------------------------
+  def _get_training_kernel_matrix(self):
+    """ gp_core.py:149-153 """
+    return self.kernel(self.X, self.X)
+
+  def _X_array(self):
+    return _as_2d_array(self.X)
+
+  def build_posterior(self):
+    """ gp_core.py:155-163: K, L = chol(K + noise I), alpha -- one device call. """
+    self._invalidate()
+    if self.num_tr_data == 0:
+      return
+    hint = getattr(self, '_X_dev_hint', None)      # training inputs already resident in HBM
+    X = hint if (hint is not None and hint.shape[0] == self.num_tr_data) else self._X_array()
+    Y_centred = np.asarray(self.Y, dtype=np.float64) - self.mean_func(self.X)
+    spec = self.kernel.to_spec(in_dim=X.shape[1])
+    self._fitted = get_engine().gp_fit(spec, X, Y_centred, self.noise_var)
+
+  def _need_fit(self):
+    if self._fitted is None and self.num_tr_data > 0:
+      raise RuntimeError('The posterior has not been built (call build_posterior()).')
+    return self._fitted
+
+  @property
+  def L(self):
+    """ Lower Cholesky factor of K + noise_var I (n x n ndarray; gp_core.py:158). """
+    if self.num_tr_data == 0 or self._fitted is None:
+      return None
+    if 'L' not in self._cache:
+      self._cache['L'] = self._fitted.get_L()
+    return self._cache['L']
+
+  @property
+  def alpha(self):
+    """ (K + noise_var I)^-1 (Y - m(X))  (gp_core.py:162-163). """
+    if self.num_tr_data == 0 or self._fitted is None:
+      return None
+    if 'alpha' not in self._cache:
+      self._cache['alpha'] = self._fitted.get_alpha()
+    return self._cache['alpha']
+
+  @property
+  def K_trtr_wo_noise(self):
+    """ kernel(X, X)  (gp_core.py:157). """
+    if self.num_tr_data == 0 or self._fitted is None:
+      return None
+    if 'K' not in self._cache:
+      self._cache['K'] = self._fitted.get_K()
+    return self._cache['K']
+
+  @property
+  def device_gp(self):
+    """ The FittedGP handle (HBM-resident posterior) for fused device calls. """
+    return self._need_fit()
+
+  def eval(self, X_test, uncert_form='none'):
+    """ gp_core.py:165-190. uncert_form: 'none' | 'std' | 'covar'. """
+    if uncert_form not in ('none', 'std', 'covar'):
+      raise ValueError('uncert_form should be none, covar or std.')
+    test_mean = self.mean_func(X_test)
+    Xt = _as_2d_array(X_test)
+    if self.num_tr_data == 0:
+      # no data: the posterior is the prior (K_tetr is n_test x 0 in the reference)
+      pred_mean = test_mean + np.zeros(len(Xt))
+      if uncert_form == 'none':
+        return pred_mean, None
+      K_tete = self.kernel(Xt, Xt)
+      return pred_mean, (K_tete if uncert_form == 'covar' else np.sqrt(np.diag(K_tete)))
+    fitted = self._need_fit()
+    if uncert_form == 'covar':
+      mu_raw, covar = fitted.predict_covar(Xt)
+      return test_mean + mu_raw, covar
+    mu_raw, sd = fitted.predict(Xt, want_std=(uncert_form == 'std'))
+    return test_mean + mu_raw, sd
+
+  def eval_with_hallucinated_observations(self, X_test, X_halluc, uncert_form='none'):
+    """ gp_core.py:192-220: mean from the real data, uncertainty from the GP augmented with the
+        in-progress points. """
+    pred_mean, _ = self.eval(X_test, uncert_form='none')
+    if uncert_form == 'none':
+      return (pred_mean, None)
+    if uncert_form not in ('std', 'covar'):
+      raise ValueError('uncert_form should be none, covar or std.')
+    Xt = _as_2d_array(X_test)
+    Xh = _as_2d_array(X_halluc)
+    if self.num_tr_data == 0:
+      raise NotImplementedError('Hallucinated observations need at least one real observation.')
+    fitted = self._need_fit()
+    if uncert_form == 'covar':
+      _, covar = fitted.predict_covar(Xt, X_halluc=Xh)
+      return (pred_mean, covar)
+    _, sd = fitted.predict(Xt, want_std=True, X_halluc=Xh)
+    return (pred_mean, sd)
+
+  def compute_log_marginal_likelihood(self):
+    """ gp_core.py:222-227 (evaluated on the device together with the fit). """
+    if self.num_tr_data == 0:
+      return -0.0
+    return self._need_fit().lml
+
+  def __str__(self):
+    return '%s, noise-var=%0.3f (n=%d)'%(self._child_str(), self.noise_var, len(self.Y))
+
+  def _child_str(self):
+    raise NotImplementedError('Implement in child class. !')
+
+  # -- sampling --------------------------------------------------------------------------------
+  def draw_samples(self, num_samples, X_test=None, mean_vals=None, covar=None):
+    """ gp_core.py:250-254.  A single joint draw at X_test runs fused on the device
+        (covariance, stable_cholesky and L u never leave HBM); the standard normals are taken
+        from the global np.random state exactly as draw_gaussian_samples does. """
+    if X_test is not None and num_samples == 1 and self.num_tr_data > 0:
+      Xt = _as_2d_array(X_test)
+      test_mean = self.mean_func(X_test)
+      U = np.random.normal(size=(len(Xt), 1))
+      _, _, samples, _ = self._need_fit().thompson(Xt, U.ravel(), block=len(Xt),
+                                                   mean_vals=test_mean, return_samples=True)
+      return samples.reshape((1, -1))
+    if X_test is not None:
+      mean_vals, covar = self.eval(X_test, 'covar')
+    return draw_gaussian_samples(num_samples, mean_vals, covar)
+
+  def draw_samples_with_hallucinated_observations(self, num_samples, X_test, X_halluc):
+    """ gp_core.py:256-261 """
+    mean_vals, aug_covar = self.eval_with_hallucinated_observations(X_test, X_halluc,
+                                                                    uncert_form='covar')
+    return draw_gaussian_samples(num_samples, mean_vals, aug_covar)

@@ -1,0 +1,239 @@
+"""Generates tests/golden/*.npz by running the REAL reference (dragonfly 0.1.7 imported from
+/root/reference, unmodified) on small seeded inputs.
+
+    python oracle/make_golden.py            # needs /root/reference; run in the build container
+
+The reference cannot travel to the GPU box, so its outputs are committed as fixtures.  They pin
+  - the NumPy oracle (oracle/ref_numpy.py) in tests/test_oracle_golden.py  (CPU), and
+  - the HIP engine (dragonfly_amd) in tests/test_gpu_golden.py              (MI355X),
+for the results the reference's own unit tests do not pin: posterior mean / std / covariance,
+alpha, L, lml, UCB / EI / PI / TTEI / TS / add-UCB choices, hallucinated std, fitter choices.
+
+The only change to the reference's environment is the NumPy-2 compatibility shim below
+(SURVEY.md section 8c): attributes NumPy removed after the reference was written.
+"""
+import math
+import os
+import sys
+import warnings
+from argparse import Namespace
+
+import numpy as np
+
+REF = os.environ.get('DRAGONFLY_REFERENCE', '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def import_reference():
+  """ NumPy-2 shim + import. Never edits the reference. """
+  np.math = math
+  np.asscalar = lambda a: np.asarray(a).item()
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    for nm, t in (('object', object), ('int', int), ('float', float), ('bool', bool)):
+      if nm not in np.__dict__:
+        setattr(np, nm, t)
+  if REF not in sys.path:
+    sys.path.insert(0, REF)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    import dragonfly  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+  return dragonfly
+
+
+def test_functions():
+  """ Synthetic objectives (in the unit cube, like Dragonfly's normalised domains). """
+  return {
+    'sin': lambda X: np.sin(3 * X.sum(axis=1)),
+    'quad': lambda X: (X ** 2).dot((np.arange(X.shape[1]) + 1.0) / X.shape[1]),
+  }
+
+
+CASES = [
+  # name, kernel kind, n, d, m, function, extra
+  dict(name='se_d2_n40', kind='se', n=40, d=2, m=37, fn='sin'),
+  dict(name='se_ard_d5_n50', kind='se', n=50, d=5, m=41, fn='quad', ard=True),
+  dict(name='matern25_d6_n60', kind='matern', nu=2.5, n=60, d=6, m=33, fn='sin'),
+  dict(name='matern15_d3_n45', kind='matern', nu=1.5, n=45, d=3, m=29, fn='quad'),
+  dict(name='matern05_d2_n30', kind='matern', nu=0.5, n=30, d=2, m=25, fn='sin'),
+  dict(name='se_d32_n130', kind='se', n=130, d=32, m=70, fn='quad', ard=True),
+  dict(name='additive_d10_n80', kind='additive', n=80, d=10, m=40, fn='quad', group_size=3),
+]
+
+
+def build_reference_kernel(case, Y, rs):
+  from dragonfly.gp import kernel as K
+  d = case['d']
+  scale = float(Y.var())
+  if case['kind'] == 'additive':
+    perm = list(rs.permutation(d))
+    gs = case['group_size']
+    groups = [perm[i:i + gs] for i in range(0, d, gs)]
+    bws = [0.3 + 0.5 * rs.rand(len(g)) for g in groups]
+    kinds = ['se' if i % 2 == 0 else 'matern' for i in range(len(groups))]
+    subs = []
+    for g, bw, kd in zip(groups, bws, kinds):
+      subs.append(K.SEKernel(len(g), 1.0, bw) if kd == 'se' else K.MaternKernel(len(g), 2.5, 1.0, bw))
+    kern = K.AdditiveKernel(scale, subs, groups)
+    meta = dict(groups=np.array([list(map(int, g)) + [-1] * (gs - len(g)) for g in groups]),
+                sub_bws=np.array([list(b) + [0.0] * (gs - len(b)) for b in bws]),
+                sub_kinds=np.array([0 if kd == 'se' else 1 for kd in kinds]), scale=scale)
+    return kern, meta
+  bw = (0.2 * np.sqrt(d) * (0.5 + np.arange(d) / float(d))) if case.get('ard') else np.full(d, 0.25 * np.sqrt(d))
+  if case['kind'] == 'se':
+    return K.SEKernel(d, scale, bw), dict(scale=scale, bw=bw)
+  return K.MaternKernel(d, case['nu'], scale, bw), dict(scale=scale, bw=bw, nu=case['nu'])
+
+
+def gen_gp_cases():
+  from dragonfly.gp.gp_core import GP
+  from dragonfly.opt import gpb_acquisitions as A
+  from dragonfly.exd.domains import EuclideanDomain
+  fns = test_functions()
+  for ci, case in enumerate(CASES):
+    rs = np.random.RandomState(1000 + ci)
+    n, d, m = case['n'], case['d'], case['m']
+    X = rs.random_sample((n, d))
+    Y = fns[case['fn']](X) + 0.05 * rs.randn(n)
+    kern, meta = build_reference_kernel(case, Y, rs)
+    mean_c = float(np.median(Y))
+    noise = float(Y.var() / 20)
+    mean_func = lambda x, _c=mean_c: np.array([_c] * len(x))
+    gp = GP(list(X), list(Y), kern, mean_func, noise)
+    Xs = rs.random_sample((m, d))
+    mu, sd = gp.eval(Xs, 'std')
+    _, cov = gp.eval(Xs, 'covar')
+    Xh = rs.random_sample((3, d))
+    _, sd_h = gp.eval_with_hallucinated_observations(Xs, list(Xh), 'std')
+    out = dict(X=X, Y=Y, Xs=Xs, Xh=Xh, mean_c=mean_c, noise=noise,
+               K=gp.K_trtr_wo_noise, L=gp.L, alpha=gp.alpha,
+               lml=gp.compute_log_marginal_likelihood(), mu=mu, sd=sd, cov=cov, sd_h=sd_h)
+    for k, v in meta.items():
+      out['kern_' + k] = v
+    # acquisitions through the reference's own callables, 'rand' maximiser, seeded global RNG
+    bounds = np.array([[0.0, 1.0]] * d)
+    best = float(Y.max())
+    def anc(max_evals, in_progress=()):
+      return Namespace(max_evals=max_evals, t=n, domain=EuclideanDomain(bounds),
+                       curr_max_val=best, eval_points_in_progress=list(in_progress),
+                       acq_opt_method='rand', handle_parallel='halluc', is_mf=False,
+                       domain_bounds=bounds)
+    for ai, acq in enumerate(['ucb', 'ei', 'pi', 'ttei', 'ts']):
+      np.random.seed(5000 + 10 * ci + ai)
+      out['asy_' + acq] = getattr(A.asy, acq)(gp, anc(64))
+    np.random.seed(6000 + ci)
+    out['asy_ucb_halluc'] = A.asy.ucb(gp, anc(64, in_progress=[Xh[0], Xh[1]]))
+    np.random.seed(7000 + ci)
+    out['syn_ei_3'] = np.array(A.syn.ei(3, gp, anc(48)))
+    if case['kind'] == 'additive':
+      np.random.seed(8000 + ci)
+      out['asy_add_ucb'] = A.asy.add_ucb(gp, anc(120))
+    # acquisition values on Xs straight from the reference formulas
+    beta = A._get_ucb_beta_th(A._get_gp_ucb_dim(gp), n)            # pylint: disable=protected-access
+    out['beta_th'] = beta
+    out['val_ucb'] = mu + beta * sd
+    nd = (mu - best) / sd
+    out['val_ei'] = sd * A._expected_improvement_for_norm_diff(nd)  # pylint: disable=protected-access
+    out['val_pi'] = A.normal_distro.cdf(nd)
+    comb = np.sqrt(0.3 ** 2 + sd ** 2)
+    out['val_ttei'] = comb * A._expected_improvement_for_norm_diff((mu - best) / comb)  # pylint: disable=protected-access
+    # joint TS draw with recorded normals
+    np.random.seed(9000 + ci)
+    state_U = np.random.RandomState(9000 + ci).normal(size=(m, 1))
+    out['ts_U'] = state_U.ravel()
+    out['ts_sample'] = gp.draw_samples(1, Xs).ravel()      # consumes the same normals from np.random
+    np.savez_compressed(os.path.join(OUT, 'gp_' + case['name'] + '.npz'), **out)
+    print('wrote gp_%s' % case['name'])
+
+
+def gen_fitter_case():
+  """ EuclideanGPFitter, ML by random search, seeded. """
+  from dragonfly.gp.euclidean_gp import EuclideanGPFitter
+  rs = np.random.RandomState(77)
+  n, d = 45, 3
+  X = rs.random_sample((n, d))
+  Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+  res = {}
+  for kt in ('se', 'matern'):
+    opts = Namespace(kernel_type=kt, ml_hp_tune_opt='rand', hp_tune_max_evals=60, hp_tune_criterion='ml')
+    np.random.seed(4242)
+    fitter = EuclideanGPFitter(list(X), list(Y), options=opts)
+    _, gp, hps = fitter.fit_gp()
+    res[kt + '_cts_hps'] = np.array(hps[0], dtype=float)
+    res[kt + '_lml'] = gp.compute_log_marginal_likelihood()
+    res[kt + '_noise'] = gp.noise_var
+    res[kt + '_scale'] = gp.kernel.hyperparams['scale']
+    res[kt + '_bw'] = np.asarray(gp.kernel.hyperparams['dim_bandwidths'], dtype=float)
+    Xs = rs.random_sample((20, d))
+    mu, sd = gp.eval(Xs, 'std')
+    res[kt + '_Xs'], res[kt + '_mu'], res[kt + '_sd'] = Xs, mu, sd
+  np.savez_compressed(os.path.join(OUT, 'fitter_d3_n45.npz'), X=X, Y=Y, **res)
+  print('wrote fitter_d3_n45')
+
+
+def gen_c1_case():
+  """ BASELINE config 1: Branin 2-D, n = 200, SE kernel, UCB over 1000 random candidates, driven
+      through the reference's own optimiser objects in ask/tell mode. """
+  from dragonfly.opt import gp_bandit
+  from dragonfly.exd.domains import EuclideanDomain
+  from dragonfly.exd.experiment_caller import EuclideanFunctionCaller
+  from dragonfly.utils.option_handler import load_options
+  from dragonfly.utils.euclidean_synthetic_functions import get_mf_branin_function
+  branin_function = get_mf_branin_function(1)[1]     # euclidean_synthetic_functions.py:108-149
+  bounds = [[-5, 10], [0, 15]]
+  opts = load_options(gp_bandit.get_all_euc_gp_bandit_args())
+  opts.kernel_type = 'se'
+  opts.acq = 'ucb'
+  opts.acq_opt_method = 'rand'
+  opts.acq_opt_max_evals = 1000
+  opts.gpb_hp_tune_criterion = 'ml'
+  opts.gpb_ml_hp_tune_opt = 'rand'
+  opts.hp_tune_max_evals = 50
+  np.random.seed(101)
+  func_caller = EuclideanFunctionCaller(None, EuclideanDomain(bounds))
+  opt = gp_bandit.EuclideanGPBandit(func_caller, ask_tell_mode=True, options=opts, reporter='silent')
+  opt.initialise()
+  Xraw = np.random.RandomState(101).random_sample((200, 2)) * np.array([15.0, 15.0]) + np.array([-5.0, 0.0])
+  Yv = np.array([branin_function(x) for x in Xraw])
+  opt.tell([(x, y) for x, y in zip(Xraw, Yv)])
+  opt.first_qinfos = []
+  # record exactly what the single acquisition call sees
+  record = {}
+  from dragonfly.opt import gpb_acquisitions as A
+  orig = A.asy.ucb
+  def spy(gp, anc_data):
+    st = np.random.get_state()
+    record['gp'] = gp
+    record['anc'] = anc_data
+    record['state'] = st
+    return orig(gp, anc_data)
+  A.asy.ucb = spy
+  try:
+    x_next = opt.ask()
+  finally:
+    A.asy.ucb = orig
+  gp = record['gp']
+  anc = record['anc']
+  # replay to capture the candidates and values
+  np.random.set_state(record['state'])
+  cands = np.random.random((int(anc.max_evals), 2)) * (anc.domain.bounds[:, 1] - anc.domain.bounds[:, 0]) + anc.domain.bounds[:, 0]
+  mu, sd = gp.eval(cands, 'std')
+  beta = A._get_ucb_beta_th(A._get_gp_ucb_dim(gp), anc.t)   # pylint: disable=protected-access
+  vals = mu + beta * sd
+  np.savez_compressed(os.path.join(OUT, 'c1_branin.npz'), Xn=np.array(gp.X), Yn=np.array(gp.Y),
+                      scale=gp.kernel.hyperparams['scale'],
+                      bw=np.asarray(gp.kernel.hyperparams['dim_bandwidths'], dtype=float),
+                      noise=gp.noise_var, mean_c=float(gp.mean_func([np.zeros(2)])[0]),
+                      cands=cands, t=anc.t, beta=beta, vals=vals, argmax=int(vals.argmax()),
+                      x_next_normalised=cands[int(vals.argmax())], x_next_raw=np.array(x_next),
+                      L=gp.L, alpha=gp.alpha, max_evals=int(anc.max_evals))
+  print('wrote c1_branin (x_next %s)' % (x_next,))
+
+
+if __name__ == '__main__':
+  os.makedirs(OUT, exist_ok=True)
+  import_reference()
+  gen_gp_cases()
+  gen_fitter_case()
+  gen_c1_case()

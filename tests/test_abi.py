@@ -1,0 +1,60 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/dfhip.h declares; the
+ctypes table binds exactly that set; no compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from dragonfly_amd import _lib
+
+HEADER = os.path.join(ROOT, 'include', 'dfhip.h')
+
+
+def declared_functions():
+  text = open(HEADER).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(dfh_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_functions():
+  names = declared_functions()
+  assert 'dfh_gp_fit' in names and 'dfh_kernel_matrix' in names and len(names) >= 25
+
+
+def test_library_exports_every_declared_symbol():
+  lib = _lib.load()
+  for name in declared_functions():
+    assert hasattr(lib, name), 'libdfhip.so does not export %s' % name
+    assert isinstance(getattr(lib, name), ctypes._CFuncPtr)    # pylint: disable=protected-access
+
+
+def test_ctypes_table_matches_header():
+  assert sorted(_lib.SIGNATURES.keys()) == declared_functions()
+
+
+def test_abi_version_and_error_string():
+  lib = _lib.load()
+  assert lib.dfh_abi_version() == 1
+  assert isinstance(_lib.last_error(), str)
+
+
+def test_kernel_desc_layout():
+  """ struct dfh_kernel_desc: 2 x int32, 2 x double, pointer, int32 (+pad), 6 pointers """
+  assert ctypes.sizeof(_lib.KernelDesc) == 88
+  assert _lib.KernelDesc.scale.offset == 8 and _lib.KernelDesc.bw.offset == 24
+  assert _lib.KernelDesc.n_groups.offset == 32 and _lib.KernelDesc.group_off.offset == 40
+
+
+def test_no_device_fails_loudly():
+  """ there is no CPU fallback: without a GPU creating an engine raises """
+  if _lib.device_count() > 0:
+    pytest.skip('a GPU is present')
+  from dragonfly_amd.engine import Engine
+  with pytest.raises(_lib.DfhipError):
+    Engine()
+  from dragonfly_amd import kernel as K
+  import numpy as np
+  with pytest.raises(_lib.DfhipError):
+    K.SEKernel(2, 1.0, [0.3, 0.3])(np.zeros((3, 2)))

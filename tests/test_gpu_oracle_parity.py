@@ -1,0 +1,218 @@
+"""MI355X: HIP path vs the NumPy oracle on identical seeded inputs, at sizes the oracle finishes
+in seconds, plus the edge cases the reference handles (empty / ragged / single-point inputs,
+non-PD matrices, the jitter ladder, NaN variance and np.argmax's NaN rule)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _spec_pair(kind, d, rs, scale=1.7, nu=2.5):
+  from dragonfly_amd.engine import KernelSpec
+  bw = 0.3 + rs.rand(d)
+  if kind == 'se':
+    return KernelSpec('se', d, scale, bw), O.KernelSpec('se', d, scale, bw)
+  return KernelSpec('matern', d, scale, bw, nu=nu), O.KernelSpec('matern', d, scale, bw, nu=nu)
+
+
+@pytest.mark.parametrize('kind,nu', [('se', None), ('matern', 0.5), ('matern', 1.5), ('matern', 2.5)])
+@pytest.mark.parametrize('shape', [(1, 1, 1), (3, 5, 2), (128, 128, 6), (257, 130, 32), (70, 515, 45)])
+def test_kernel_matrix(engine, kind, nu, shape):
+  n1, n2, d = shape
+  rs = np.random.RandomState(n1 * 7 + n2)
+  spec, ospec = _spec_pair(kind, d, rs, nu=nu or 2.5)
+  X1, X2 = rs.rand(n1, d), rs.rand(n2, d)
+  assert relerr(engine.kernel_matrix(spec, X1, X2), ospec(X1, X2)) < 1e-12
+  Ks = engine.kernel_matrix(spec, X1, None, diag_add=0.3)
+  assert np.array_equal(Ks, Ks.T)                                       # bitwise symmetric
+  tol = 1e-6 if nu == 0.5 else 1e-12     # reference diagonal carries sqrt(rounding of dist_sq)
+  assert relerr(Ks, ospec(X1, X1) + 0.3 * np.eye(n1)) < tol
+
+
+def test_reference_known_answers_on_device(engine):
+  """ gp/unittest_kernel.py:82-124 and utils/unittest_general_utils.py:27-35 run on the HIP path """
+  from dragonfly_amd import kernel as K
+  from dragonfly_amd.general_utils import dist_squared
+  d1 = np.array([[1, 2], [3, 4.5]])
+  d2 = np.array([[1, 2], [3, 4]])
+  kern = K.SEKernel(2, 2, [0.1, 1])
+  true_12 = 2 * np.array([[1, np.exp(-404/2)], [np.exp(-406.25/2), np.exp(-0.25/2)]])
+  true_11 = 2 * np.array([[1, np.exp(-406.25/2)], [np.exp(-406.25/2), 1]])
+  assert np.linalg.norm(true_12 - kern(d1, d2)) < 1e-10
+  assert np.linalg.norm(true_11 - kern(d1)) < 1e-10
+  dist12 = np.array([[0, np.sqrt(404)], [np.sqrt(406.25), np.sqrt(0.25)]])
+  for nu in (0.5, 1.5, 2.5):
+    km = K.MaternKernel(2, nu, 2.1, [0.1, 1])
+    if nu == 0.5:
+      ref = np.exp(-dist12)
+    elif nu == 1.5:
+      ref = np.exp(-np.sqrt(3) * dist12) * (1 + np.sqrt(3) * dist12)
+    else:
+      ref = np.exp(-np.sqrt(5) * dist12) * (1 + np.sqrt(5) * dist12 + (5/3.0) * dist12**2)
+    assert np.linalg.norm(2.1 * ref - km(d1, d2)) < 1e-10
+  X1 = np.array([[1, 2, 3], [1, 2, 4], [2, 3, 4.5]])
+  X2 = np.array([[1, 2, 4], [1, 2, 5], [2, 3, 5]])
+  assert (np.array([[1, 4, 6], [0, 1, 3], [2.25, 2.25, 0.25]]) == dist_squared(X1, X2)).all()
+  with pytest.raises(ValueError):
+    dist_squared(X1, X2[:, :2])
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 511, 512, 513, 1000, 2048])
+def test_cholesky_and_solves(engine, n):
+  from dragonfly_amd import general_utils as G
+  from scipy.linalg import solve_triangular
+  rs = np.random.RandomState(n)
+  X = rs.rand(n, 4)
+  M = O.se_kernel(X, X, 1.0, np.full(4, 0.4)) + 0.05 * np.eye(n)
+  L = G.stable_cholesky(M)
+  Lr = np.linalg.cholesky(M)
+  assert relerr(L, Lr) < 1e-11 and np.array_equal(np.triu(L, 1), np.zeros_like(L))
+  b = rs.randn(n)
+  assert relerr(G.solve_lower_triangular(Lr, b), solve_triangular(Lr, b, lower=True)) < 1e-11
+  assert relerr(G.solve_upper_triangular(Lr.T, b), solve_triangular(Lr.T, b, lower=False)) < 1e-11
+  if n in (65, 1000):
+    B = rs.randn(n, 19)
+    assert relerr(G.solve_lower_triangular(Lr, B), solve_triangular(Lr, B, lower=True)) < 1e-11
+    assert relerr(G.solve_upper_triangular(Lr.T, B), solve_triangular(Lr.T, B, lower=False)) < 1e-11
+
+
+def test_cholesky_failure_modes(engine):
+  from dragonfly_amd import general_utils as G
+  rs = np.random.RandomState(0)
+  # not positive definite: numpy raises LinAlgError (general_utils.py:178)
+  X = rs.rand(300, 3)
+  M = O.se_kernel(X, X, 1.0, np.full(3, 0.4)) + 0.05 * np.eye(300)
+  M[150, 150] = -1.0
+  with pytest.raises(np.linalg.LinAlgError):
+    G.stable_cholesky(M, add_to_diag_till_psd=False)
+  # rank deficient: ladder adds 10^p max(diag) (general_utils.py:183-203), same power as numpy
+  A = rs.randn(200, 20)
+  M = A.dot(A.T)
+  L, p = engine.stable_cholesky(M, return_power=True)
+  _, pr = O.stable_cholesky(M, return_power=True)
+  assert p == pr and relerr(L.dot(L.T), M) < 1e-8
+  # hopeless: ValueError after p = 4 (general_utils.py:199-203)
+  with pytest.raises(ValueError):
+    G.stable_cholesky(-np.eye(70))
+  with pytest.raises(ValueError):
+    bad = np.eye(10); bad[3, 3] = np.nan
+    G.stable_cholesky(bad)
+  assert G.stable_cholesky(np.zeros((0, 0))).size == 0
+  assert G.solve_lower_triangular(np.zeros((0, 0)), np.zeros((0,))).shape == (0,)
+
+
+@pytest.mark.parametrize('kind,d,n,m', [('se', 32, 1500, 3000), ('matern', 6, 2048, 4096), ('se', 2, 200, 1000)])
+def test_fit_and_posterior_against_oracle(engine, kind, d, n, m):
+  rs = np.random.RandomState(d * 1000 + n)
+  spec, ospec = _spec_pair(kind, d, rs, scale=1.0)
+  X = rs.rand(n, d)
+  Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 20)
+  og = O.GPOracle(X, Y, ospec, mean_c, noise)
+  gp = engine.gp_fit(spec, X, Y - mean_c, noise)
+  assert gp.jitter_power is None
+  assert relerr(gp.get_alpha(), og.alpha) < TOL
+  assert abs(gp.lml - og.lml()) <= TOL * abs(og.lml())
+  Xs = rs.rand(m, d)
+  mu, sd = gp.predict(Xs)
+  mur, sdr = og.eval_chunked(Xs, chunk=1024)
+  assert relerr(mu + mean_c, mur) < TOL and relerr(sd, sdr) < TOL
+  best = float(Y.max())
+  for acq, params in (('ucb', (2.5, 0.0)), ('ei', (best, 0.0)), ('pi', (best, 0.0)), ('ttei', (best, 0.2))):
+    bv, bi, vals = gp.acq_argmax(acq, Xs, params=params, mean_const=mean_c, return_vals=True)
+    vr = O.acq_values(acq, mur, sdr, *params)
+    assert relerr(vals, vr) < 1e-9
+    assert bi == O.argmax_first(vr)[1]
+  # blocked Thompson sampling, several blocks per call
+  U = rs.randn(m)
+  blk = 512
+  bv, bi, samp, jps = gp.thompson(Xs[:2048], U[:2048], block=blk, mean_const=mean_c, return_samples=True)
+  sr = og.draw_samples_blocked(Xs[:2048], U[:2048], blk)
+  assert relerr(samp, sr) < 1e-6 and bi == int(np.argmax(sr))
+
+
+def test_ragged_and_single_point_inputs(engine):
+  rs = np.random.RandomState(5)
+  spec, ospec = _spec_pair('se', 3, rs)
+  X = rs.rand(7, 3)
+  Y = rs.randn(7)
+  og = O.GPOracle(X, Y, ospec, 0.0, 0.1)
+  gp = engine.gp_fit(spec, X, Y, 0.1)
+  for m in (1, 2, 129):
+    Xs = rs.rand(m, 3)
+    mu, sd = gp.predict(Xs)
+    mur, sdr = og.eval(Xs, 'std')
+    assert relerr(mu, mur) < TOL and relerr(sd, sdr) < TOL
+    mu_only, none = gp.predict(Xs, want_std=False)
+    assert none is None and np.array_equal(mu_only, mu)
+  # single training point
+  gp1 = engine.gp_fit(spec, X[:1], Y[:1], 0.1)
+  og1 = O.GPOracle(X[:1], Y[:1], ospec, 0.0, 0.1)
+  mu, sd = gp1.predict(X)
+  mur, sdr = og1.eval(X, 'std')
+  assert relerr(mu, mur) < TOL and relerr(sd, sdr) < TOL
+
+
+def test_nan_variance_and_argmax_rule(engine):
+  """ gp_core.py:187 does not clip: a negative variance gives NaN, and np.argmax (oper_utils.py:73)
+      returns the first NaN.  Tiny noise + a candidate on a training point forces the case. """
+  rs = np.random.RandomState(9)
+  from dragonfly_amd.engine import KernelSpec
+  d = 2
+  spec = KernelSpec('se', d, 1.0, np.full(d, 2.0))
+  X = rs.rand(60, d)
+  Y = rs.randn(60)
+  gp = engine.gp_fit(spec, X, Y, 1e-13)
+  Xs = np.vstack((rs.rand(50, d), X, rs.rand(50, d)))
+  bv, bi, vals = gp.acq_argmax('ucb', Xs, params=(2.0, 0.0), return_vals=True)
+  nan_idx = np.flatnonzero(np.isnan(vals))
+  if len(nan_idx):
+    assert bi == nan_idx[0] and bv != bv
+  else:
+    assert bi == int(np.argmax(vals))
+  # explicit tie: duplicated candidates -> the first index wins
+  Xt = np.vstack((Xs[:10], Xs[:10]))
+  gp2 = engine.gp_fit(spec, X, Y, 0.1)
+  bv, bi, vals = gp2.acq_argmax('ucb', Xt, params=(2.0, 0.0), return_vals=True)
+  assert bi == int(np.argmax(vals)) and bi < 10
+
+
+def test_gemm_public_entry(engine):
+  rs = np.random.RandomState(2)
+  A, B, C = rs.randn(300, 70), rs.randn(129, 70), rs.randn(300, 129)
+  assert relerr(engine.gemm(A, B, C, alpha=1.5, beta=0.5), 0.5 * C + 1.5 * A.dot(B.T)) < 1e-13
+  Bn = rs.randn(70, 129)
+  assert relerr(engine.gemm(A, Bn, alpha=-1.0, transb=True), -A.dot(Bn)) < 1e-13
+  # transpose-detecting: asymmetric A = I check (cdna_hip_programming.md section 3)
+  I = np.eye(64)
+  Basym = np.arange(64 * 64, dtype=float).reshape(64, 64)
+  assert np.array_equal(engine.gemm(I, Basym, transb=True), Basym)
+  assert np.array_equal(engine.gemm(I, Basym), Basym.T)
+
+
+def test_additive_gp_and_add_ucb_groups(engine):
+  from dragonfly_amd.engine import KernelSpec
+  rs = np.random.RandomState(21)
+  d, n = 12, 600
+  perm = list(rs.permutation(d))
+  groups = [perm[i:i + 5] for i in range(0, d, 5)]
+  bws = [0.4 + rs.rand(len(g)) for g in groups]
+  spec = KernelSpec('additive', d, 2.2, groups=groups, sub_kinds=['se'] * len(groups),
+                    sub_scales=[1.0] * len(groups), sub_nus=[0.0] * len(groups), sub_bandwidths=bws)
+  subs = [O.KernelSpec('se', len(g), 1.0, b) for g, b in zip(groups, bws)]
+  ospec = O.KernelSpec('additive', d, 2.2, groups=groups, subs=subs)
+  X = rs.rand(n, d)
+  Y = (X ** 2).sum(axis=1) + 0.05 * rs.randn(n)
+  og = O.GPOracle(X, Y, ospec, 0.0, float(Y.var() / 20))
+  gp = engine.gp_fit(spec, X, Y, float(Y.var() / 20))
+  assert relerr(gp.get_alpha(), og.alpha) < TOL
+  for j, grp in enumerate(groups):
+    Xj = rs.rand(333, len(grp))
+    beta = O.add_ucb_beta_th(len(grp), n)
+    bv, bi, vals = gp.add_ucb_group(j, beta, Xj, return_vals=True)
+    vr = O.add_ucb_group_values(og, j, Xj, n)
+    assert relerr(vals, vr) < 1e-9 and bi == int(np.argmax(vr))

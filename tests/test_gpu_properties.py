@@ -1,0 +1,121 @@
+"""MI355X, BASELINE.json's full sizes (n = 16384, d = 32): size-independent properties instead of a
+CPU oracle run -- factorisation and solve residuals, determinism, linearity, chunk / shard / block
+invariance of the candidate stage."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+N, D = 16384, 32
+
+
+def c3_problem(n=N, d=D, seed=103):
+  """ BASELINE config 3 inputs """
+  rs = np.random.RandomState(seed)
+  X = rs.random_sample((n, d))
+  w = (np.arange(d) + 1.0) / d
+  Y = (X ** 2).dot(w) + 0.01 * rs.randn(n)
+  bw = 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0)
+  return X, Y, bw
+
+
+@pytest.fixture(scope='module')
+def fitted(engine):
+  from dragonfly_amd.engine import KernelSpec
+  X, Y, bw = c3_problem()
+  spec = KernelSpec('se', D, float(Y.var()), bw)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 20)
+  gp = engine.gp_fit(spec, X, Y - mean_c, noise)
+  return dict(gp=gp, spec=spec, X=X, Y=Y, mean_c=mean_c, noise=noise)
+
+
+def test_cholesky_and_alpha_residuals_at_full_size(engine, fitted):
+  gp, noise = fitted['gp'], fitted['noise']
+  assert gp.jitter_power is None
+  K = gp.get_K()
+  assert np.array_equal(K, K.T)
+  L = gp.get_L()
+  assert np.array_equal(np.triu(L[:600, :600], 1), np.zeros((600, 600)))
+  # || K + noise I - L L^T || / ||K||: product on the device, difference on the host
+  LLt = engine.gemm(L, L)
+  R = K - LLt
+  R[np.diag_indices(N)] += noise
+  assert np.abs(R).max() / np.abs(K).max() < 1e-13
+  del LLt, R
+  alpha = gp.get_alpha()
+  yc = fitted['Y'] - fitted['mean_c']
+  res = K.dot(alpha) + noise * alpha - yc
+  assert np.abs(res).max() / np.abs(yc).max() < 1e-10
+  # lml from its definition with the downloaded factor
+  lml = -0.5 * yc.dot(alpha) - np.log(np.diag(L)).sum() - 0.5 * N * np.log(2 * np.pi)
+  assert abs(lml - gp.lml) <= 1e-10 * abs(lml)
+
+
+def test_fit_is_deterministic_and_linear(engine, fitted):
+  X, Y = fitted['X'][:4096], fitted['Y'][:4096]
+  spec, noise = fitted['spec'], fitted['noise']
+  g1 = engine.gp_fit(spec, X, Y, noise)
+  g2 = engine.gp_fit(spec, X, Y, noise)
+  assert np.array_equal(g1.get_alpha(), g2.get_alpha()) and g1.lml == g2.lml
+  rs = np.random.RandomState(0)
+  Y2 = rs.randn(4096)
+  g3 = engine.gp_fit(spec, X, Y2, noise)
+  g4 = engine.gp_fit(spec, X, Y + Y2, noise)
+  assert relerr(g4.get_alpha(), g1.get_alpha() + g3.get_alpha()) < 1e-10
+
+
+def test_candidate_stage_is_chunk_and_shard_invariant(engine, fitted):
+  from dragonfly_amd import parallel
+  gp, mean_c = fitted['gp'], fitted['mean_c']
+  m = 40000                                # > one internal chunk (16384 rows at n = 16384)
+  Xc = np.random.RandomState(203).random_sample((m, D))
+  bv, bi, vals = gp.acq_argmax('ei', Xc, params=(float(fitted['Y'].max()), 0.0), mean_const=mean_c,
+                               return_vals=True)
+  assert bi == int(np.argmax(vals)) and bv == vals[bi]
+  # the same rows in a different call / chunk composition give bit-identical values
+  _, _, v2 = gp.acq_argmax('ei', Xc[10000:30000], params=(float(fitted['Y'].max()), 0.0),
+                           mean_const=mean_c, return_vals=True)
+  assert np.array_equal(v2, vals[10000:30000])
+  # sharding over 1, 2, 4, 8 ranks reproduces the single-GPU arg-max
+  for world in (2, 4, 8):
+    pairs = []
+    for r in range(world):
+      lo, hi = parallel.shard_bounds(m, r, world)
+      v, i = gp.acq_argmax('ei', Xc[lo:hi], params=(float(fitted['Y'].max()), 0.0), mean_const=mean_c)
+      pairs.append((v, i + lo))
+    v, i = parallel.reduce_argmax([p[0] for p in pairs], [p[1] for p in pairs])
+    assert i == bi and v == bv
+  # posterior sanity: variance shrinks towards the data, never exceeds the prior
+  mu, sd = gp.predict(Xc[:2000])
+  assert np.all(sd >= 0) and np.all(sd <= np.sqrt(fitted['spec'].scale) * (1 + 1e-12))
+  mu_tr, sd_tr = gp.predict(fitted['X'][:512])
+  assert sd_tr.mean() < sd.mean()
+
+
+def test_blocked_thompson_is_block_aligned_shard_invariant(engine, fitted):
+  """ BASELINE config 4 in miniature: blocks of 4096, shards cut on block boundaries """
+  from dragonfly_amd import parallel
+  gp, mean_c = fitted['gp'], fitted['mean_c']
+  m, B = 5 * 4096 + 1000, 4096
+  Xc = np.random.RandomState(204).random_sample((m, D))
+  U = np.random.RandomState(304).standard_normal(m)
+  bv, bi, samp, jps = gp.thompson(Xc, U, block=B, mean_const=mean_c, return_samples=True)
+  assert len(jps) == 6 and bi == int(np.argmax(samp)) and np.all(np.isfinite(samp))
+  for world in (2, 4):
+    got = np.empty(m)
+    pairs = []
+    for r in range(world):
+      lo, hi = parallel.shard_bounds(m, r, world, align=B)
+      if hi > lo:
+        v, i, s, _ = gp.thompson(Xc[lo:hi], U[lo:hi], block=B, mean_const=mean_c, return_samples=True)
+        got[lo:hi] = s
+        pairs.append((v, i + lo))
+    assert np.array_equal(got, samp)
+    v, i = parallel.reduce_argmax([p[0] for p in pairs], [p[1] for p in pairs])
+    assert i == bi and v == bv
+  # a block's draw has the block's posterior mean and a covariance consistent with sd
+  mu, sd = gp.predict(Xc[:B])
+  z = (samp[:B] - (mu + mean_c)) / sd
+  assert abs(z.mean()) < 0.2 and 0.7 < z.std() < 1.3

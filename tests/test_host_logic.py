@@ -1,0 +1,138 @@
+"""CPU: host-side logic of the reference-interface mirror (no device compute)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from dragonfly_amd import kernel as K
+from dragonfly_amd import parallel
+from dragonfly_amd.engine import KernelSpec
+from dragonfly_amd import _lib
+from dragonfly_amd.option_handler import get_option_specs, load_options
+from dragonfly_amd.oper_utils import EuclideanDomain, random_sample
+
+
+def test_kernel_hyperparams_and_errors():
+  k = K.SEKernel(2, 2.0, [0.1, 1.0])
+  assert k.hyperparams['scale'] == 2.0 and list(k.hyperparams['dim_bandwidths']) == [0.1, 1.0]
+  assert k.is_guaranteed_psd() and k.dim == 2
+  with pytest.raises(ValueError):
+    K.SEKernel(3, 1.0, [0.1, 1.0])                    # kernel.py:151
+  k1 = K.SEKernel(3, 1.0, 0.5)                        # single bandwidth
+  assert list(k1.hyperparams['dim_bandwidths']) == [0.5] * 3
+  with pytest.raises(ValueError):
+    K.MaternKernel(2, 2.0, 1.0, [1.0, 1.0])           # kernel.py:244 nu must be p + 1/2
+  m = K.MaternKernel(2, 2.5, 2.1, [0.1, 1.0])
+  assert m.p == 2 and m.hyperparams['nu'] == 2.5
+  with pytest.raises(ValueError):
+    K.AdditiveKernel(1.0, [k], [[0], [1]])            # kernel.py:471
+  assert 'SE: ' in str(k) and 'Matern: nu=2.5' in str(m)
+
+
+def test_empty_inputs_return_empty_matrix():
+  """ kernel.py:81-82 -- decided on the host, no device needed """
+  k = K.SEKernel(2, 2.0, [0.1, 1.0])
+  assert k(np.zeros((0, 2)), np.zeros((5, 2))).shape == (0, 5)
+  assert k([], []).shape == (0, 0)
+
+
+def test_kernel_desc_marshalling():
+  d = K.MaternKernel(3, 1.5, 0.7, [0.2, 0.3, 0.4]).to_spec().to_desc()
+  assert d.kind == _lib.KERNEL_MATERN and d.dim == 3 and d.nu == 1.5 and d.scale == 0.7
+  assert [d.bw[i] for i in range(3)] == [0.2, 0.3, 0.4]
+  subs = [K.SEKernel(2, 1.0, [0.5, 0.6]), K.MaternKernel(1, 2.5, 1.0, [0.7])]
+  spec = K.AdditiveKernel(3.0, subs, [[2, 0], [1]]).to_spec()
+  d = spec.to_desc()
+  assert d.kind == _lib.KERNEL_ADDITIVE and d.n_groups == 2 and d.dim == 3 and d.scale == 3.0
+  assert [d.group_off[i] for i in range(3)] == [0, 2, 3]
+  assert [d.group_dims[i] for i in range(3)] == [2, 0, 1]
+  assert [d.sub_kind[i] for i in range(2)] == [_lib.KERNEL_SE, _lib.KERNEL_MATERN]
+  assert [d.sub_bw[i] for i in range(3)] == [0.5, 0.6, 0.7]
+  with pytest.raises(ValueError):
+    KernelSpec('poly', 2, 1.0, [1, 1]).to_desc()
+
+
+def test_option_handler():
+  specs = [get_option_specs('a', False, 1, ''), get_option_specs('b', False, 'x', '')]
+  o = load_options(specs)
+  assert o.a == 1 and o.b == 'x'
+  o = load_options(specs, partial_options=Namespace(a=5))
+  assert o.a == 5 and o.b == 'x'
+  o = load_options(specs, partial_options={'b': 'y'})
+  assert o.b == 'y'
+
+
+def test_random_sample_draw_order_matches_reference():
+  """ oper_utils.py:59-67: candidates = map_to_bounds(np.random.random((m, d)), bounds) """
+  bounds = np.array([[-5.0, 10.0], [0.0, 15.0]])
+  np.random.seed(7)
+  pts, vals = random_sample(lambda x: x.sum(axis=1), bounds, 11)
+  np.random.seed(7)
+  ref = np.random.random((11, 2)) * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+  assert np.array_equal(pts, ref) and np.array_equal(vals, ref.sum(axis=1))
+
+
+def test_shard_bounds_cover_and_align():
+  for m, w, align in ((10, 3, 1), (2097152, 8, 4096), (1000, 8, 4096), (5, 8, 1), (12289, 4, 4096)):
+    spans = [parallel.shard_bounds(m, r, w, align) for r in range(w)]
+    assert spans[0][0] == 0 and spans[-1][1] == m
+    for (lo, hi), (lo2, _) in zip(spans[:-1], spans[1:]):
+      assert hi == lo2 and lo <= hi
+    for lo, hi in spans:
+      assert lo % align == 0 or lo == m
+
+
+def test_reduce_argmax_numpy_semantics():
+  rs = np.random.RandomState(0)
+  for trial in range(200):
+    vals = rs.randint(0, 4, size=9).astype(float)
+    if trial % 3 == 0:
+      vals[rs.randint(0, 9, size=2)] = np.nan
+    # split into 3 shards, each reports its own np.argmax
+    shard_v, shard_i = [], []
+    for lo, hi in ((0, 3), (3, 3), (3, 9)):          # middle shard empty
+      if hi > lo:
+        j = int(np.argmax(vals[lo:hi]))
+        shard_v.append(vals[lo + j]); shard_i.append(lo + j)
+      else:
+        shard_v.append(float('nan')); shard_i.append(-1)
+    v, i = parallel.reduce_argmax(shard_v, shard_i)
+    assert i == int(np.argmax(vals))
+    assert (v != v) if np.isnan(vals[i]) else v == vals[i]
+
+
+def test_gp_rejects_foreign_kernels_and_bad_lengths():
+  from dragonfly_amd.gp_core import GP
+  class Foreign(object):
+    def is_guaranteed_psd(self):
+      return True
+  with pytest.raises(TypeError):
+    GP([np.zeros(2)], [0.0], Foreign(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
+  with pytest.raises(ValueError):
+    GP([np.zeros(2)], [0.0, 1.0], K.SEKernel(2, 1.0, [1, 1]), lambda x: np.zeros(len(x)), 0.1,
+       build_posterior=False)
+
+
+def test_fitter_set_up_matches_reference_bounds():
+  """ gp_core.py:393-416, euclidean_gp.py:254-268: hyper-parameter boxes """
+  from dragonfly_amd.euclidean_gp import EuclideanGPFitter
+  rs = np.random.RandomState(1)
+  X = rs.rand(20, 3)
+  Y = rs.randn(20)
+  f = EuclideanGPFitter(list(X), list(Y), options=Namespace(kernel_type='se', ml_hp_tune_opt='rand'))
+  Yvar = Y.std() ** 2 + 0.0001
+  assert f.param_order[0] == ['noise_mean', 'cts'] and f.param_order[1] == ['noise_var', 'cts']
+  assert np.allclose(f.cts_hp_bounds[1], [np.log(0.005 * Yvar), np.log(0.2 * Yvar)])
+  assert np.allclose(f.cts_hp_bounds[2], [np.log(0.1 * Yvar), np.log(10 * Yvar)])
+  xn = np.linalg.norm(X, 'fro') + 1e-4
+  assert np.allclose(f.cts_hp_bounds[3], [np.log(0.01 * xn), np.log(10 * xn)])
+  assert f.num_hps == 2 + 1 + 3 and f.hp_tune_max_evals == min(1e4, max(500, 6 * 200))
+  with pytest.raises(NotImplementedError):
+    EuclideanGPFitter(list(X), list(Y), options=Namespace(ml_hp_tune_opt='direct'))
+  with pytest.raises(ValueError):
+    EuclideanGPFitter(list(X), list(Y), options=Namespace(kernel_type='poly'))
+
+
+def test_domain_stub():
+  dom = EuclideanDomain([[0, 1], [2, 3]])
+  assert dom.get_type() == 'euclidean' and dom.get_dim() == 2 and dom.is_a_member([0.5, 2.5])
