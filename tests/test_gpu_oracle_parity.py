@@ -132,7 +132,9 @@ def test_fit_and_posterior_against_oracle(engine, kind, d, n, m):
   blk = 512
   bv, bi, samp, jps = gp.thompson(Xs[:2048], U[:2048], block=blk, mean_const=mean_c, return_samples=True)
   sr = og.draw_samples_blocked(Xs[:2048], U[:2048], blk)
-  assert relerr(samp, sr) < 1e-6 and bi == int(np.argmax(sr))
+  # the block covariance needs the jitter ladder (cond ~1e11 after it): rounding differences of
+  # 1e-16 in Sigma are amplified by its Cholesky factor, hence the looser tolerance on the draw
+  assert relerr(samp, sr) < 1e-4 and bi == int(np.argmax(sr))
 
 
 def test_ragged_and_single_point_inputs(engine):
