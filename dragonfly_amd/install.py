@@ -19,7 +19,7 @@ edited):
 Dragonfly's own serial maximisers (DIRECT / PDOO) keep working: they call gp.eval per point, which
 now runs on the device, through `external_maximise_with_method`.
 """
-_saved = {}
+_saved = []     # (object, attribute name, original value)
 
 
 def install():
@@ -31,7 +31,7 @@ def install():
   from . import kernel, euclidean_gp, gpb_acquisitions
   patched = []
   def _set(mod, name, new):
-    _saved[(mod, name)] = getattr(mod, name)
+    _saved.append((mod, name, getattr(mod, name)))
     setattr(mod, name, new)
     patched.append('%s.%s' % (mod.__name__, name))
   for name in ('SEKernel', 'MaternKernel', 'AdditiveKernel'):
@@ -41,7 +41,7 @@ def install():
     ref_ns = getattr(ref_acq, ns_name)
     our_ns = getattr(gpb_acquisitions, ns_name)
     for acq in ('ucb', 'ei', 'pi', 'ttei', 'ts', 'add_ucb'):
-      _saved[(ref_ns, acq)] = getattr(ref_ns, acq)
+      _saved.append((ref_ns, acq, getattr(ref_ns, acq)))
       setattr(ref_ns, acq, getattr(our_ns, acq))
       patched.append('dragonfly.opt.gpb_acquisitions.%s.%s' % (ns_name, acq))
   gpb_acquisitions.external_maximise_with_method = maximise_with_method
@@ -51,7 +51,7 @@ def install():
 def uninstall():
   """ Restores every name install() rebound. """
   from . import gpb_acquisitions
-  for (obj, name), old in list(_saved.items()):
+  for obj, name, old in reversed(_saved):
     setattr(obj, name, old)
-  _saved.clear()
+  del _saved[:]
   gpb_acquisitions.external_maximise_with_method = None

@@ -136,3 +136,34 @@ def test_fitter_set_up_matches_reference_bounds():
 def test_domain_stub():
   dom = EuclideanDomain([[0, 1], [2, 3]])
   assert dom.get_type() == 'euclidean' and dom.get_dim() == 2 and dom.is_a_member([0.5, 2.5])
+
+
+def test_install_rebinds_reference_names():
+  """ dragonfly_amd.install (SURVEY.md section 8b seams S1-S4); needs the reference importable,
+      which is only the case in the build container. """
+  import os
+  import sys
+  ref = os.environ.get('DRAGONFLY_REFERENCE', '/root/reference')
+  if not os.path.isdir(os.path.join(ref, 'dragonfly')):
+    pytest.skip('reference not present')
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+  import make_golden
+  make_golden.import_reference()
+  import dragonfly.gp.kernel as ref_kernel
+  import dragonfly.gp.euclidean_gp as ref_egp
+  import dragonfly.opt.gpb_acquisitions as ref_acq
+  from dragonfly_amd import install, euclidean_gp, gpb_acquisitions
+  orig_se, orig_gp, orig_ucb = ref_kernel.SEKernel, ref_egp.EuclideanGP, ref_acq.asy.ucb
+  patched = install.install()
+  try:
+    assert ref_kernel.SEKernel is K.SEKernel and ref_kernel.AdditiveKernel is K.AdditiveKernel
+    assert ref_egp.EuclideanGP is euclidean_gp.EuclideanGP
+    assert ref_acq.asy.ucb is gpb_acquisitions.asy_ucb and ref_acq.syn.ts is gpb_acquisitions.syn_ts
+    assert gpb_acquisitions.external_maximise_with_method is not None and len(patched) >= 20
+    # the reference's kernel factory now builds device kernels
+    kern, _, _ = ref_egp.get_euclidean_integral_gp_kernel_with_scale(
+        'se', 2.0, {'dim': 3}, np.log([0.3, 0.4, 0.5]), [], False, [[0, 2], [1]])
+    assert isinstance(kern, K.AdditiveKernel) and isinstance(kern.kernel_list[0], K.SEKernel)
+  finally:
+    install.uninstall()
+  assert ref_kernel.SEKernel is orig_se and ref_egp.EuclideanGP is orig_gp and ref_acq.asy.ucb is orig_ucb
