@@ -1,0 +1,31 @@
+"""Small fixed workload for rocprofv3 --pmc passes: the kernel-matrix build at n=16384 (HBM-bound
+pass) and the n=15872, k=512 trailing SYRK + an 8192^3 GEMM (MFMA_F64 passes)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dragonfly_amd.engine import Engine, KernelSpec   # noqa: E402
+
+eng = Engine()
+rs = np.random.RandomState(0)
+n, d = 16384, 32
+X = eng.to_device(rs.rand(n, d))
+Kd = eng.empty((n, n))
+spec = KernelSpec('se', d, 1.3, 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0))
+for _ in range(3):
+  eng.kernel_matrix(spec, X, None, out=Kd)
+M, K = 15872, 512
+A = eng.to_device(rs.rand(M, K) - 0.5)
+Cd = eng.empty((M, M))
+for _ in range(3):
+  eng.gemm(A, A, alpha=-1.0, beta=1.0, shape=(M, M, K), out=Cd, lower_only=True)
+M = 8192
+A2 = eng.to_device(rs.rand(M, M) - 0.5)
+B2 = eng.to_device(rs.rand(M, M) - 0.5)
+C2 = eng.empty((M, M))
+for _ in range(2):
+  eng.gemm(A2, B2, shape=(M, M, M), out=C2)
+eng.sync()
+print('pmc workload done')
