@@ -5,6 +5,8 @@
 #include <limits.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <stdlib.h>
 
 struct dfh_gp {
   dfh_ctx* ctx = nullptr;
@@ -246,16 +248,19 @@ int halluc_prepare(dfh_gp* gp, const double* Xh_user, int64_t q, Halluc* h) {
 // pre_gathered/part range select the add-UCB group path.
 int posterior_chunk(dfh_gp* gp, const double* Xs_dev, int64_t mc, int64_t ldxs, int part_lo, int part_hi,
                     bool pre_gathered, bool want_var, const Halluc* h, double** Kct_out,
-                    double* mu_raw, double* ss, double* ss2) {
+                    double* mu_raw, double* ss, double* ss2, int parity = 0, double** Xsp_out = nullptr,
+                    double** Nsp_out = nullptr) {
   dfh_ctx* ctx = gp->ctx;
   const KernDev& kd = gp->kd;
   double* Xsp = nullptr; double* Nsp = nullptr; double* Kct = nullptr;
   char* xs = nullptr;
   const size_t b_xsp = ((size_t)mc * kd.P * 8 + 255) / 256 * 256;
-  DFH_TRY(scratch_get(ctx, SCR_XS, b_xsp + (size_t)mc * kd.n_parts * 8, (void**)&xs));
+  DFH_TRY(scratch_get(ctx, parity ? SCR_XS2 : SCR_XS, b_xsp + (size_t)mc * kd.n_parts * 8, (void**)&xs));
   Xsp = reinterpret_cast<double*>(xs);
   Nsp = reinterpret_cast<double*>(xs + b_xsp);
-  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)mc * gp->n * 8, (void**)&Kct));
+  DFH_TRY(scratch_get(ctx, parity ? SCR_KCT2 : SCR_KCT, (size_t)mc * gp->n * 8, (void**)&Kct));
+  if (Xsp_out) *Xsp_out = Xsp;
+  if (Nsp_out) *Nsp_out = Nsp;
   {
     SectionTimer t(ctx, DFH_T_CROSS);
     DFH_TRY(pack_scaled(ctx, kd, part_lo, part_hi, pre_gathered, Xs_dev, mc, ldxs, Xsp, Nsp));
@@ -268,7 +273,7 @@ int posterior_chunk(dfh_gp* gp, const double* Xs_dev, int64_t mc, int64_t ldxs, 
       DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, Kct, mc, gp->n));                // gp_core.py:180
     }
     SectionTimer t(ctx, DFH_T_ACQ);
-    DFH_TRY(row_sumsq(ctx, Kct, mc, gp->n, gp->n, ss));
+    if (ss) DFH_TRY(row_sumsq(ctx, Kct, mc, gp->n, gp->n, ss));
     if (h && h->q > 0) {
       const int64_t q = h->q;
       double* T = nullptr;
@@ -751,21 +756,61 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   // several TS blocks share one posterior chunk so the TRSM runs on big GEMMs
   int64_t bpc = std::max<int64_t>(1, pick_chunk(n, m) / block);
   const int64_t mc_max = std::min(m, bpc * block);
+  const int64_t nchunks = (m + mc_max - 1) / mc_max;
   const bool xs_dev = is_device_ptr(Xs), u_dev = is_device_ptr(U);
   const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
-  double* vec = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 4, (void**)&vec));
-  double* mu_raw = vec; double* ss = vec + mc_max; double* samp = vec + 2 * mc_max;
-  double* Sig = nullptr; double* Lb = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)block * block * 8, (void**)&Sig));
+  double* vec[2] = {nullptr, nullptr};
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 2, (void**)&vec[0]));
+  DFH_TRY(scratch_get(ctx, SCR_VECB, (size_t)mc_max * 8 * 2, (void**)&vec[1]));
+  double* Lb = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)block * block * 8, (void**)&Lb));
-  bool have = false; double bv = 0.0; int64_t bi = -1;
-  int64_t blk_idx = 0;
-  for (int64_t i0 = 0; i0 < m; i0 += mc_max) {
+  // Two-stage software pipeline over chunks.  Stage 1 (low-priority `bulk` stream): cross kernel
+  // matrix, mu, and the posterior TRSM of chunk c+1 -- large MFMA GEMMs.  Stage 2 (main + panel
+  // streams): per TS block of chunk c the covariance SYRK, its stable_cholesky (latency-bound
+  // look-ahead factorisation, host-synchronous because of the jitter ladder) and the draw.
+  // The factorisations hide behind the next chunk's TRSM instead of idling the GPU.
+  static const bool ts_half_occ = []() { const char* e = getenv("DFH_TS_HALF_OCC"); return e ? atoi(e) != 0 : true; }();
+  hipStream_t mainS = ctx->stream, bulkS = ctx->bulk;
+  struct Stage1 { double* Kct; double* Xsp; double* Nsp; double* mu; };
+  Stage1 st[2];
+  hipEvent_t ev_in, ev_ready[2], ev_free[2];
+  DFH_TRY(ctx_event(ctx, 1000, &ev_in));
+  for (int p = 0; p < 2; ++p) {
+    DFH_TRY(ctx_event(ctx, 1001 + p, &ev_ready[p]));
+    DFH_TRY(ctx_event(ctx, 1003 + p, &ev_free[p]));
+  }
+  DFH_HIP(hipEventRecord(ev_in, mainS));
+  DFH_HIP(hipStreamWaitEvent(bulkS, ev_in, 0));        // inputs produced on the main stream are ready
+
+  auto stage1 = [&](int64_t c) -> int {
+    const int p = (int)(c & 1);
+    const int64_t i0 = c * mc_max;
     const int64_t mc = std::min(mc_max, m - i0);
+    StreamSwap on_bulk(ctx, bulkS);
+    // one workgroup per CU for the bulk GEMMs: the other half of each CU stays free for the
+    // latency-bound factorisation kernels of stage 2 (which otherwise queue behind full CUs)
+    struct HalfOcc { dfh_ctx* c; bool old; HalfOcc(dfh_ctx* x, bool v) : c(x), old(x->gemm_half_occupancy) { c->gemm_half_occupancy = v; }
+                     ~HalfOcc() { c->gemm_half_occupancy = old; } } half(ctx, nchunks > 1 && ts_half_occ);
+    if (c >= 2) DFH_HIP(hipStreamWaitEvent(bulkS, ev_free[p], 0));   // parity buffers released by stage 2
     const double* xs_c = nullptr;
     if (xs_dev) xs_c = Xs + i0 * gp->d;
-    else DFH_TRY(to_device(ctx, Xs + i0 * gp->d, (size_t)mc * gp->d * 8, SCR_STAGE_A, &xs_c));
+    else DFH_TRY(to_device(ctx, Xs + i0 * gp->d, (size_t)mc * gp->d * 8, p ? SCR_STAGE_A2 : SCR_STAGE_A, &xs_c));
+    st[p].mu = vec[p];
+    DFH_TRY(posterior_chunk(gp, xs_c, mc, gp->d, 0, kd.n_parts, false, true, nullptr, &st[p].Kct, st[p].mu,
+                            nullptr, nullptr, p, &st[p].Xsp, &st[p].Nsp));
+    DFH_HIP(hipEventRecord(ev_ready[p], bulkS));
+    return DFH_OK;
+  };
+
+  bool have = false; double bv = 0.0; int64_t bi = -1;
+  int64_t blk_idx = 0;
+  DFH_TRY(stage1(0));
+  for (int64_t c = 0; c < nchunks; ++c) {
+    const int p = (int)(c & 1);
+    const int64_t i0 = c * mc_max;
+    const int64_t mc = std::min(mc_max, m - i0);
+    if (c + 1 < nchunks) DFH_TRY(stage1(c + 1));        // enqueue ahead: overlaps with the blocks below
+    DFH_HIP(hipStreamWaitEvent(mainS, ev_ready[p], 0));
     const double* u_c = nullptr;
     if (u_dev) u_c = U + i0;
     else DFH_TRY(to_device(ctx, U + i0, (size_t)mc * 8, SCR_STAGE_C, &u_c));
@@ -774,23 +819,22 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
       if (mv_dev) mv_c = mean_vals + i0;
       else DFH_TRY(to_device(ctx, mean_vals + i0, (size_t)mc * 8, SCR_STAGE_D, &mv_c));
     }
-    double* Kct = nullptr;
-    DFH_TRY(posterior_chunk(gp, xs_c, mc, gp->d, 0, kd.n_parts, false, true, nullptr, &Kct, mu_raw, ss, nullptr));
+    double* mu_raw = st[p].mu;
+    double* samp = vec[p] + mc_max;
+    double* Kct = st[p].Kct;
     // mean_vals = test_mean + K_tetr alpha
     hipLaunchKernelGGL(k_add_vec, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, mu_raw, mv_c,
                        mv_c ? 0.0 : mean_const, (long)mc);
     DFH_LAUNCH_CHECK();
-    char* xs = reinterpret_cast<char*>(ctx->scratch[SCR_XS].p);
-    double* Xsp = reinterpret_cast<double*>(xs);
-    double* Nsp = reinterpret_cast<double*>(xs + ((size_t)mc * kd.P * 8 + 255) / 256 * 256);
     for (int64_t b0 = 0; b0 < mc; b0 += block, ++blk_idx) {
       const int64_t B = std::min(block, mc - b0);
       SectionTimer t(ctx, DFH_T_TS);
       const double* Vt = Kct + b0 * n;
+      const double* Xbp = st[p].Xsp + b0 * kd.P;
+      const double* Nbp = st[p].Nsp + b0 * kd.n_parts;
       auto build_sigma = [&]() -> int {
         // Sigma = K(Xb,Xb) - V^T V     (gp_core.py:179-181) ; lower triangle is what chol reads
-        DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xsp + b0 * kd.P, Nsp + b0 * kd.n_parts, B,
-                               Xsp + b0 * kd.P, Nsp + b0 * kd.n_parts, B, true, 0.0, Lb, B));
+        DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xbp, Nbp, B, Xbp, Nbp, B, true, 0.0, Lb, B));
         return gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, Lb, B, Lb, B);
       };
       DFH_TRY(build_sigma());
@@ -802,10 +846,61 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
     }
     DFH_TRY(argmax_update(ctx, samp, mc, i0, &have, &bv, &bi));
     if (samples_out) DFH_TRY(from_device(ctx, samples_out + i0, samp, (size_t)mc * 8));
+    DFH_HIP(hipEventRecord(ev_free[p], mainS));
   }
-  (void)Sig;
-  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  DFH_HIP(hipStreamSynchronize(mainS));
+  DFH_HIP(hipStreamSynchronize(bulkS));
   if (best_val) *best_val = bv;
   if (best_idx) *best_idx = bi;
+  return DFH_OK;
+}
+
+// Diagnostics hook (not part of the product path): do kernels on the bulk stream and on the main /
+// panel streams actually run concurrently?  Enqueues `n_big` large GEMMs on stream A and `n_small`
+// tiny kernels on stream B and reports the time of each alone and together.
+// which: 0 = A is bulk, B is main; 1 = A is main, B is side; 2 = A is bulk, B is side
+extern "C" int dfh_debug_overlap(dfh_ctx* ctx, int which, int n_big, int n_small, double* out_ms /*[4]*/) {
+  DFH_ARG(ctx && out_ms);
+  hipStream_t A = (which == 1) ? ctx->main_stream : ctx->bulk;
+  hipStream_t B = (which == 0) ? ctx->main_stream : ctx->side;
+  const int64_t M = 16384, N = 512, K = 4096;
+  double *a = nullptr, *b = nullptr, *c = nullptr, *v = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)M * K * 8, (void**)&a));
+  DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)N * K * 8, (void**)&b));
+  DFH_TRY(scratch_get(ctx, SCR_TMP, (size_t)M * N * 8, (void**)&c));
+  DFH_TRY(scratch_get(ctx, SCR_VEC, 1 << 20, (void**)&v));
+  DFH_TRY(fill_f64(ctx, a, M * K, 0.5));
+  DFH_TRY(fill_f64(ctx, b, N * K, 0.25));
+  DFH_HIP(hipDeviceSynchronize());
+  int least = 0, greatest = 0;
+  DFH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  out_ms[3] = least * 100.0 + greatest;
+  auto run = [&](bool big, bool small, double* ms) -> int {
+    DFH_HIP(hipDeviceSynchronize());
+    auto t0 = std::chrono::steady_clock::now();
+    if (big) {
+      StreamSwap sw(ctx, A);
+      for (int i = 0; i < n_big; ++i) DFH_TRY(gemm_f64(ctx, 0, M, N, K, 1.0, a, K, b, K, 0.0, nullptr, 0, c, N));
+    }
+    if (small) {
+      StreamSwap sw(ctx, B);
+      for (int i = 0; i < n_small; ++i) {
+        if (which >= 10) DFH_TRY(fill_f64(ctx, v, 4096, 1.0));
+        else DFH_TRY(gemm_f64(ctx, 0, 64, 64, 64, 1.0, a, K, b, K, 0.0, nullptr, 0, v, 64));   // 38 KB LDS, 1 workgroup
+      }
+    }
+    DFH_HIP(hipStreamSynchronize(B));
+    auto t1 = std::chrono::steady_clock::now();
+    DFH_HIP(hipDeviceSynchronize());
+    auto t2 = std::chrono::steady_clock::now();
+    ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    ms[1] = std::chrono::duration<double, std::milli>(t2 - t0).count();
+    return DFH_OK;
+  };
+  double m[2];
+  DFH_TRY(run(true, false, m));  out_ms[0] = m[1];            // big alone
+  DFH_TRY(run(false, true, m));  out_ms[1] = m[1];            // small alone
+  DFH_TRY(run(true, true, m));   out_ms[2] = m[0];            // small-stream completion time when both run
+  out_ms[3] += m[1] * 1e6;                                    // total together (packed: ms*1e6 + prio)
   return DFH_OK;
 }

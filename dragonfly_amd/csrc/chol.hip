@@ -123,7 +123,7 @@ __device__ __forceinline__ double quad_sum(double v) {
 }
 
 // One 64-wide step of the diagonal-block factorisation, one launch:
-//   workgroup 0     : factors the nb x nb pivot block at D in place (upper part zeroed);
+//   workgroup 0     : factors the nb x nb pivot block at D and writes the factor to Lout;
 //   workgroup b >= 1: factors the same block redundantly (bit-identical, no inter-workgroup
 //                     hand-off needed) and solves 64 rows of the column below it,
 //                     P[r,:] <- P[r,:] L^-T, by forward substitution with four lanes per row.
@@ -131,7 +131,7 @@ __device__ __forceinline__ double quad_sum(double v) {
 constexpr int SPP = 66;      // row stride of the column-permuted factor image (16-byte aligned rows)
 __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D, long lda, int nb,
                                                           int rows_below, long pivot_base,
-                                                          long long* info) {
+                                                          long long* info, double* __restrict__ Lout) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* Sp = dsm;                       // [64][SPP] factor, columns permuted by perm16
   double* R = dsm + PB * SPP;             // [64][65] panel rows
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     return;
   }
   if (blockIdx.x == 0) {
+    // The factor goes to a scratch block (64 x 64, ld 64), NOT back into D: the other workgroups
+    // of this launch re-read the unfactored pivot block from D and may start arbitrarily later.
+    // trtri64_kernel moves it into place once the whole diagonal block is done.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = w + 4 * r;
-      if (i < nb && k < nb) D[i * lda + k] = a[r];
-    }
+    for (int r = 0; r < 16; ++r) Lout[(w + 4 * r) * PB + k] = a[r];
     return;
   }
   {
@@ -232,16 +232,29 @@ constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 2 * PB) * 8;
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
 // Padded rows/cols are identity so the full 64-loop is safe.
-__global__ __launch_bounds__(256) void trtri64_kernel(const double* __restrict__ D, long lda, int nbk,
-                                                      double* __restrict__ inv, long ldinv) {
+// Lscr != null: block b's factor is read from Lscr + b*64*64 (ld 64) and also copied into its
+// place on the diagonal of D (upper part zero); Lscr == null: the factor is read from D.
+__global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, long lda, int nbk,
+                                                      double* __restrict__ inv, long ldinv,
+                                                      const double* __restrict__ Lscr) {
   __shared__ double S[PB * PBP];
   const int tid = threadIdx.x;
   const int k = tid & 63, w = tid >> 6;
   const int j0 = blockIdx.x * PB;
   const int nb = min(PB, nbk - j0);
-  const double* A = D + (long)j0 * lda + j0;
+  double* A = D + (long)j0 * lda + j0;
   double a[16];
-  load_block64(A, lda, nb, w, k, a);
+  if (Lscr) {
+    const double* src = Lscr + (long)blockIdx.x * PB * PB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = w + 4 * r;
+      a[r] = src[i * PB + k];
+      if (i < nb && k < nb) A[i * lda + k] = a[r];
+    }
+  } else {
+    load_block64(A, lda, nb, w, k, a);
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) S[(w + 4 * r) * PBP + k] = a[r];
   __syncthreads();
@@ -319,7 +332,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   double* inv_scratch = nullptr;
   if (!keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)NB * NB * 8, (void**)&inv_scratch));
   double* T = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)NB * NB * 8, (void**)&T));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)(NB * NB + (NB / PB) * PB * PB) * 8, (void**)&T));
+  double* Lscr = T + NB * NB;                 // factors of the pivot blocks of the current panel
   double* W = nullptr;
   if (n > NB) DFH_TRY(scratch_get(ctx, SCR_CHOLW, (size_t)(n - NB) * NB * 8, (void**)&W));
 
@@ -330,6 +344,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     attr_set = true;
   }
   const int64_t nblk = (n + NB - 1) / NB;
+  DFH_ARG(2 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
   hipEvent_t ev_start, ev_done;
   DFH_TRY(ctx_event(ctx, 0, &ev_start));
   DFH_TRY(ctx_event(ctx, 1, &ev_done));
@@ -356,7 +371,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
         const int64_t rows = nbk - j0 - w;
         const unsigned nwg = 1 + (unsigned)((rows + PB - 1) / PB);
         hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, P, Djj, (long)lda, w,
-                           (int)rows, (long)(k0 + j0), d_info);
+                           (int)rows, (long)(k0 + j0), d_info, Lscr + (j0 / PB) * PB * PB);
         DFH_LAUNCH_CHECK();
         if (rows > 0) {
           double* Pn = D + (j0 + w) * lda + j0;                      // rows x w, already solved
@@ -365,7 +380,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
         }
       }
       hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, P, D, (long)lda,
-                         (int)nbk, Linv, (long)NB);
+                         (int)nbk, Linv, (long)NB, Lscr);
       DFH_LAUNCH_CHECK();
       DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T));
       // ---- panel solve, then the next block column --------------------------------------
@@ -471,8 +486,8 @@ int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, do
     double* Linv = inv + (k0 / NB) * NB * NB;
     DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, ctx->stream));
     const double* D = L + k0 * ldl + k0;
-    hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, ctx->stream, D,
-                       (long)ldl, (int)nbk, Linv, (long)NB);
+    hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, ctx->stream,
+                       const_cast<double*>(D), (long)ldl, (int)nbk, Linv, (long)NB, (const double*)nullptr);
     DFH_LAUNCH_CHECK();
     DFH_TRY(assemble_block_inverse(ctx, D, ldl, nbk, Linv, T));
   }
@@ -525,7 +540,7 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   for (int r = 0; r < reps; ++r) {
     // the block is re-factored from its own output (still SPD: L has a dominant diagonal)
     hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, ctx->stream, A, (long)nn, 64,
-                       rows_below, 0L, d_info);
+                       rows_below, 0L, d_info, A + 256 * nn);
   }
   DFH_HIP(hipEventRecord(e1, ctx->stream));
   DFH_HIP(hipEventSynchronize(e1));

@@ -48,6 +48,7 @@ struct dfh_ctx {
   hipStream_t stream = nullptr;      // every kernel is launched on this stream ...
   hipStream_t main_stream = nullptr; // (== stream except inside StreamSwap scopes)
   hipStream_t side = nullptr;        // high-priority panel stream of the look-ahead Cholesky
+  hipStream_t bulk = nullptr;        // low-priority stream: next chunk's cross kernel + TRSM (TS)
   std::vector<hipEvent_t> evpool;    // untimed events for cross-stream ordering
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
@@ -61,6 +62,9 @@ struct dfh_ctx {
   char name[256] = {0};
   int n_cu = 256;
   // per-launch HIP-event profile of the GEMM kernel (bench.py roofline numbers)
+  // When set, 128x128 GEMM launches request > 80 KB of LDS so that only ONE workgroup fits per
+  // CU: the other half of every CU stays available to latency-critical kernels of another stream.
+  bool gemm_half_occupancy = false;
   bool gemm_prof = false;
   struct GemmRec { hipEvent_t e0, e1; double flops; int variant; };
   std::vector<GemmRec> gemm_recs;
@@ -74,6 +78,10 @@ enum ScratchSlot {
   SCR_STAGE_D,
   SCR_XS,           // scaled / gathered copies
   SCR_KCT,          // candidate-by-train cross kernel / V^T chunk
+  SCR_XS2,          // second parity of SCR_XS / SCR_KCT / SCR_VEC (pipelined Thompson sampling)
+  SCR_KCT2,
+  SCR_VECB,
+  SCR_STAGE_A2,
   SCR_TMP,          // TRSM block temp
   SCR_TMP2,
   SCR_VEC,          // small vectors

@@ -11,9 +11,10 @@
 // Tiling (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave
 // owns 64x64 = 4x4 MFMA tiles (16 accumulators x 4 f64 = 128 VGPRs).  K is consumed in
 // chunks of 16 through a double-buffered, padded LDS image (one barrier per chunk); global
-// loads of chunk c+1 are issued before the 64 MFMAs of chunk c and written to LDS after
-// them, so HBM/L2 latency hides under the matrix pipe.  2 workgroups per CU (73.7 KB LDS,
-// <=256 VGPRs) keep a second wave per SIMD ready while one sits at the barrier.
+// loads of chunk c+1 are issued before the MFMAs of chunk c, and the MFMA fragments are read from
+// LDS one k-pair ahead into a second register set, so every HBM/L2 and LDS latency hides under
+// the matrix pipe.  2 workgroups per CU (73.7 KB LDS, 250 VGPRs): the second wave per SIMD fills
+// the matrix pipe while the first sits at the barrier (measured: 1 workgroup per CU is ~10 % slower).
 //
 // MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3):
 //   A operand : lane l holds A[i = l&15][k = l>>4]
@@ -102,11 +103,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   if (p.flags & GEMM_KTRI_B) kend = min(p.K, n0 + BN);   // B[j][k] = 0 for k > j
   const int nchunks = (kend + BK - 1) / BK;
 
+  // C enters through the accumulators when alpha = +-1 (the SYRK / TRSM-update case): the tile of
+  // beta*C is loaded at kernel entry, in flight together with the first operand chunk, instead of
+  // being read -- one exposed HBM round trip per tile -- in the epilogue.  out = alpha * acc.
+  const double* __restrict__ Cin0 = p.Cin ? p.Cin + bz * p.sCin : nullptr;
+  const bool c_in_acc = (Cin0 != nullptr) && (p.alpha == 1.0 || p.alpha == -1.0);
   double4_t acc[WT][WT];
+  if (c_in_acc) {
+    const double cscale = p.beta * p.alpha;
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WT; ++i) {
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * WS + i * 16 + l4 + 4 * r;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const int col = n0 + wn * WS + j * 16 + l15;
+          double v = 0.0;
+          if (!EDGE || (row < p.M && col < p.N)) v = cscale * Cin0[(long)row * p.ldcin + col];
+          acc[i][j][r] = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  }
 
   // staging registers: 4 x 16B for A and 4 x 16B for B per thread per chunk
   double2_t ra[G::PA], rb[(G::PA > G::NN_PASSES) ? G::PA : G::NN_PASSES];
@@ -180,29 +204,67 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   }
   __syncthreads();
 
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < nchunks) load_chunk(kc + 1);
-
-    const double* as = As + buf * TILE_A + (wm * WS + l15) * BKP + l4;
-    const double* bs = TRANSB ? (Bs + buf * TILE_B + l4 * BNP + wn * WS + l15)
-                              : (Bs + buf * TILE_B + (wn * WS + l15) * BKP + l4);
+  // Fragment registers for the two k-pairs of a chunk (a pair = two MFMA k-steps = 8 columns).
+  // Schedule per chunk c (one wave per SIMD, so nothing else hides a stall):
+  //   global loads of chunk c+1 | LDS reads of pair 1 (chunk c) | 32 MFMAs on pair 0 |
+  //   LDS writes of chunk c+1, barrier | LDS reads of pair 0 (chunk c+1) | 32 MFMAs on pair 1
+  // so every LDS read has a 32-MFMA (~2000 cycle) shadow and the only exposed work between the
+  // two MFMA groups is the store + barrier.
+  double fa[2][WT][2], fb[2][WT][2];
+  auto read_frags = [&](int buf, int pair, int slot) {
+    const double* as = As + buf * TILE_A + (wm * WS + l15) * BKP + l4 + pair * 8;
+    const double* bs = TRANSB ? (Bs + buf * TILE_B + (l4 + pair * 8) * BNP + wn * WS + l15)
+                              : (Bs + buf * TILE_B + (wn * WS + l15) * BKP + l4 + pair * 8);
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[WT], b[WT];
+    for (int t = 0; t < WT; ++t) {
+      fa[slot][t][0] = as[t * 16 * BKP];
+      fa[slot][t][1] = as[t * 16 * BKP + 4];
+    }
 #pragma unroll
-      for (int t = 0; t < WT; ++t) a[t] = as[t * 16 * BKP + kk * 4];
+    for (int t = 0; t < WT; ++t) {
+      fb[slot][t][0] = TRANSB ? bs[t * 16] : bs[t * 16 * BKP];
+      fb[slot][t][1] = TRANSB ? bs[4 * BNP + t * 16] : bs[t * 16 * BKP + 4];
+    }
+  };
+  auto mfma_pair = [&](int slot) {
 #pragma unroll
-      for (int t = 0; t < WT; ++t) b[t] = TRANSB ? bs[kk * 4 * BNP + t * 16] : bs[t * 16 * BKP + kk * 4];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < WT; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i][ks], fb[slot][j][ks], acc[i][j], 0, 0, 0);
+  };
 
-    if (kc + 1 < nchunks) store_chunk(buf ^ 1);
-    __syncthreads();
+  if (WT == 4) {
+    if (nchunks > 0) read_frags(0, 0, 0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int buf = kc & 1;
+      const bool more = kc + 1 < nchunks;
+      if (more) load_chunk(kc + 1);
+      read_frags(buf, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store_chunk(buf ^ 1);
+      __syncthreads();
+      if (more) read_frags(buf ^ 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // small / latency-bound problems (64 x 64 tiles, few chunks): plain double-buffered loop
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < nchunks) load_chunk(kc + 1);
+      read_frags(buf, 0, 0);
+      read_frags(buf, 1, 1);
+      mfma_pair(0);
+      mfma_pair(1);
+      if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // epilogue
@@ -219,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         const int col = n0 + wn * WS + j * 16 + l15;
         if (EDGE && (row >= p.M || col >= p.N)) continue;
         double v = alpha * acc[i][j][r];
-        if (beta != 0.0) v += beta * Cin[(long)row * p.ldcin + col];
+        if (!c_in_acc && beta != 0.0) v += beta * Cin[(long)row * p.ldcin + col];
         Cout[(long)row * p.ldc + col] = v;
       }
     }
@@ -230,11 +292,16 @@ template <bool TRANSB, bool EDGE, int WT>
 int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
   static bool attr_set = false;
   auto kern = gemm_f64_kernel<TRANSB, EDGE, WT>;
+  constexpr int HALF_OCC_SMEM = 84 * 1024;            // two of these do not fit in 160 KB
+  constexpr int MAX_SMEM = (WT == 4) ? HALF_OCC_SMEM : Geo<WT>::SMEM_BYTES;
   if (!attr_set) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WT>::SMEM_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM));
     attr_set = true;
   }
+  // Optional half occupancy (> 80 KB of LDS keeps a second workgroup off the CU): used for bulk
+  // GEMMs that run beside latency-critical kernels of another stream, which then find free slots.
+  const int smem = (WT == 4 && ctx->gemm_half_occupancy) ? HALF_OCC_SMEM : Geo<WT>::SMEM_BYTES;
   dfh_ctx::GemmRec* rec = nullptr;
   if (ctx->gemm_prof) {
     if (ctx->gemm_used == ctx->gemm_recs.size()) {
@@ -253,7 +320,7 @@ int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
     rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);
     DFH_HIP(hipEventRecord(rec->e0, ctx->stream));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), Geo<WT>::SMEM_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->stream, p);
   DFH_LAUNCH_CHECK();
   if (rec) DFH_HIP(hipEventRecord(rec->e1, ctx->stream));
   return DFH_OK;
@@ -309,6 +376,7 @@ extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out)
     for (int i = 0; i < 24; ++i) stats_out[i] = 0.0;
     DFH_HIP(hipStreamSynchronize(ctx->main_stream));
     DFH_HIP(hipStreamSynchronize(ctx->side));
+    DFH_HIP(hipStreamSynchronize(ctx->bulk));
     for (size_t i = 0; i < ctx->gemm_used; ++i) {
       float ms = 0.f;
       DFH_HIP(hipEventElapsedTime(&ms, ctx->gemm_recs[i].e0, ctx->gemm_recs[i].e1));

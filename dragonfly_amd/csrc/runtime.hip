@@ -58,6 +58,7 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     int least = 0, greatest = 0;
     DFH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     DFH_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
+    DFH_HIP(hipStreamCreateWithPriority(&ctx->bulk, hipStreamNonBlocking, least));
   }
   DFH_HIP(hipEventCreate(&ctx->ev0));
   DFH_HIP(hipEventCreate(&ctx->ev1));
@@ -90,6 +91,7 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   for (auto e : ctx->evpool) (void)hipEventDestroy(e);
   for (auto& r : ctx->gemm_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->bulk) (void)hipStreamDestroy(ctx->bulk);
   (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
 }
@@ -97,6 +99,8 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
 extern "C" int dfh_sync(dfh_ctx* ctx) {
   DFH_ARG(ctx != nullptr);
   DFH_HIP(hipStreamSynchronize(ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->side));
+  DFH_HIP(hipStreamSynchronize(ctx->bulk));
   return DFH_OK;
 }
 
@@ -188,6 +192,7 @@ int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out) {
     if (b.p) {
       DFH_HIP(hipStreamSynchronize(ctx->main_stream));
       DFH_HIP(hipStreamSynchronize(ctx->side));
+      DFH_HIP(hipStreamSynchronize(ctx->bulk));
       DFH_HIP(hipFree(b.p));
       b.p = nullptr; b.bytes = 0;
     }

@@ -119,3 +119,20 @@ def test_blocked_thompson_is_block_aligned_shard_invariant(engine, fitted):
   mu, sd = gp.predict(Xc[:B])
   z = (samp[:B] - (mu + mean_c)) / sd
   assert abs(z.mean()) < 0.2 and 0.7 < z.std() < 1.3
+
+
+def test_fit_is_bitwise_repeatable_under_concurrent_load(engine, fitted):
+  """ Regression for a cross-workgroup race in the pivot-block kernel (the factor used to be
+      written back while late-starting workgroups still read the unfactored block): refits
+      interleaved with heavy multi-stream work must be bit-identical. """
+  gp0 = fitted['gp']
+  a0, lml0 = gp0.get_alpha(), gp0.lml
+  Xc = np.random.RandomState(5).random_sample((3 * 4096, D))
+  U = np.random.RandomState(6).standard_normal(len(Xc))
+  for rep in range(3):
+    gp = engine.gp_fit(fitted['spec'], fitted['X'], fitted['Y'] - fitted['mean_c'], fitted['noise'])
+    v1 = gp.thompson(Xc, U, block=4096, mean_const=fitted['mean_c'])
+    assert gp.lml == lml0 and np.array_equal(gp.get_alpha(), a0)
+    v2 = gp0.thompson(Xc, U, block=4096, mean_const=fitted['mean_c'])
+    assert v1 == v2
+    gp.free()
