@@ -904,3 +904,43 @@ extern "C" int dfh_debug_overlap(dfh_ctx* ctx, int which, int n_big, int n_small
   out_ms[3] += m[1] * 1e6;                                    // total together (packed: ms*1e6 + prio)
   return DFH_OK;
 }
+
+// Diagnostics hook: achievable pure-write HBM bandwidth (the kernel-matrix build is write-only).
+__global__ void k_dbg_fill16(double2_t* p, long n2, double v) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const double2_t vv = (double2_t){v, v};
+  for (; i < n2; i += stride) p[i] = vv;
+}
+__global__ void k_dbg_copy16(const double2_t* __restrict__ s, double2_t* __restrict__ d, long n2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n2; i += stride) d[i] = s[i];
+}
+extern "C" int dfh_debug_write_bw(dfh_ctx* ctx, double gbytes, double* out /*[3]: fill16 TB/s, memset TB/s, copy TB/s (r+w)*/) {
+  DFH_ARG(ctx && out && gbytes > 0.01 && gbytes < 16);
+  const long n2 = (long)(gbytes * 1e9 / 16);
+  double2_t *a = nullptr, *b = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n2 * 16, (void**)&a));
+  DFH_TRY(scratch_get(ctx, SCR_KCT2, (size_t)n2 * 16, (void**)&b));
+  hipEvent_t e0, e1;
+  DFH_HIP(hipEventCreate(&e0)); DFH_HIP(hipEventCreate(&e1));
+  float ms;
+  for (int grid : {2048, 8192}) {
+    hipLaunchKernelGGL(k_dbg_fill16, dim3(grid), dim3(256), 0, ctx->stream, a, n2, 1.0);
+  }
+  DFH_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_dbg_fill16, dim3(4096), dim3(256), 0, ctx->stream, a, n2, 2.0);
+  DFH_HIP(hipEventRecord(e1, ctx->stream)); DFH_HIP(hipEventSynchronize(e1));
+  DFH_HIP(hipEventElapsedTime(&ms, e0, e1)); out[0] = 5.0 * n2 * 16 / (ms * 1e-3) / 1e12;
+  DFH_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < 5; ++r) DFH_HIP(hipMemsetAsync(a, 0, (size_t)n2 * 16, ctx->stream));
+  DFH_HIP(hipEventRecord(e1, ctx->stream)); DFH_HIP(hipEventSynchronize(e1));
+  DFH_HIP(hipEventElapsedTime(&ms, e0, e1)); out[1] = 5.0 * n2 * 16 / (ms * 1e-3) / 1e12;
+  DFH_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_dbg_copy16, dim3(4096), dim3(256), 0, ctx->stream, a, b, n2);
+  DFH_HIP(hipEventRecord(e1, ctx->stream)); DFH_HIP(hipEventSynchronize(e1));
+  DFH_HIP(hipEventElapsedTime(&ms, e0, e1)); out[2] = 5.0 * 2.0 * n2 * 16 / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return DFH_OK;
+}

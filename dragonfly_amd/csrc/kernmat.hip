@@ -16,6 +16,7 @@
 // 8*(n1*n2 + (n1+n2)*d) algorithmic bytes).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -41,15 +42,39 @@ __device__ __forceinline__ double ipow(double m, int k) {
   return r;
 }
 
+// exp(x) for the arguments a stationary kernel produces (x <= 0; also fine for moderate x > 0):
+// x = n ln2 + r, |r| <= ln2/2, degree-11 polynomial (Chebyshev-node interpolant of exp on that
+// interval: 4e-18 approximation error, ~0.7 ulp after Horner in fp64), scaled by v_ldexp_f64.
+// 17 fp64 VALU ops -- the epilogue of the kernel-matrix build is VALU-bound, so this is the lever.
+__device__ __forceinline__ double exp_fast(double x) {
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 0x1.af631d0059becp-26;
+  p = fma(p, r, 0x1.28b4057f44145p-22);
+  p = fma(p, r, 0x1.71ddf5749d126p-19);
+  p = fma(p, r, 0x1.a01991ac8730ap-16);
+  p = fma(p, r, 0x1.a01a01b14378fp-13);
+  p = fma(p, r, 0x1.6c16c187fbe02p-10);
+  p = fma(p, r, 0x1.111111110f225p-7);
+  p = fma(p, r, 0x1.555555554f0cfp-5);
+  p = fma(p, r, 0x1.555555555555ap-3);
+  p = fma(p, r, 0x1.0000000000011p-1);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  // |x| beyond the double exponent range: n saturates, ldexp returns 0 / inf; NaN propagates
+  return ldexp(p, (int)fmax(fmin(n, 4000.0), -4000.0));
+}
+
 __device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq) {
   if (pd.kind == DFH_KERNEL_SE) {
-    return pd.scale_c * exp(-dsq / 2);                     // kernel.py:176
+    return pd.scale_c * exp_fast(-dsq / 2);                // kernel.py:176
   } else if (pd.kind == DFH_KERNEL_MATERN) {
     const double dist = sqrt(dsq);                         // kernel.py:296
     const double mult = pd.s8 * dist;                      // kernel.py:265
     double u = 0.0;
     for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * ipow(mult, pd.p - i);   // kernel.py:266
-    u *= (pd.gfac * exp(-pd.s2 * dist));                   // kernel.py:268-269
+    u *= (pd.gfac * exp_fast(-pd.s2 * dist));              // kernel.py:268-269
     return pd.scale_c * u;                                 // kernel.py:298
   }
   return dsq;                                              // DFH_KERNEL_DIST
@@ -78,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
   }
 
   for (int part = p.part_lo; part < p.part_hi; ++part) {
-    const PartDev pd = p.parts[part];
+    const PartDev& pd = p.parts[part];          // stays in global memory: uniform scalar loads
     double4_t acc[4][TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -170,6 +195,155 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
           if (p.symmetric && row == col) v += p.diag_add;         // gp_core.py:843
           p.K[row * p.ldk + col] = v;
         }
+      }
+    }
+  }
+}
+
+// Symmetric Gram matrix K(X, X) + diag_add I, single-part kernels: only the tiles on and below the
+// diagonal are computed; each off-diagonal tile is written twice, as itself and transposed into its
+// mirror position.  Both images go through an LDS staging buffer so that every global store is a
+// full 16-byte-per-lane row segment (the natural MFMA accumulator layout only offers 8-byte stores
+// in 128-byte segments, and none at all for the transposed image).
+// TS = tile edge: 64 (2x2 MFMA tiles per wave, ~35 KB LDS, 4 workgroups per CU -- the phases
+// load / MFMA / exp / store of different workgroups overlap) or 128.
+template <int TS, int KC, int SR, int OCC>
+__global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
+  constexpr int WT = TS / 32;            // MFMA tiles per wave per dimension
+  constexpr int WS = TS / 2;             // wave tile edge
+  constexpr int SP = TS + 2;             // staging row stride (doubles): 16-byte aligned rows
+  constexpr int NH = TS / SR;            // SR-row staging passes per image
+  constexpr int KP = KC + 2;             // operand row stride: = 2 (mod 32) for KC = 32, 18 for KC = 16
+  constexpr int OPER = 2 * TS * KP;      // doubles of the two operand tiles
+  constexpr int STAGE = SR * SP;
+  constexpr int BODY = (OPER > STAGE) ? OPER : STAGE;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                     // [TS][KP]
+  double* Bs = As + TS * KP;             // [TS][KP]
+  double* na = smem + BODY;              // [TS]
+  double* nb = na + TS;                  // [TS]
+  double* St = smem;                     // [SR][SP] staging, reuses the operand tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // lower-triangular tile enumeration
+  const unsigned lin = blockIdx.x;
+  unsigned ti = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+  while ((unsigned long long)ti * (ti + 1) / 2 > lin) --ti;
+  while ((unsigned long long)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+  const unsigned tj = lin - (unsigned)((unsigned long long)ti * (ti + 1) / 2);
+  const long m0 = (long)ti * TS, n0 = (long)tj * TS;
+  const PartDev& pd = p.parts[p.part_lo];
+
+  double4_t acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < pd.kc; k0 += KC) {
+    const int kc = min(KC, pd.kc - k0);
+    const int kh = kc >> 1;
+    __syncthreads();
+    for (int idx = tid; idx < TS * kh; idx += 256) {
+      const int r = idx / kh, c2 = (idx - r * kh) * 2;
+      const long rowa = m0 + r, rowb = n0 + r;
+      double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
+      if (rowa < p.n1) va = *reinterpret_cast<const double2_t*>(p.Xp1 + rowa * p.P + pd.poff + k0 + c2);
+      if (rowb < p.n1) vb = *reinterpret_cast<const double2_t*>(p.Xp1 + rowb * p.P + pd.poff + k0 + c2);
+      *reinterpret_cast<double2_t*>(As + r * KP + c2) = va;
+      *reinterpret_cast<double2_t*>(Bs + r * KP + c2) = vb;
+    }
+    if (k0 == 0) {
+      if (tid < TS) {
+        const long row = m0 + tid;
+        na[tid] = row < p.n1 ? p.Np1[row * p.n_parts_total + p.part_lo] : 0.0;
+      } else if (tid - TS < TS) {
+        const long row = n0 + tid - TS;
+        nb[tid - TS] = row < p.n1 ? p.Np1[row * p.n_parts_total + p.part_lo] : 0.0;
+      }
+    }
+    __syncthreads();
+    const double* as = As + (wm * WS + l15) * KP + l4;
+    const double* bs = Bs + (wn * WS + l15) * KP + l4;
+    for (int kk = 0; kk < kc; kk += 4) {
+      double a[WT], b[WT];
+#pragma unroll
+      for (int t = 0; t < WT; ++t) a[t] = as[t * 16 * KP + kk];
+#pragma unroll
+      for (int t = 0; t < WT; ++t) b[t] = bs[t * 16 * KP + kk];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // distances -> kernel values (in the accumulator registers).  SE: -dsq/2 is formed directly as
+  // acc - (na/2 + nb/2): scaling by powers of two commutes with rounding, so this is bit-identical
+  // to ((nb + na) - 2 acc) clipped at 0 and then halved and negated (general_utils.py:66-69,
+  // kernel.py:176).  The diagonal term only exists in diagonal tiles.
+  const bool se = (pd.kind == DFH_KERNEL_SE);
+  const bool diag_tile = (ti == tj);
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = wm * WS + i * 16 + l4 + 4 * r;
+      const double nai = na[lr];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        const int lc = wn * WS + j * 16 + l15;
+        double kv;
+        if (se) {
+          double t = acc[i][j][r] - (0.5 * nb[lc] + 0.5 * nai);
+          t = t > 0.0 ? 0.0 : t;
+          kv = pd.scale_c * exp_fast(t);
+        } else {
+          double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];
+          dsq = dsq < 0.0 ? 0.0 : dsq;
+          kv = kern_eval(pd, dsq);
+        }
+        if (diag_tile && lr == lc) kv += p.diag_add;
+        acc[i][j][r] = kv;
+      }
+    }
+  }
+
+  // staged stores: passes [0, NH) = the tile itself, SR rows at a time; passes [NH, 2 NH) = the
+  // mirror image (rows = original columns)
+  const int npass = (ti == tj) ? NH : 2 * NH;
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool mirror = pass >= NH;
+    const int h = mirror ? pass - NH : pass;
+    __syncthreads();                                   // staging buffer free (and operands dead)
+    // image row of an accumulator element: direct -> wm*WS + i*16 + l4 + 4r ; mirror -> wn*WS + j*16 + l15
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const int irow = mirror ? (wn * WS + j * 16 + l15) : (wm * WS + i * 16 + l4 + 4 * r);
+          const int icol = mirror ? (wm * WS + i * 16 + l4 + 4 * r) : (wn * WS + j * 16 + l15);
+          if (irow / SR == h) St[(irow - h * SR) * SP + icol] = acc[i][j][r];
+        }
+    __syncthreads();
+    const long row_base = (mirror ? n0 : m0) + h * SR;
+    const long col_base = mirror ? m0 : n0;
+    constexpr int RP = TS / 2;                         // double2 per staged row
+#pragma unroll
+    for (int q = 0; q < (SR * RP) / 256; ++q) {
+      const int idx = tid + 256 * q;
+      const int r = idx / RP, c2 = (idx % RP) * 2;
+      const long row = row_base + r, col = col_base + c2;
+      if (row < p.n1 && col + 1 < p.n1) {
+        *reinterpret_cast<double2_t*>(p.K + row * p.ldk + col) =
+            *reinterpret_cast<const double2_t*>(St + r * SP + c2);
+      } else if (row < p.n1 && col < p.n1) {
+        p.K[row * p.ldk + col] = St[r * SP + c2];
       }
     }
   }
@@ -412,6 +586,30 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
     attr_set = true;
+  }
+  if (symmetric && !multi && part_hi == part_lo + 1 && (ldk & 1) == 0 &&
+      (reinterpret_cast<uintptr_t>(K) & 15) == 0) {
+    // 64 x 64 tiles, 16-column operand chunks, 32-row staging: ~20 KB of LDS and 69 VGPRs per
+    // workgroup -> 7-8 workgroups per CU whose load / MFMA / exp / store phases overlap.
+    static const int sym_cfg = []() { const char* e = getenv("DFH_KM_CFG"); return e ? atoi(e) : 0; }();
+    auto smem_bytes = [](int TS, int KC, int SR) {
+      const int oper = 2 * TS * (KC + 2), stage = SR * (TS + 2);
+      return ((oper > stage ? oper : stage) + 2 * TS) * 8;
+    };
+    if (sym_cfg == 2) {
+      static bool attr = false;
+      if (!attr) { DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_sym_kernel<128, 32, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(128, 32, 64))); attr = true; }
+      const int64_t T = (n1 + 127) / 128;
+      hipLaunchKernelGGL((kernmat_sym_kernel<128, 32, 64, 2>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(128, 32, 64), ctx->stream, a);
+    } else if (sym_cfg == 1) {
+      const int64_t T = (n1 + 63) / 64;
+      hipLaunchKernelGGL((kernmat_sym_kernel<64, 32, 64, 4>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 32, 64), ctx->stream, a);
+    } else {
+      const int64_t T = (n1 + 63) / 64;
+      hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 16, 32), ctx->stream, a);
+    }
+    DFH_LAUNCH_CHECK();
+    return DFH_OK;
   }
   const int64_t rows_per_launch = 65535LL * KM_BM;
   for (int64_t r0 = 0; r0 < n1; r0 += rows_per_launch) {
