@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
 // in 128-byte segments, and none at all for the transposed image).
 // TS = tile edge: 64 (2x2 MFMA tiles per wave, ~35 KB LDS, 4 workgroups per CU -- the phases
 // load / MFMA / exp / store of different workgroups overlap) or 128.
-template <int TS, int KC, int SR, int OCC>
+template <int TS, int KC, int SR, int OCC, bool SYM>
 __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
   constexpr int WT = TS / 32;            // MFMA tiles per wave per dimension
   constexpr int WS = TS / 2;             // wave tile edge
@@ -227,14 +227,21 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
-  // lower-triangular tile enumeration
-  const unsigned lin = blockIdx.x;
-  unsigned ti = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
-  while ((unsigned long long)ti * (ti + 1) / 2 > lin) --ti;
-  while ((unsigned long long)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
-  const unsigned tj = lin - (unsigned)((unsigned long long)ti * (ti + 1) / 2);
+  unsigned ti, tj;
+  if (SYM) {                              // lower-triangular tile enumeration
+    const unsigned lin = blockIdx.x;
+    ti = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+    while ((unsigned long long)ti * (ti + 1) / 2 > lin) --ti;
+    while ((unsigned long long)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+    tj = lin - (unsigned)((unsigned long long)ti * (ti + 1) / 2);
+  } else {                                // cross matrix: plain 2-D grid
+    ti = blockIdx.y; tj = blockIdx.x;
+  }
   const long m0 = (long)ti * TS, n0 = (long)tj * TS;
   const PartDev& pd = p.parts[p.part_lo];
+  const double* __restrict__ XpB = SYM ? p.Xp1 : p.Xp2;
+  const double* __restrict__ NpB = SYM ? p.Np1 : p.Np2;
+  const long nB = SYM ? p.n1 : p.n2;
 
   double4_t acc[WT][WT];
 #pragma unroll
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
       const long rowa = m0 + r, rowb = n0 + r;
       double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
       if (rowa < p.n1) va = *reinterpret_cast<const double2_t*>(p.Xp1 + rowa * p.P + pd.poff + k0 + c2);
-      if (rowb < p.n1) vb = *reinterpret_cast<const double2_t*>(p.Xp1 + rowb * p.P + pd.poff + k0 + c2);
+      if (rowb < nB) vb = *reinterpret_cast<const double2_t*>(XpB + rowb * p.P + pd.poff + k0 + c2);
       *reinterpret_cast<double2_t*>(As + r * KP + c2) = va;
       *reinterpret_cast<double2_t*>(Bs + r * KP + c2) = vb;
     }
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
         na[tid] = row < p.n1 ? p.Np1[row * p.n_parts_total + p.part_lo] : 0.0;
       } else if (tid - TS < TS) {
         const long row = n0 + tid - TS;
-        nb[tid - TS] = row < p.n1 ? p.Np1[row * p.n_parts_total + p.part_lo] : 0.0;
+        nb[tid - TS] = row < nB ? NpB[row * p.n_parts_total + p.part_lo] : 0.0;
       }
     }
     __syncthreads();
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
   // to ((nb + na) - 2 acc) clipped at 0 and then halved and negated (general_utils.py:66-69,
   // kernel.py:176).  The diagonal term only exists in diagonal tiles.
   const bool se = (pd.kind == DFH_KERNEL_SE);
-  const bool diag_tile = (ti == tj);
+  const bool diag_tile = SYM && (ti == tj);
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
 
   // staged stores: passes [0, NH) = the tile itself, SR rows at a time; passes [NH, 2 NH) = the
   // mirror image (rows = original columns)
-  const int npass = (ti == tj) ? NH : 2 * NH;
+  const int npass = (!SYM || ti == tj) ? NH : 2 * NH;
   for (int pass = 0; pass < npass; ++pass) {
     const bool mirror = pass >= NH;
     const int h = mirror ? pass - NH : pass;
@@ -339,11 +346,13 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
       const int idx = tid + 256 * q;
       const int r = idx / RP, c2 = (idx % RP) * 2;
       const long row = row_base + r, col = col_base + c2;
-      if (row < p.n1 && col + 1 < p.n1) {
+      const long nrow = mirror ? nB : p.n1, ncol = mirror ? p.n1 : nB;
+      if (row < nrow && col + 1 < ncol) {
         *reinterpret_cast<double2_t*>(p.K + row * p.ldk + col) =
             *reinterpret_cast<const double2_t*>(St + r * SP + c2);
-      } else if (row < p.n1 && col < p.n1) {
+      } else if (row < nrow && col < ncol) {
         p.K[row * p.ldk + col] = St[r * SP + c2];
+        if (col + 1 < ncol) p.K[row * p.ldk + col + 1] = St[r * SP + c2 + 1];
       }
     }
   }
@@ -587,8 +596,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
     attr_set = true;
   }
-  if (symmetric && !multi && part_hi == part_lo + 1 && (ldk & 1) == 0 &&
-      (reinterpret_cast<uintptr_t>(K) & 15) == 0) {
+  if (!multi && part_hi == part_lo + 1 && (ldk & 1) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 &&
+      (n1 + 63) / 64 <= 65535) {
     // 64 x 64 tiles, 16-column operand chunks, 32-row staging: ~20 KB of LDS and 69 VGPRs per
     // workgroup -> 7-8 workgroups per CU whose load / MFMA / exp / store phases overlap.
     static const int sym_cfg = []() { const char* e = getenv("DFH_KM_CFG"); return e ? atoi(e) : 0; }();
@@ -596,17 +605,22 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
       const int oper = 2 * TS * (KC + 2), stage = SR * (TS + 2);
       return ((oper > stage ? oper : stage) + 2 * TS) * 8;
     };
-    if (sym_cfg == 2) {
-      static bool attr = false;
-      if (!attr) { DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_sym_kernel<128, 32, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(128, 32, 64))); attr = true; }
-      const int64_t T = (n1 + 127) / 128;
-      hipLaunchKernelGGL((kernmat_sym_kernel<128, 32, 64, 2>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(128, 32, 64), ctx->stream, a);
-    } else if (sym_cfg == 1) {
-      const int64_t T = (n1 + 63) / 64;
-      hipLaunchKernelGGL((kernmat_sym_kernel<64, 32, 64, 4>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 32, 64), ctx->stream, a);
+    if (symmetric) {
+      if (sym_cfg == 2) {
+        static bool attr = false;
+        if (!attr) { DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_sym_kernel<128, 32, 64, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(128, 32, 64))); attr = true; }
+        const int64_t T = (n1 + 127) / 128;
+        hipLaunchKernelGGL((kernmat_sym_kernel<128, 32, 64, 2, true>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(128, 32, 64), ctx->stream, a);
+      } else if (sym_cfg == 1) {
+        const int64_t T = (n1 + 63) / 64;
+        hipLaunchKernelGGL((kernmat_sym_kernel<64, 32, 64, 4, true>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 32, 64), ctx->stream, a);
+      } else {
+        const int64_t T = (n1 + 63) / 64;
+        hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7, true>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 16, 32), ctx->stream, a);
+      }
     } else {
-      const int64_t T = (n1 + 63) / 64;
-      hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 16, 32), ctx->stream, a);
+      dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64));
+      hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7, false>), grid, dim3(256), smem_bytes(64, 16, 32), ctx->stream, a);
     }
     DFH_LAUNCH_CHECK();
     return DFH_OK;
