@@ -124,12 +124,15 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   dist = None
   torch = None
-  if world > 1:
+  force_dist = os.environ.get('DFH_BENCH_FORCE_DIST', '0') == '1'   # exercise the RCCL path on one GPU
+  if world > 1 or force_dist:
     # torch is plumbing only: process group (RCCL) for the barrier and the 16-byte all-gather
     import torch                      # pylint: disable=import-outside-toplevel
     import torch.distributed as dist  # pylint: disable=import-outside-toplevel
     torch.cuda.set_device(local_rank)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if force_dist and 'RANK' not in os.environ:
+      os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'))
     dist.init_process_group('nccl')
   os.environ['DFH_DEVICE'] = str(local_rank)
 
@@ -181,6 +184,7 @@ def main():
     elapsed = float(tt.item())
   ms_per_step = elapsed * 1e3 / args.steps
 
+  out = None
   if rank == 0:
     g0 = gstats[0]                       # 128x128 NT tiles: the throughput configuration
     all_ms = sum(g['ms'] for g in gstats)
@@ -216,10 +220,12 @@ def main():
       out['cpu_baseline'] = cpu_baseline(X, Y, bw, mean_c, noise)
     elif not args.no_cpu_baseline:
       out['cpu_baseline'] = None
-    print(json.dumps(out))
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()
+  if rank == 0:
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout
 
 
 if __name__ == '__main__':
