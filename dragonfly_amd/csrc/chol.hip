@@ -67,45 +67,125 @@ __device__ __forceinline__ int perm16(int i) { return (i & 3) * 16 + (i >> 2); }
 
 #define LDS_FENCE() asm volatile("" ::: "memory")   // keeps every LDS load above it, every use below
 
-__device__ __forceinline__ bool factor64(double (&a)[16], int nb, int w, int k, double (*colbuf)[PB],
+// 1/sqrt(d) and sqrt(d) for a positive normal d: v_rsq_f64 seed + two Newton steps + one
+// residual correction each (<= ~1 ulp).
+__device__ __forceinline__ void fast_rsqrt_sqrt(double d, double* rs, double* sq) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  double s = d * y;
+  s = fma(fma(-s, s, d), 0.5 * y, s);        // sqrt(d)
+  const double r = fast_div(1.0, s, y);      // 1/sqrt(d) consistent with s
+  *rs = r;
+  *sq = s;
+}
+
+// Rank-4 blocked factorisation of the register-resident 64 x 64 block: 16 super-steps instead of
+// 64 column steps.  Super-step s (columns j0 = 4s .. j0+3): the owners of those four columns
+// publish them (raw) through a double-buffered LDS panel, one barrier, then EVERY thread
+//   - factors the raw 4 x 4 diagonal block (identical arithmetic in all threads -> uniform),
+//   - forward-substitutes the raw 4-vectors of its own 16 rows and of row k against it, and
+//   - applies the rank-4 update a[i][k] -= sum_c L[i][j0+c] L[k][j0+c] to its 16 elements
+// (column owners instead keep the transformed values: their column is final).  The redundant
+// 4 x 4 work costs ~250 fp64 ops per thread per super-step but removes three of every four
+// barrier + LDS round trips, which is what the column-at-a-time version spent its time on.
+// colbuf: [2][4][64] doubles.  Returns false (uniformly) on a non-positive / NaN pivot.
+__device__ __forceinline__ bool factor64(double (&a)[16], int nb, int w, int k, double* colbuf,
                                          int* fail_j, double* diag_out) {
-  double my_d = 1.0;
   const int pk = perm16(k);
-  for (int j = 0; j < nb; ++j) {
-    double* cb = colbuf[j & 1];
-    if (k == j) {
+  double my_diag = 1.0;
+  const int nsuper = (nb + 3) >> 2;
+  for (int sidx = 0; sidx < nsuper; ++sidx) {
+    const int j0 = sidx * 4;
+    double* cb = colbuf + (sidx & 1) * 4 * PB;
+    if (k >= j0 && k < j0 + 4) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) cb[w * 16 + r] = a[r];
+      for (int r = 0; r < 16; ++r) cb[(k - j0) * PB + w * 16 + r] = a[r];
     }
     __syncthreads();
-    // issue every LDS read of the step together (one latency, not sixteen)
-    const double d = cb[perm16(j)];
-    const double cbk = cb[pk];
-    double ci[16];
+    // every LDS read of the super-step up front
+    double D[4][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ci[r] = cb[w * 16 + r];
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) D[rr][c] = (c <= rr) ? cb[c * PB + perm16(j0 + rr)] : 0.0;
+    double pkv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pkv[c] = cb[c * PB + pk];
+    double pr[4][16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[c][r] = cb[c * PB + w * 16 + r];
     LDS_FENCE();
-    if (!(d > 0.0)) {                                  // uniform: every thread reads the same d
-      *fail_j = j;
-      return false;
-    }
-    if (k == j) my_d = d;
-    if (k > j) {
-      const double ck = fast_div(cbk, d, fast_rcp(d));
+
+    // 4 x 4 Cholesky of the raw diagonal block.  Branch-free: a bad pivot only raises a flag that
+    // is tested once per super-step, so the whole super-step is one basic block and the scheduler
+    // can interleave the row solves below with the reciprocal-sqrt latency chains.
+    double r0, r1, r2, r3, l00, l11, l22, l33;
+    int bad = -1;
+    bad = (!(D[0][0] > 0.0)) ? 0 : bad;
+    fast_rsqrt_sqrt(D[0][0], &r0, &l00);
+    const double l10 = D[1][0] * r0, l20 = D[2][0] * r0, l30 = D[3][0] * r0;
+    const double d1 = fma(-l10, l10, D[1][1]);
+    bad = (bad < 0 && !(d1 > 0.0)) ? 1 : bad;
+    fast_rsqrt_sqrt(d1, &r1, &l11);
+    const double l21 = fma(-l20, l10, D[2][1]) * r1, l31 = fma(-l30, l10, D[3][1]) * r1;
+    const double d2 = fma(-l21, l21, fma(-l20, l20, D[2][2]));
+    bad = (bad < 0 && !(d2 > 0.0)) ? 2 : bad;
+    fast_rsqrt_sqrt(d2, &r2, &l22);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, D[3][2])) * r2;
+    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, D[3][3])));
+    bad = (bad < 0 && !(d3 > 0.0)) ? 3 : bad;
+    fast_rsqrt_sqrt(d3, &r3, &l33);
+
+    // x L4^T = p for row k and for the thread's 16 rows
+    auto solve4 = [&](double p0, double p1, double p2, double p3, double (&x)[4]) {
+      x[0] = p0 * r0;
+      x[1] = fma(-x[0], l10, p1) * r1;
+      x[2] = fma(-x[1], l21, fma(-x[0], l20, p2)) * r2;
+      x[3] = fma(-x[2], l32, fma(-x[1], l31, fma(-x[0], l30, p3))) * r3;
+    };
+    double xk[4];
+    solve4(pkv[0], pkv[1], pkv[2], pkv[3], xk);
+    // One divergence-free update for every lane:  a[r] <- base + sum_c xi[c] * coef[c]
+    //   trailing column (k >= j0+4): base = a[r], coef = -x_k            (rank-4 update)
+    //   panel column    (k = j0+kc): base = 0,    coef = e_kc            (the column becomes final)
+    //   finished column (k <  j0)  : base = a[r], coef = 0               (unchanged)
+    // Rows of this thread are i = w + 4r: rows below the panel are r > sidx, the row inside the
+    // 4 x 4 diagonal block is r == sidx (i - j0 = w), rows above are r < sidx.
+    const bool trailing = k >= j0 + 4;
+    const bool owner = (k >= j0) && !trailing;
+    const int kc = k - j0;
+    double coef[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = w + 4 * r;
-        const double upd = fma(-ci[r], ck, a[r]);
-        a[r] = (i > j) ? upd : a[r];
-      }
+    for (int c = 0; c < 4; ++c) coef[c] = trailing ? -xk[c] : ((owner && kc == c) ? 1.0 : 0.0);
+    // L4[w][kc]: the owner's value in the diagonal block row (wave-uniform row w, per-lane column kc)
+    const double l4row[4] = {(w == 0) ? l00 : (w == 1) ? l10 : (w == 2) ? l20 : l30,
+                             (w == 1) ? l11 : (w == 2) ? l21 : (w == 3) ? l31 : 0.0,
+                             (w == 2) ? l22 : (w == 3) ? l32 : 0.0,
+                             (w == 3) ? l33 : 0.0};
+    const double l4wk = (kc == 0) ? l4row[0] : (kc == 1) ? l4row[1] : (kc == 2) ? l4row[2] : l4row[3];
+    if (owner) my_diag = (kc == 0) ? l00 : (kc == 1) ? l11 : (kc == 2) ? l22 : l33;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double xi[4];
+      solve4(pr[0][r], pr[1][r], pr[2][r], pr[3][r], xi);
+      const double base = owner ? 0.0 : a[r];
+      const double res = fma(xi[3], coef[3], fma(xi[2], coef[2], fma(xi[1], coef[1], fma(xi[0], coef[0], base))));
+      const double in_or_above = owner ? ((r == sidx) ? l4wk : 0.0) : a[r];
+      a[r] = (r > sidx) ? res : in_or_above;
     }
+    if (bad >= 0) { *fail_j = j0 + bad; return false; }      // uniform: identical data in every thread
   }
-  const double sd = sqrt(my_d);
-  *diag_out = sd;
+  *diag_out = my_diag;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = w + 4 * r;
-    if (k < nb) a[r] = (i > k) ? a[r] / sd : ((i == k) ? sd : 0.0);
+    if (k < nb && i < k) a[r] = 0.0;             // strict upper part
   }
   return true;
 }
@@ -135,7 +215,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* Sp = dsm;                       // [64][SPP] factor, columns permuted by perm16
   double* R = dsm + PB * SPP;             // [64][65] panel rows
-  double(*colbuf)[PB] = reinterpret_cast<double(*)[PB]>(dsm + PB * SPP + PB * PBP);
+  double* colbuf = dsm + PB * SPP + PB * PBP;      // [2][4][64] published panel columns
   const int tid = threadIdx.x;
   const int k = tid & 63, w = tid >> 6;
 
@@ -165,7 +245,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
 #pragma unroll
     for (int r = 0; r < 16; ++r) Sp[(w + 4 * r) * SPP + pk] = a[r];
   }
-  double* rdiag = colbuf[0];                       // 1 / L[c][c]  (colbuf is free after factor64)
+  double* rdiag = colbuf;                          // 1 / L[c][c]  (colbuf is free after factor64)
   __syncthreads();                                 // every thread is done reading colbuf
   if (w == 0) rdiag[k] = fast_div(1.0, my_diag, fast_rcp(my_diag));
   // stage this workgroup's 64 panel rows (coalesced along k)
@@ -227,7 +307,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   }
   if (info[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1) info[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
 }
-constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 2 * PB) * 8;
+constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 8 * PB) * 8;
 
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
