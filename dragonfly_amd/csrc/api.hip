@@ -762,8 +762,11 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   double* vec[2] = {nullptr, nullptr};
   DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 2, (void**)&vec[0]));
   DFH_TRY(scratch_get(ctx, SCR_VECB, (size_t)mc_max * 8 * 2, (void**)&vec[1]));
+  // up to 6 blocks of a chunk are factored as one batch (cholesky_device's batch limit)
+  static const int ts_batch = []() { const char* e = getenv("DFH_TS_BATCH"); int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 6 ? 6 : v); }();
+  const int64_t lb_slots = std::max<int64_t>(1, std::min<int64_t>(ts_batch, mc_max / block));
   double* Lb = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)block * block * 8, (void**)&Lb));
+  DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)lb_slots * block * block * 8, (void**)&Lb));
   // Two-stage software pipeline over chunks.  Stage 1 (low-priority `bulk` stream): cross kernel
   // matrix, mu, and the posterior TRSM of chunk c+1 -- large MFMA GEMMs.  Stage 2 (main + panel
   // streams): per TS block of chunk c the covariance SYRK, its stable_cholesky (latency-bound
@@ -826,24 +829,61 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
     hipLaunchKernelGGL(k_add_vec, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, mu_raw, mv_c,
                        mv_c ? 0.0 : mean_const, (long)mc);
     DFH_LAUNCH_CHECK();
-    for (int64_t b0 = 0; b0 < mc; b0 += block, ++blk_idx) {
-      const int64_t B = std::min(block, mc - b0);
-      SectionTimer t(ctx, DFH_T_TS);
-      const double* Vt = Kct + b0 * n;
+    // one TS block: Sigma = K(Xb,Xb) - V^T V (gp_core.py:179-181; chol reads the lower triangle),
+    // stable_cholesky (general_utils.py:229), s = L u + mu (general_utils.py:231)
+    auto sigma_kernel = [&](int64_t b0, int64_t B, double* dst) -> int {
       const double* Xbp = st[p].Xsp + b0 * kd.P;
       const double* Nbp = st[p].Nsp + b0 * kd.n_parts;
+      return kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xbp, Nbp, B, Xbp, Nbp, B, true, 0.0, dst, B);
+    };
+    auto single_block = [&](int64_t b0, int64_t B, double* dst, int64_t bidx) -> int {
+      const double* Vt = Kct + b0 * n;
       auto build_sigma = [&]() -> int {
-        // Sigma = K(Xb,Xb) - V^T V     (gp_core.py:179-181) ; lower triangle is what chol reads
-        DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, Xbp, Nbp, B, Xbp, Nbp, B, true, 0.0, Lb, B));
-        return gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, Lb, B, Lb, B);
+        DFH_TRY(sigma_kernel(b0, B, dst));
+        return gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, dst, B, dst, B);
       };
       DFH_TRY(build_sigma());
       int32_t jp = INT32_MIN;
-      DFH_TRY(stable_cholesky_device(ctx, Lb, B, nullptr, true, build_sigma, &jp, nullptr));   // general_utils.py:229
-      if (jitter_powers_out) jitter_powers_out[blk_idx] = jp;
-      // s = L u + mu        (general_utils.py:231)
+      DFH_TRY(stable_cholesky_device(ctx, dst, B, nullptr, true, build_sigma, &jp, nullptr));
+      if (jitter_powers_out) jitter_powers_out[bidx] = jp;
+      return DFH_OK;
+    };
+    const int64_t nfull = mc / block;
+    for (int64_t g0 = 0; g0 < nfull; g0 += lb_slots) {
+      // the equal-sized blocks of the chunk are factored in lock-step: one batched launch sequence
+      // instead of `nb` latency-bound ones
+      const int nb = (int)std::min<int64_t>(lb_slots, nfull - g0);
+      const int64_t B = block;
+      SectionTimer t(ctx, DFH_T_TS);
+      if (nb == 1) {
+        DFH_TRY(single_block(g0 * B, B, Lb, blk_idx + g0));
+      } else {
+        for (int b = 0; b < nb; ++b) DFH_TRY(sigma_kernel((g0 + b) * B, B, Lb + b * B * B));
+        GemmBatch bs;
+        bs.count = nb; bs.sA = bs.sB = B * n; bs.sCin = bs.sCout = B * B;
+        const double* Vt = Kct + g0 * B * n;
+        DFH_TRY(gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, Lb, B, Lb, B, &bs));
+        int64_t piv[8] = {0};
+        int rc = cholesky_device(ctx, Lb, B, B, nullptr, piv, nb, B * B);
+        if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
+        for (int b = 0; b < nb; ++b) {
+          if (piv[b] == 0) { if (jitter_powers_out) jitter_powers_out[blk_idx + g0 + b] = INT32_MIN; continue; }
+          // this block needs the jitter ladder: redo it alone (rebuilds Sigma first)
+          DFH_TRY(single_block((g0 + b) * B, B, Lb + b * B * B, blk_idx + g0 + b));
+        }
+      }
+      for (int b = 0; b < nb; ++b) {
+        const int64_t b0 = (g0 + b) * B;
+        DFH_TRY(gemv_rows(ctx, Lb + b * B * B, B, B, B, u_c + b0, 1.0, mu_raw + b0, 1.0, samp + b0, true));
+      }
+    }
+    if (nfull * block < mc) {           // ragged last block
+      const int64_t b0 = nfull * block, B = mc - b0;
+      SectionTimer t(ctx, DFH_T_TS);
+      DFH_TRY(single_block(b0, B, Lb, blk_idx + nfull));
       DFH_TRY(gemv_rows(ctx, Lb, B, B, B, u_c + b0, 1.0, mu_raw + b0, 1.0, samp + b0, true));
     }
+    blk_idx += (mc + block - 1) / block;
     DFH_TRY(argmax_update(ctx, samp, mc, i0, &have, &bv, &bi));
     if (samples_out) DFH_TRY(from_device(ctx, samples_out + i0, samp, (size_t)mc * 8));
     DFH_HIP(hipEventRecord(ev_free[p], mainS));

@@ -211,7 +211,13 @@ __device__ __forceinline__ double quad_sum(double v) {
 constexpr int SPP = 66;      // row stride of the column-permuted factor image (16-byte aligned rows)
 __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D, long lda, int nb,
                                                           int rows_below, long pivot_base,
-                                                          long long* info, double* __restrict__ Lout) {
+                                                          long long* info, double* __restrict__ Lout,
+                                                          long strideD, long strideL) {
+  // batch element = blockIdx.y
+  D += (long)blockIdx.y * strideD;
+  Lout += (long)blockIdx.y * strideL;
+  long long* const info_dbg = info;
+  info += blockIdx.y;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* Sp = dsm;                       // [64][SPP] factor, columns permuted by perm16
   double* R = dsm + PB * SPP;             // [64][65] panel rows
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   const bool fok = factor64(a, nb, w, k, colbuf, &fail_j, &my_diag);
   const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-  if (info[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1) { info[2] = (long long)(t1 - t0); info[3] = (long long)(t2 - t1); }
+  if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) { info_dbg[2] = (long long)(t1 - t0); info_dbg[3] = (long long)(t2 - t1); }
   if (!fok) {
     if (blockIdx.x == 0 && tid == 0 && info[0] == 0) info[0] = pivot_base + fail_j + 1;
     return;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     const int i = w + 4 * r;
     if (r0 + i < rows_below && k < nb) Pn[i * lda + k] = R[i * PBP + k];
   }
-  if (info[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1) info[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
+  if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) info_dbg[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
 }
 constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 8 * PB) * 8;
 
@@ -316,8 +322,12 @@ constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 8 * PB) * 8;
 // place on the diagonal of D (upper part zero); Lscr == null: the factor is read from D.
 __global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, long lda, int nbk,
                                                       double* __restrict__ inv, long ldinv,
-                                                      const double* __restrict__ Lscr) {
+                                                      const double* __restrict__ Lscr, long strideD,
+                                                      long strideInv, long strideL) {
   __shared__ double S[PB * PBP];
+  D += (long)blockIdx.y * strideD;
+  inv += (long)blockIdx.y * strideInv;
+  if (Lscr) Lscr += (long)blockIdx.y * strideL;
   const int tid = threadIdx.x;
   const int k = tid & 63, w = tid >> 6;
   const int j0 = blockIdx.x * PB;
@@ -361,13 +371,17 @@ __global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, lo
 // nbk x nbk lower-triangular block D (ld = lda) by recursive doubling:
 //   [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]]
 int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t nbk, double* Linv,
-                           double* T) {
+                           double* T, int nbatch = 1, int64_t strideD = 0, int64_t strideInv = 0,
+                           int64_t strideT = 0) {
   const int64_t NB = CHOL_NB;
   for (int64_t s = PB; s < nbk; s *= 2) {
     const int64_t full_pairs = nbk / (2 * s);
     if (full_pairs > 0) {
       GemmBatch b1, b2;
       b1.count = b2.count = (int)full_pairs;
+      b1.count2 = b2.count2 = nbatch;
+      b1.sA2 = strideD; b1.sB2 = strideInv; b1.sCout2 = strideT;
+      b2.sA2 = strideInv; b2.sB2 = strideT; b2.sCout2 = strideInv;
       // T_q = B_q * A_q^-1 : B_q = D[hi rows, lo cols], A_q^-1 = Linv[lo, lo]
       b1.sA = 2 * s * (lda + 1); b1.sB = 2 * s * (NB + 1); b1.sCout = s * s;
       DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, s, s, s, 1.0, D + s * lda, lda, Linv, NB, 0.0, nullptr, 0,
@@ -380,10 +394,14 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
     const int64_t lo = full_pairs * 2 * s, hi = lo + s;
     if (hi < nbk) {                                   // trailing partial pair
       const int64_t hs = nbk - hi;
+      GemmBatch c1, c2;
+      c1.count = c2.count = nbatch;
+      c1.sA = strideD; c1.sB = strideInv; c1.sCout = strideT;
+      c2.sA = strideInv; c2.sB = strideT; c2.sCout = strideInv;
       DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, hs, s, s, 1.0, D + hi * lda + lo, lda, Linv + lo * (NB + 1),
-                       NB, 0.0, nullptr, 0, T, s));
+                       NB, 0.0, nullptr, 0, T, s, &c1));
       DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, hs, s, hs, -1.0, Linv + hi * (NB + 1), NB, T, s, 0.0,
-                       nullptr, 0, Linv + hi * NB + lo, NB));
+                       nullptr, 0, Linv + hi * NB + lo, NB, &c2));
     }
   }
 
@@ -401,21 +419,27 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
 // latency-bound diagonal work leaves the critical path while the trailing update is long enough
 // to cover it.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot) {
-  if (info_pivot) *info_pivot = 0;
+                    int64_t* info_pivot, int nbatch, int64_t strideA) {
+  DFH_ARG(nbatch >= 1 && nbatch <= 6 && (nbatch == 1 || keep_inv == nullptr));
+  if (info_pivot) for (int b = 0; b < nbatch; ++b) info_pivot[b] = 0;
   if (n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
   long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
   hipStream_t M = ctx->stream, P = ctx->side;
-  DFH_HIP(hipMemsetAsync(d_info, 0, 8, M));
+  DFH_HIP(hipMemsetAsync(d_info, 0, 8 * (size_t)nbatch, M));
 
+  const int64_t strideInv = NB * NB;
+  const int64_t strideT = NB * NB + (NB / PB) * PB * PB;
+  const int64_t strideW = (n > NB) ? (n - NB) * NB : 0;
   double* inv_scratch = nullptr;
-  if (!keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)NB * NB * 8, (void**)&inv_scratch));
+  if (!keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * strideInv * 8, (void**)&inv_scratch));
   double* T = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)(NB * NB + (NB / PB) * PB * PB) * 8, (void**)&T));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
   double* Lscr = T + NB * NB;                 // factors of the pivot blocks of the current panel
   double* W = nullptr;
-  if (n > NB) DFH_TRY(scratch_get(ctx, SCR_CHOLW, (size_t)(n - NB) * NB * 8, (void**)&W));
+  if (n > NB) DFH_TRY(scratch_get(ctx, SCR_CHOLW, (size_t)nbatch * strideW * 8, (void**)&W));
+  GemmBatch bA;                               // every operand inside the batch matrices
+  bA.count = nbatch; bA.sA = bA.sB = bA.sCin = bA.sCout = strideA;
 
   static bool attr_set = false;
   if (!attr_set) {
@@ -443,36 +467,41 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 2 * (kb - 1), &e_trail_prev));
     {
       StreamSwap on_p(ctx, P);
-      DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, P));
+      DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)nbatch * strideInv * 8, P));
       // ---- factor the diagonal block with 64-wide steps -----------------------------------
       for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
         const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
         double* Djj = D + j0 * lda + j0;
         const int64_t rows = nbk - j0 - w;
         const unsigned nwg = 1 + (unsigned)((rows + PB - 1) / PB);
-        hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, P, Djj, (long)lda, w,
-                           (int)rows, (long)(k0 + j0), d_info, Lscr + (j0 / PB) * PB * PB);
+        hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg, (unsigned)nbatch), dim3(256), DIAG_STEP_SMEM, P, Djj,
+                           (long)lda, w, (int)rows, (long)(k0 + j0), d_info, Lscr + (j0 / PB) * PB * PB,
+                           (long)strideA, (long)strideT);
         DFH_LAUNCH_CHECK();
         if (rows > 0) {
           double* Pn = D + (j0 + w) * lda + j0;                      // rows x w, already solved
           double* D22 = D + (j0 + w) * lda + (j0 + w);
-          DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rows, rows, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda));
+          DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rows, rows, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda, &bA));
         }
       }
-      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, P, D, (long)lda,
-                         (int)nbk, Linv, (long)NB, Lscr);
+      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, P,
+                         D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
+                         (long)strideT);
       DFH_LAUNCH_CHECK();
-      DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T));
+      DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
       // ---- panel solve, then the next block column --------------------------------------
       if (rem > 0) {
         double* A21 = A + (k0 + nbk) * lda + k0;          // rem x nbk
-        DFH_TRY(copy_matrix(ctx, A21, lda, W, NB, rem, nbk));
-        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, rem, nbk, nbk, 1.0, W, NB, Linv, NB, 0.0, nullptr, 0, A21, lda));
+        for (int b = 0; b < nbatch; ++b)
+          DFH_TRY(copy_matrix(ctx, A21 + b * strideA, lda, W + b * strideW, NB, rem, nbk));
+        GemmBatch bt;
+        bt.count = nbatch; bt.sA = strideW; bt.sB = strideInv; bt.sCout = strideA;
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, rem, nbk, nbk, 1.0, W, NB, Linv, NB, 0.0, nullptr, 0, A21, lda, &bt));
         DFH_HIP(hipEventRecord(e_trsm, P));
         if (e_trail_prev) DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
         const int64_t nb1 = rem < NB ? rem : NB;
         double* C1 = A + (k0 + nbk) * lda + (k0 + nbk);   // rows k+1.., block column k+1
-        DFH_TRY(gemm_f64(ctx, 0, rem, nb1, nbk, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda));
+        DFH_TRY(gemm_f64(ctx, 0, rem, nb1, nbk, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
       }
     }
     if (rem > NB) {
@@ -480,7 +509,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       const double* A31 = A + (k0 + nbk + NB) * lda + k0;                // rows k+2.. of the panel
       double* A33 = A + (k0 + nbk + NB) * lda + (k0 + nbk + NB);
       DFH_HIP(hipStreamWaitEvent(M, e_trsm, 0));
-      DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rem2, rem2, nbk, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda));
+      DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rem2, rem2, nbk, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda, &bA));
       DFH_HIP(hipEventRecord(e_trail, M));
     } else {
       // nothing for M to do: keep the event chain well-formed for the next panel's wait
@@ -490,15 +519,18 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   DFH_HIP(hipEventRecord(ev_done, P));
   DFH_HIP(hipStreamWaitEvent(M, ev_done, 0));
 
-  DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8, hipMemcpyDeviceToHost, M));
+  DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8 * (size_t)nbatch, hipMemcpyDeviceToHost, M));
   DFH_HIP(hipStreamSynchronize(M));
-  const int64_t piv = ctx->h_info[0];
-  if (info_pivot) *info_pivot = piv;
-  if (piv != 0) {
-    dfh_set_error("Matrix is not positive definite (pivot %lld)", (long long)piv);
-    return DFH_ERR_NOT_PD;
+  int rc = DFH_OK;
+  for (int b = 0; b < nbatch; ++b) {
+    const int64_t piv = ctx->h_info[b];
+    if (info_pivot) info_pivot[b] = piv;
+    if (piv != 0 && rc == DFH_OK) {
+      dfh_set_error("Matrix is not positive definite (pivot %lld)", (long long)piv);
+      rc = DFH_ERR_NOT_PD;
+    }
   }
-  return DFH_OK;
+  return rc;
 }
 
 // Right-looking block substitution: once x_i is final it is pushed into every remaining row
@@ -567,7 +599,7 @@ int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, do
     DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, ctx->stream));
     const double* D = L + k0 * ldl + k0;
     hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, ctx->stream,
-                       const_cast<double*>(D), (long)ldl, (int)nbk, Linv, (long)NB, (const double*)nullptr);
+                       const_cast<double*>(D), (long)ldl, (int)nbk, Linv, (long)NB, (const double*)nullptr, 0L, 0L, 0L);
     DFH_LAUNCH_CHECK();
     DFH_TRY(assemble_block_inverse(ctx, D, ldl, nbk, Linv, T));
   }
@@ -620,7 +652,7 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   for (int r = 0; r < reps; ++r) {
     // the block is re-factored from its own output (still SPD: L has a dominant diagonal)
     hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, ctx->stream, A, (long)nn, 64,
-                       rows_below, 0L, d_info, A + 256 * nn);
+                       rows_below, 0L, d_info, A + 256 * nn, 0L, 0L);
   }
   DFH_HIP(hipEventRecord(e1, ctx->stream));
   DFH_HIP(hipEventSynchronize(e1));

@@ -131,7 +131,11 @@ struct SectionTimer {
 #define GEMM_KTRI_B  2   // B is [N x K] lower triangular (B[j][k]=0 for k>j): clip k-range
 #define GEMM_TRANSB  4   // B is [K x N]
 
-struct GemmBatch { int count = 1; int64_t sA = 0, sB = 0, sCin = 0, sCout = 0; };
+// Two-level batch: blockIdx.z = b2 * count + b1 ; operand offset = b1 * s? + b2 * s?2
+struct GemmBatch {
+  int count = 1; int64_t sA = 0, sB = 0, sCin = 0, sCout = 0;
+  int count2 = 1; int64_t sA2 = 0, sB2 = 0, sCin2 = 0, sCout2 = 0;
+};
 
 // Cout = beta*Cin + alpha * A * op(B).  Cin may equal Cout.  Cin may be null iff beta == 0.
 int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double alpha,
@@ -194,8 +198,11 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
 // block b at keep_inv + b*CHOL_NB*CHOL_NB, row-major with ld = CHOL_NB, zero upper part.
 // *info_pivot = 0 on success, else the 1-based index of the first non-positive pivot.
 constexpr int64_t CHOL_NB = 512;
+// nbatch > 1: nbatch independent matrices of the same size at A + b*strideA are factored in lock
+// step (one launch sequence, every kernel batched): the latency-bound pivot chain is paid once.
+// keep_inv is only supported for nbatch == 1; info_pivot has nbatch entries (<= 6).
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot);
+                    int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0);
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x

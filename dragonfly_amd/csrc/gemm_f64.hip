@@ -43,10 +43,11 @@ template <int WT> struct Geo {
 
 struct GemmArgs {
   int M, N, K;
-  const double* A; long lda; long sA;
-  const double* B; long ldb; long sB;
-  const double* Cin; long ldcin; long sCin;
-  double* Cout; long ldc; long sCout;
+  const double* A; long lda; long sA; long sA2;
+  const double* B; long ldb; long sB; long sB2;
+  const double* Cin; long ldcin; long sCin; long sCin2;
+  double* Cout; long ldc; long sCout; long sCout2;
+  int cnt1;
   double alpha, beta;
   int flags;
   int tiles_m, tiles_n;
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const long bz = blockIdx.z;
-  const double* __restrict__ A = p.A + bz * p.sA;
-  const double* __restrict__ B = p.B + bz * p.sB;
+  const long bz1 = blockIdx.z % p.cnt1, bz2 = blockIdx.z / p.cnt1;
+  const double* __restrict__ A = p.A + bz1 * p.sA + bz2 * p.sA2;
+  const double* __restrict__ B = p.B + bz1 * p.sB + bz2 * p.sB2;
 
   int kend = p.K;
   if (p.flags & GEMM_KTRI_B) kend = min(p.K, n0 + BN);   // B[j][k] = 0 for k > j
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
   // C enters through the accumulators when alpha = +-1 (the SYRK / TRSM-update case): the tile of
   // beta*C is loaded at kernel entry, in flight together with the first operand chunk, instead of
   // being read -- one exposed HBM round trip per tile -- in the epilogue.  out = alpha * acc.
-  const double* __restrict__ Cin0 = p.Cin ? p.Cin + bz * p.sCin : nullptr;
+  const double* __restrict__ Cin0 = p.Cin ? p.Cin + bz1 * p.sCin + bz2 * p.sCin2 : nullptr;
   const bool c_in_acc = (Cin0 != nullptr) && (p.alpha == 1.0 || p.alpha == -1.0);
   double4_t acc[WT][WT];
   if (c_in_acc) {
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 
   // epilogue
   const double alpha = p.alpha, beta = p.beta;
-  const double* __restrict__ Cin = p.Cin ? p.Cin + bz * p.sCin : nullptr;
-  double* __restrict__ Cout = p.Cout + bz * p.sCout;
+  const double* __restrict__ Cin = Cin0;
+  double* __restrict__ Cout = p.Cout + bz1 * p.sCout + bz2 * p.sCout2;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -354,12 +355,18 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
   p.Cin = (beta == 0.0) ? nullptr : Cin; p.ldcin = ldcin; p.Cout = Cout; p.ldc = ldc;
   p.sA = p.sB = p.sCin = p.sCout = 0;
+  p.sA2 = p.sB2 = p.sCin2 = p.sCout2 = 0;
+  p.cnt1 = 1;
   int count = 1;
-  if (batch) { count = batch->count; p.sA = batch->sA; p.sB = batch->sB; p.sCin = batch->sCin; p.sCout = batch->sCout; }
+  if (batch) {
+    p.cnt1 = batch->count; count = batch->count * batch->count2;
+    p.sA = batch->sA; p.sB = batch->sB; p.sCin = batch->sCin; p.sCout = batch->sCout;
+    p.sA2 = batch->sA2; p.sB2 = batch->sB2; p.sCin2 = batch->sCin2; p.sCout2 = batch->sCout2;
+  }
   p.alpha = alpha; p.beta = beta; p.flags = flags;
   auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool edge = (K % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B) ||
-                    ((p.sA | p.sB) & 1);
+                    ((p.sA | p.sB | p.sA2 | p.sB2) & 1);
   // Small problems are latency-bound on a single 128x128 tile per CU: use 64x64 tiles when the
   // 128-tiling would leave most of the 256 CUs idle.
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * (long)count;
