@@ -772,7 +772,7 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   // streams): per TS block of chunk c the covariance SYRK, its stable_cholesky (latency-bound
   // look-ahead factorisation, host-synchronous because of the jitter ladder) and the draw.
   // The factorisations hide behind the next chunk's TRSM instead of idling the GPU.
-  static const bool ts_half_occ = []() { const char* e = getenv("DFH_TS_HALF_OCC"); return e ? atoi(e) != 0 : true; }();
+  static const bool ts_half_occ = []() { const char* e = getenv("DFH_TS_HALF_OCC"); return e ? atoi(e) != 0 : false; }();
   hipStream_t mainS = ctx->stream, bulkS = ctx->bulk;
   struct Stage1 { double* Kct; double* Xsp; double* Nsp; double* mu; };
   Stage1 st[2];
@@ -790,8 +790,10 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
     const int64_t i0 = c * mc_max;
     const int64_t mc = std::min(mc_max, m - i0);
     StreamSwap on_bulk(ctx, bulkS);
-    // one workgroup per CU for the bulk GEMMs: the other half of each CU stays free for the
-    // latency-bound factorisation kernels of stage 2 (which otherwise queue behind full CUs)
+    // DFH_TS_HALF_OCC=1: one workgroup per CU for the bulk GEMMs so the other half of each CU stays
+    // free for the latency-bound factorisation kernels of stage 2.  Off by default: with the blocks
+    // of a chunk factored as one batch the latency-bound share is small and the ~14% the bulk GEMMs
+    // lose at half occupancy costs more than the overlap returns (measured 1602 vs 1495 ms/step).
     struct HalfOcc { dfh_ctx* c; bool old; HalfOcc(dfh_ctx* x, bool v) : c(x), old(x->gemm_half_occupancy) { c->gemm_half_occupancy = v; }
                      ~HalfOcc() { c->gemm_half_occupancy = old; } } half(ctx, nchunks > 1 && ts_half_occ);
     if (c >= 2) DFH_HIP(hipStreamWaitEvent(bulkS, ev_free[p], 0));   // parity buffers released by stage 2

@@ -1,0 +1,87 @@
+"""MI355X, BASELINE.json configs 2 and 5 at their full sizes: the fit is
+checked against the oracle on the full training set, the candidate stage against the oracle on a
+sub-sample of the candidates plus the chunk-invariance of the device arg-max over all of them."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def hartmann6(X):
+  """ Hartmann-6 on the unit cube, the usual constants (the reference defines the same function in
+      exd/../euclidean_synthetic_functions.py:16-49); only used to produce O(1) synthetic targets. """
+  A = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14],
+                [3, 3.5, 1.7, 10, 17, 8], [17, 8, 0.05, 10, 0.1, 14]], dtype=float)
+  P = 1e-4 * np.array([[1312, 1696, 5569, 124, 8283, 5886], [2329, 4135, 8307, 3736, 1004, 9991],
+                       [2348, 1451, 3522, 2883, 3047, 6650], [4047, 8828, 8732, 5743, 1091, 381]], dtype=float)
+  alpha = np.array([1.0, 1.2, 3.0, 3.2])
+  inner = (A[None, :, :] * (X[:, None, :] - P[None, :, :]) ** 2).sum(axis=2)
+  return (alpha[None, :] * np.exp(-inner)).sum(axis=1)
+
+
+def park1(X4):
+  """ Park function 1 on [0,1]^4 (synthetic targets for the additive config). """
+  x1, x2, x3, x4 = [np.maximum(X4[:, i], 1e-6) for i in range(4)]
+  return -((x1 / 2) * (np.sqrt(1 + (x2 + x3 ** 2) * x4 / x1 ** 2) - 1) + (x1 + 3 * x4) * np.exp(1 + np.sin(x3)))
+
+
+def test_config2_hartmann6_matern_ei_full_size(engine):
+  from dragonfly_amd.engine import KernelSpec
+  n, d, m = 4096, 6, 65536
+  X = np.random.RandomState(102).random_sample((n, d))
+  Y = hartmann6(X)
+  scale, bw = float(Y.var()), 0.5 * np.ones(d)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 20)
+  spec = KernelSpec('matern', d, scale, bw, nu=2.5)
+  ospec = O.KernelSpec('matern', d, scale, bw, nu=2.5)
+  og = O.GPOracle(X, Y, ospec, mean_c, noise)
+  gp = engine.gp_fit(spec, X, Y - mean_c, noise)
+  assert gp.jitter_power is None
+  assert relerr(gp.get_alpha(), og.alpha) < TOL
+  assert abs(gp.lml - og.lml()) <= TOL * abs(og.lml())
+  Xs = np.random.RandomState(202).random_sample((m, d))
+  best = float(Y.max())
+  bv, bi, vals = gp.acq_argmax('ei', Xs, params=(best, 0.0), mean_const=mean_c, return_vals=True)
+  # oracle on the first 4096 candidates, on a stride through all of them, and around the winner
+  for sel in (np.arange(4096), np.arange(0, m, 16), np.arange(max(0, bi - 2048), min(m, bi + 2048))):
+    mur, sdr = og.eval_chunked(Xs[sel], chunk=2048)
+    vr = O.acq_values('ei', mur, sdr, best, 0.0)
+    assert relerr(vals[sel], vr) < 1e-9
+    assert int(np.argmax(vals[sel])) == O.argmax_first(vr)[1]
+  assert bi == int(np.argmax(vals)) and bv == vals[bi]
+  # the device arg-max does not depend on how the candidates are chunked / sharded
+  parts = [gp.acq_argmax('ei', Xs[lo:lo + 16384], params=(best, 0.0), mean_const=mean_c) for lo in range(0, m, 16384)]
+  k = int(np.argmax([p[0] for p in parts]))
+  assert parts[k][0] == bv and parts[k][1] + 16384 * k == bi
+
+
+def test_config5_additive_d100_add_ucb_full_size(engine):
+  from dragonfly_amd.engine import KernelSpec
+  n, d, G = 4096, 100, 20
+  X = np.random.RandomState(105).random_sample((n, d))
+  Y = sum(park1(X[:, 4 * i:4 * i + 4]) for i in range(25))          # 'park1-100': 25 tiles of Park1
+  perm = list(np.random.RandomState(405).permutation(d))
+  groups = [perm[i:i + 5] for i in range(0, d, 5)]                   # euclidean_gp.py:733-735
+  bws = [0.2 * np.sqrt(5) * np.ones(5) for _ in groups]
+  scale = float(Y.var())
+  noise = float(Y.var() / 20)
+  mean_c = float(np.median(Y))
+  spec = KernelSpec('additive', d, scale, groups=groups, sub_kinds=['se'] * G, sub_scales=[1.0] * G,
+                    sub_nus=[0.0] * G, sub_bandwidths=bws)
+  ospec = O.KernelSpec('additive', d, scale, groups=groups,
+                       subs=[O.KernelSpec('se', 5, 1.0, b) for b in bws])
+  og = O.GPOracle(X, Y, ospec, mean_c, noise)
+  gp = engine.gp_fit(spec, X, Y - mean_c, noise)
+  assert relerr(gp.get_alpha(), og.alpha) < TOL
+  assert abs(gp.lml - og.lml()) <= TOL * abs(og.lml())
+  m_j = 65536 // G
+  for j in (0, 7, 19):
+    Xj = np.random.RandomState(205 + j).random_sample((m_j, 5))
+    beta = O.add_ucb_beta_th(5, n)
+    bv, bi, vals = gp.add_ucb_group(j, beta, Xj, return_vals=True)
+    vr = O.add_ucb_group_values(og, j, Xj, n)
+    assert relerr(vals, vr) < 1e-9 and bi == int(np.argmax(vr))
