@@ -69,6 +69,7 @@ struct dfh_ctx {
   struct GemmRec { hipEvent_t e0, e1; double flops; int variant; };
   std::vector<GemmRec> gemm_recs;
   size_t gemm_used = 0;
+  hipEvent_t gemm_base = nullptr;   // time origin of the per-launch intervals
 };
 
 enum ScratchSlot {

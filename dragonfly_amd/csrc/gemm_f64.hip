@@ -21,6 +21,8 @@
 //   B operand : lane l holds B[k = l>>4][j = l&15]
 //   C/D       : reg r of lane l holds D[i = (l>>4) + 4r][j = l&15]
 #include "common.h"
+#include <algorithm>
+#include <utility>
 
 namespace {
 
@@ -375,25 +377,48 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
 }
 
 // Enable / disable per-launch event timing of the GEMM kernel and fetch the totals.
-// stats_out[8][3]: per kernel variant (bit2 = NN, bit1 = edge path, bit0 = 64x64 tiles; variant 0
-// is the 128x128 NT throughput configuration) {launches, total ms, algorithmic flop}.
+// stats_out[8][4]: per kernel variant (bit2 = NN, bit1 = edge path, bit0 = 64x64 tiles; variant 0
+// is the 128x128 NT throughput configuration) {launches, sum of launch durations in ms,
+// algorithmic flop, busy ms}.  `busy` is the length of the union of the variant's launch
+// intervals: launches on different streams overlap (look-ahead Cholesky, TS pipeline) and then
+// share the CUs, so the plain sum counts that wall-clock more than once.
 extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out) {
   DFH_ARG(ctx != nullptr);
   if (stats_out) {
-    for (int i = 0; i < 24; ++i) stats_out[i] = 0.0;
+    for (int i = 0; i < 32; ++i) stats_out[i] = 0.0;
     DFH_HIP(hipStreamSynchronize(ctx->main_stream));
     DFH_HIP(hipStreamSynchronize(ctx->side));
     DFH_HIP(hipStreamSynchronize(ctx->bulk));
+    std::vector<std::pair<float, float>> iv[8];
     for (size_t i = 0; i < ctx->gemm_used; ++i) {
-      float ms = 0.f;
-      DFH_HIP(hipEventElapsedTime(&ms, ctx->gemm_recs[i].e0, ctx->gemm_recs[i].e1));
-      const int v = ctx->gemm_recs[i].variant;
-      stats_out[v * 3 + 0] += 1.0;
-      stats_out[v * 3 + 1] += (double)ms;
-      stats_out[v * 3 + 2] += ctx->gemm_recs[i].flops;
+      float ms = 0.f, t0 = 0.f;
+      const dfh_ctx::GemmRec& r = ctx->gemm_recs[i];
+      DFH_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+      if (ctx->gemm_base) DFH_HIP(hipEventElapsedTime(&t0, ctx->gemm_base, r.e0));
+      const int v = r.variant;
+      stats_out[v * 4 + 0] += 1.0;
+      stats_out[v * 4 + 1] += (double)ms;
+      stats_out[v * 4 + 2] += r.flops;
+      iv[v].emplace_back(t0, t0 + ms);
+    }
+    for (int v = 0; v < 8; ++v) {
+      std::sort(iv[v].begin(), iv[v].end());
+      double busy = 0.0; float hi = -1e30f;
+      for (const auto& x : iv[v]) {
+        if (x.first >= hi) { busy += x.second - x.first; hi = x.second; }
+        else if (x.second > hi) { busy += x.second - hi; hi = x.second; }
+      }
+      stats_out[v * 4 + 3] = busy;
     }
   }
   ctx->gemm_used = 0;
   ctx->gemm_prof = enable != 0;
+  if (ctx->gemm_prof) {
+    if (!ctx->gemm_base) DFH_HIP(hipEventCreate(&ctx->gemm_base));
+    DFH_HIP(hipStreamSynchronize(ctx->main_stream));
+    DFH_HIP(hipStreamSynchronize(ctx->side));
+    DFH_HIP(hipStreamSynchronize(ctx->bulk));
+    DFH_HIP(hipEventRecord(ctx->gemm_base, ctx->main_stream));
+  }
   return DFH_OK;
 }

@@ -187,10 +187,11 @@ class Engine(object):
     return dict(zip(_lib.T_NAMES, list(arr)))
 
   def gemm_profile(self, enable=True, fetch=True):
-    """ Per-variant {launches, ms, flop} of the GEMM kernel since the last call (HIP events). """
-    arr = (C.c_double * 24)()
+    """ Per-variant {launches, ms (sum of launch durations), flop, busy_ms (union of the launch
+        intervals)} of the GEMM kernel since the last call (HIP events). """
+    arr = (C.c_double * 32)()
     check(self.lib.dfh_ctx_gemm_profile(self.ctx, 1 if enable else 0, arr if fetch else None))
-    return [dict(launches=int(arr[3 * v]), ms=arr[3 * v + 1], flop=arr[3 * v + 2]) for v in range(8)]
+    return [dict(launches=int(arr[4 * v]), ms=arr[4 * v + 1], flop=arr[4 * v + 2], busy_ms=arr[4 * v + 3]) for v in range(8)]
 
   # -- building blocks ---------------------------------------------------------------------
   def kernel_matrix(self, spec, X1, X2=None, diag_add=0.0, out=None):

@@ -213,7 +213,7 @@ int dfh_ctx_timings(dfh_ctx* ctx, int enable, double* ms_out /* [DFH_T_COUNT] or
  * stats_out[8][3] = per kernel variant {launches, total ms, algorithmic flop}; variant index =
  * 4*(B is [K x N]) + 2*(edge path) + (64x64 tiles), so variant 0 is the 128x128 NT throughput
  * configuration.  stats_out may be NULL.  Then enables (1) / disables (0) further recording.   */
-int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out /* [24] or NULL */);
+int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out /* [32] or NULL */);
 
 #ifdef __cplusplus
 }

@@ -29,3 +29,14 @@ for _ in range(2):
   eng.gemm(A2, B2, shape=(M, M, M), out=C2)
 eng.sync()
 print('pmc workload done')
+# FETCH_SIZE calibration in the GEMM's own load pattern (16 B per lane): A [32768 x 16384] is read
+# exactly once from HBM (4.295 GB, well past the 256 MB Infinity Cache), B [128 x 16384] (16.8 MB)
+# stays cache-resident, C is 33.5 MB.
+M, N, K = 32768, 128, 16384
+A3 = eng.empty((M, K))
+B3 = eng.to_device(rs.rand(N, K) - 0.5)
+C3 = eng.empty((M, N))
+for _ in range(2):
+  eng.gemm(A3, B3, shape=(M, N, K), out=C3)
+eng.sync()
+print('pmc calibration gemm done')

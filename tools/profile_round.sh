@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round profile on the MI355X box (run through gpurun from the repo root):
+#   kernel trace + stats of bench.py, PMC passes over tools/pmc_workload.py and over bench.py.
+# Outputs rocpd databases under gpurun_out/prof/; summarise locally with tools/rocpd_*.py.
+set -u
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python $REPO/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B --steps 2 --warmup 1 > $OUT/trace.log 2>&1
+tail -1 $OUT/trace.log | cut -c1-2000 > $OUT/bench_under_trace.json
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/wl_$tag -o wl -- python $REPO/tools/pmc_workload.py > $OUT/wl_$tag.log 2>&1
+done
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/bench_$set -o bench -- $B --steps 1 --warmup 0 > $OUT/bench_$set.log 2>&1
+done
+find $OUT -name '*.db' -size +40M -delete
+ls -la $OUT $OUT/*/ 2>/dev/null | head -60
