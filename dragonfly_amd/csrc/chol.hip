@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   // batch element = blockIdx.y
   D += (long)blockIdx.y * strideD;
   Lout += (long)blockIdx.y * strideL;
-  long long* const info_dbg = info;
+  long long* const info_dbg = info + CHOL_MAX_BATCH;   // debug words follow the pivot flags
   info += blockIdx.y;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* Sp = dsm;                       // [64][SPP] factor, columns permuted by perm16
@@ -419,8 +419,8 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
 // latency-bound diagonal work leaves the critical path while the trailing update is long enough
 // to cover it.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot, int nbatch, int64_t strideA) {
-  DFH_ARG(nbatch >= 1 && nbatch <= 6 && (nbatch == 1 || keep_inv == nullptr));
+                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep) {
+  DFH_ARG(nbatch >= 1 && nbatch <= CHOL_MAX_BATCH);
   if (info_pivot) for (int b = 0; b < nbatch; ++b) info_pivot[b] = 0;
   if (n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
@@ -428,7 +428,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   hipStream_t M = ctx->stream, P = ctx->side;
   DFH_HIP(hipMemsetAsync(d_info, 0, 8 * (size_t)nbatch, M));
 
-  const int64_t strideInv = NB * NB;
+  const int64_t strideInv = keep_inv ? strideKeep : NB * NB;   // between the batch matrices' inverse blocks
   const int64_t strideT = NB * NB + (NB / PB) * PB * PB;
   const int64_t strideW = (n > NB) ? (n - NB) * NB : 0;
   double* inv_scratch = nullptr;
@@ -467,7 +467,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 2 * (kb - 1), &e_trail_prev));
     {
       StreamSwap on_p(ctx, P);
-      DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)nbatch * strideInv * 8, P));
+      for (int b = 0; b < nbatch; ++b) DFH_HIP(hipMemsetAsync(Linv + b * strideInv, 0, (size_t)NB * NB * 8, P));
       // ---- factor the diagonal block with 64-wide steps -----------------------------------
       for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
         const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
@@ -642,7 +642,7 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   DFH_HIP(hipMemcpyAsync(A, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
   long long init[8] = {0, 0, 0, 0, 0, 0, 0, 1};
-  DFH_HIP(hipMemcpyAsync(d_info, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(d_info + CHOL_MAX_BATCH, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
   DFH_HIP(hipStreamSynchronize(ctx->stream));
   const unsigned nwg = 1 + (unsigned)((rows_below + PB - 1) / PB);
   hipEvent_t e0, e1;
@@ -659,11 +659,11 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   float ms = 0.f;
   DFH_HIP(hipEventElapsedTime(&ms, e0, e1));
   long long out[8];
-  DFH_HIP(hipMemcpy(out, d_info, sizeof(out), hipMemcpyDeviceToHost));
+  DFH_HIP(hipMemcpy(out, d_info + CHOL_MAX_BATCH, sizeof(out), hipMemcpyDeviceToHost));
   if (ms_per_launch) *ms_per_launch = ms / reps;
   if (cycles_out) { cycles_out[0] = out[2]; cycles_out[1] = out[3]; cycles_out[2] = out[4]; }
   long long zero[8] = {0};
-  DFH_HIP(hipMemcpy(d_info, zero, sizeof(zero), hipMemcpyHostToDevice));
+  DFH_HIP(hipMemcpy(d_info + CHOL_MAX_BATCH, zero, sizeof(zero), hipMemcpyHostToDevice));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return DFH_OK;
 }

@@ -43,6 +43,9 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// matrices factored in lock-step by one batched cholesky_device call (one pivot flag each)
+constexpr int CHOL_MAX_BATCH = 64;
+
 struct dfh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // every kernel is launched on this stream ...
@@ -53,7 +56,7 @@ struct dfh_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
   std::vector<DevBuf> scratch;
-  int64_t* d_info = nullptr;                         // device int64[8] status words
+  int64_t* d_info = nullptr;                         // device int64[CHOL_MAX_BATCH + 8]: pivot flag per batch matrix, then debug words
   int64_t* h_info = nullptr;                         // pinned mirror
   // section timing
   bool timing = false;
@@ -173,9 +176,15 @@ struct KernDev {
   int* d_cols = nullptr;
   int* d_lcols = nullptr;
   double* d_bw = nullptr;
+  void* d_blob = nullptr;      // the one device allocation behind the four pointers (owned if set)
   double kxx = 0.0;            // prior variance k(x,x)
 };
 int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* out);
+// host-only part of kerndev_build, and the upload of several descriptors with one copy into a
+// caller-provided device blob (kerndev_blob_bytes each, in order); such KernDevs own no memory
+int kerndev_build_host(const dfh_kernel_desc* k, KernDev* out);
+size_t kerndev_blob_bytes(const KernDev& kd);
+int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, size_t blob_bytes);
 int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* out);
 void kerndev_free(KernDev* kd);
 double kerndev_part_kxx(const KernDev& kd, int part);
@@ -203,7 +212,7 @@ constexpr int64_t CHOL_NB = 512;
 // step (one launch sequence, every kernel batched): the latency-bound pivot chain is paid once.
 // keep_inv is only supported for nbatch == 1; info_pivot has nbatch entries (<= 6).
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0);
+                    int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0, int64_t strideKeep = 0);
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x
@@ -240,5 +249,7 @@ int gemv_cols(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, 
 // out[m] = sum_j A[i][j]^2
 int row_sumsq(dfh_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, double* out);
 // host result: sum(log(diag(L))) and dot(a,b)
+int logdet_and_dot_device(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* a,
+                          const double* b, double* d_out2);
 int logdet_and_dot(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* a,
                    const double* b, double* host_logdet, double* host_dot);

@@ -15,6 +15,7 @@
 // only HBM traffic is the coalesced write of K (the pass is HBM-write bound:
 // 8*(n1*n2 + (n1+n2)*d) algorithmic bytes).
 #include "common.h"
+#include <cstring>
 #include <math.h>
 #include <stdlib.h>
 
@@ -459,15 +460,41 @@ double part_value_at_zero(const PartDev& pd) {
   return 0.0;
 }
 
+// device image of a KernDev: [parts | bw | cols | lcols], each section 16-byte aligned
+static size_t pad16(size_t x) { return (x + 15) & ~(size_t)15; }
+static void blob_layout(const KernDev& kd, size_t off[4], size_t* total) {
+  const size_t P = kd.P ? kd.P : 1;
+  off[0] = 0;
+  off[1] = off[0] + pad16(sizeof(PartDev) * kd.parts.size());
+  off[2] = off[1] + pad16(sizeof(double) * P);
+  off[3] = off[2] + pad16(sizeof(int) * P);
+  *total = off[3] + pad16(sizeof(int) * P);
+}
+static void blob_fill(const KernDev& kd, char* host) {
+  size_t off[4], total;
+  blob_layout(kd, off, &total);
+  std::memcpy(host + off[0], kd.parts.data(), sizeof(PartDev) * kd.parts.size());
+  std::memcpy(host + off[1], kd.bw.data(), sizeof(double) * kd.P);
+  std::memcpy(host + off[2], kd.cols.data(), sizeof(int) * kd.P);
+  std::memcpy(host + off[3], kd.lcols.data(), sizeof(int) * kd.P);
+}
+static void blob_point(KernDev* kd, char* dev) {
+  size_t off[4], total;
+  blob_layout(*kd, off, &total);
+  kd->d_parts = reinterpret_cast<PartDev*>(dev + off[0]);
+  kd->d_bw = reinterpret_cast<double*>(dev + off[1]);
+  kd->d_cols = reinterpret_cast<int*>(dev + off[2]);
+  kd->d_lcols = reinterpret_cast<int*>(dev + off[3]);
+}
+
 int upload(dfh_ctx* ctx, KernDev* kd) {
-  DFH_HIP(hipMalloc(&kd->d_parts, sizeof(PartDev) * kd->parts.size()));
-  DFH_HIP(hipMalloc(&kd->d_cols, sizeof(int) * (kd->P ? kd->P : 1)));
-  DFH_HIP(hipMalloc(&kd->d_lcols, sizeof(int) * (kd->P ? kd->P : 1)));
-  DFH_HIP(hipMalloc(&kd->d_bw, sizeof(double) * (kd->P ? kd->P : 1)));
-  DFH_HIP(hipMemcpyAsync(kd->d_parts, kd->parts.data(), sizeof(PartDev) * kd->parts.size(), hipMemcpyHostToDevice, ctx->stream));
-  DFH_HIP(hipMemcpyAsync(kd->d_cols, kd->cols.data(), sizeof(int) * kd->P, hipMemcpyHostToDevice, ctx->stream));
-  DFH_HIP(hipMemcpyAsync(kd->d_lcols, kd->lcols.data(), sizeof(int) * kd->P, hipMemcpyHostToDevice, ctx->stream));
-  DFH_HIP(hipMemcpyAsync(kd->d_bw, kd->bw.data(), sizeof(double) * kd->P, hipMemcpyHostToDevice, ctx->stream));
+  size_t off[4], total;
+  blob_layout(*kd, off, &total);
+  std::vector<char> host(total, 0);
+  blob_fill(*kd, host.data());
+  DFH_HIP(hipMalloc(&kd->d_blob, total));
+  blob_point(kd, static_cast<char*>(kd->d_blob));
+  DFH_HIP(hipMemcpyAsync(kd->d_blob, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
   DFH_HIP(hipStreamSynchronize(ctx->stream));
   return DFH_OK;
 }
@@ -485,7 +512,7 @@ void add_part_cols(KernDev* kd, PartDev& pd, const int* cols, const double* bw, 
 
 }  // namespace
 
-int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* kd) {
+int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
   DFH_ARG(k != nullptr && kd != nullptr);
   DFH_ARG(k->dim >= 1);
   kd->kind = k->kind; kd->dim = k->dim; kd->P = 0;
@@ -521,8 +548,36 @@ int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* kd) {
     return DFH_ERR_BAD_ARG;
   }
   kd->n_parts = (int)kd->parts.size();
+  return DFH_OK;
+}
+
+int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* kd) {
+  DFH_TRY(kerndev_build_host(k, kd));
   return upload(ctx, kd);
 }
+
+size_t kerndev_blob_bytes(const KernDev& kd) {
+  size_t off[4], total;
+  blob_layout(kd, off, &total);
+  return total;
+}
+
+int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, size_t blob_bytes) {
+  std::vector<char> host(blob_bytes, 0);
+  size_t at = 0;
+  for (int c = 0; c < count; ++c) {
+    const size_t sz = kerndev_blob_bytes(kds[c]);
+    DFH_ARG(at + sz <= blob_bytes);
+    blob_fill(kds[c], host.data() + at);
+    kds[c].d_blob = nullptr;                    // not owned
+    blob_point(&kds[c], static_cast<char*>(d_blob) + at);
+    at += sz;
+  }
+  DFH_HIP(hipMemcpyAsync(d_blob, host.data(), at, hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
 
 int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* kd) {
   DFH_ARG(dim >= 1);
@@ -542,10 +597,8 @@ int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* kd) {
 
 void kerndev_free(KernDev* kd) {
   if (!kd) return;
-  if (kd->d_parts) (void)hipFree(kd->d_parts);
-  if (kd->d_cols) (void)hipFree(kd->d_cols);
-  if (kd->d_lcols) (void)hipFree(kd->d_lcols);
-  if (kd->d_bw) (void)hipFree(kd->d_bw);
+  if (kd->d_blob) (void)hipFree(kd->d_blob);
+  kd->d_blob = nullptr;
   kd->d_parts = nullptr; kd->d_cols = nullptr; kd->d_lcols = nullptr; kd->d_bw = nullptr;
 }
 

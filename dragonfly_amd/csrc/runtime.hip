@@ -67,9 +67,9 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     DFH_HIP(hipEventCreate(&ctx->tev1[i]));
   }
   ctx->scratch.resize(SCR_COUNT);
-  DFH_HIP(hipMalloc(&ctx->d_info, 8 * sizeof(int64_t)));
-  DFH_HIP(hipMemset(ctx->d_info, 0, 8 * sizeof(int64_t)));
-  DFH_HIP(hipHostMalloc(&ctx->h_info, 8 * sizeof(int64_t)));
+  DFH_HIP(hipMalloc(&ctx->d_info, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
+  DFH_HIP(hipMemset(ctx->d_info, 0, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
+  DFH_HIP(hipHostMalloc(&ctx->h_info, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
   *out = ctx;
   return DFH_OK;
 }
@@ -565,12 +565,17 @@ __global__ void k_logdet_dot(const double* L, int64_t n, int64_t ldl, const doub
   }
   if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
+int logdet_and_dot_device(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* a,
+                          const double* b, double* d_out2) {
+  hipLaunchKernelGGL(k_logdet_dot, dim3(1), dim3(256), 0, ctx->stream, L, n, ldl, a, b, d_out2);
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
 int logdet_and_dot(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* a,
                    const double* b, double* host_logdet, double* host_dot) {
   double* d = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_RED, 256, (void**)&d));
-  hipLaunchKernelGGL(k_logdet_dot, dim3(1), dim3(256), 0, ctx->stream, L, n, ldl, a, b, d);
-  DFH_LAUNCH_CHECK();
+  DFH_TRY(logdet_and_dot_device(ctx, L, n, ldl, a, b, d));
   double h[2];
   DFH_HIP(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
   DFH_HIP(hipStreamSynchronize(ctx->stream));

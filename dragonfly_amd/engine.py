@@ -278,6 +278,29 @@ class Engine(object):
     return x
 
   # -- GP ----------------------------------------------------------------------------------
+  def gp_lml_batch(self, specs, X, y, mean_consts, noise_vars, allow_jitter=True, return_powers=False):
+    """ Log marginal likelihoods of len(specs) hyper-parameter candidates on the same (X, y): the
+        tuning objective of GPFitter (gp_core.py:551-564) for a list of candidates, fitted in
+        lock-step groups on the device.  y holds raw labels; mean_consts[c] is subtracted. """
+    nb = len(specs)
+    Xh = X if isinstance(X, DeviceArray) else _f64(X)
+    yh = y if isinstance(y, DeviceArray) else _f64(y)
+    n, d = Xh.shape
+    descs = (_lib.KernelDesc * max(nb, 1))()
+    for i, sp in enumerate(specs):
+      descs[i] = sp.to_desc()          # the spec objects keep the arrays the descriptors point at
+    mc = _f64(np.zeros(nb) if mean_consts is None else mean_consts).reshape(-1)
+    nv = _f64(noise_vars).reshape(-1)
+    if len(mc) != nb or len(nv) != nb:
+      raise ValueError('gp_lml_batch: need one mean constant and one noise variance per candidate.')
+    lml = np.empty(nb, dtype=np.float64)
+    jps = np.empty(nb, dtype=np.int32)
+    check(self.lib.dfh_gp_lml_batch(self.ctx, descs, nb, _ptr(Xh), n, d, _ptr(yh), _ptr(mc), _ptr(nv),
+                                    0 if allow_jitter else _lib.FIT_NO_JITTER, _ptr(lml), _ptr(jps)))
+    if return_powers:
+      return lml, [None if p == INT32_MIN else int(p) for p in jps]
+    return lml
+
   def gp_fit(self, spec, X, y_centred, noise_var, allow_jitter=True):
     """ Returns a FittedGP (posterior resident in HBM). """
     return FittedGP(self, spec, X, y_centred, noise_var, allow_jitter)

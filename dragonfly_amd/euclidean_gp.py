@@ -222,6 +222,7 @@ class EuclideanGPFitter(object):
     self.Y = np.asarray(Y, dtype=np.float64)
     self.num_data = len(X)
     self._X_dev = None
+    self.batch_lml = True      # False: one dfh_gp_fit per candidate (the reference's loop shape)
     self._set_up()
 
   # -- set up (gp_core.py:323-356, 393-416; euclidean_gp.py:215-276) -------------------------------
@@ -314,13 +315,16 @@ class EuclideanGPFitter(object):
       self.hp_tune_max_evals = min(1e4, max(500, self.num_hps * 200))
     else:
       self.hp_tune_max_evals = min(1e5, max(500, self.num_hps * 400))
+    # The reference evaluates the sampled candidates one at a time (vectorised=False,
+    # gp_core.py:437,441); here the whole sample goes to the device as one batch.  The random
+    # draws are the same calls in the same order, so a seeded run picks the same candidates.
     def _rand_wrap(obj, max_evals):
-      opt_val, opt_pt, _ = random_maximise(obj, self.cts_hp_bounds, max_evals, vectorised=False)
+      opt_val, opt_pt, _ = random_maximise(obj, self.cts_hp_bounds, max_evals, vectorised=True)
       return opt_val, opt_pt, None
     def _rand_exp_sampling_wrap(obj, max_evals):
       sample_cts_hps, sample_dscr_hps, lml_vals = \
         random_sample_cts_dscr(obj, self.cts_hp_bounds, self.dscr_hp_vals, max_evals,
-                               vectorised=False)
+                               vectorised=True)
       sample_probs = np.exp(lml_vals - max(lml_vals))
       sample_probs = sample_probs / sample_probs.sum()
       return sample_cts_hps, sample_dscr_hps, sample_probs
@@ -334,11 +338,9 @@ class EuclideanGPFitter(object):
       self._X_dev = get_engine().to_device(_as_2d_array(self.X))
     return self._X_dev
 
-  def build_gp(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None, *args, **kwargs):
-    """ gp_core.py:501-543 """
-    if self.num_hps != len(gp_cts_hps) + len(gp_dscr_hps):
-      raise ValueError('gp_hyperparams should be of length %d. Given length: %d.'%(
-          self.num_hps, len(gp_cts_hps) + len(gp_dscr_hps)))
+  def _mean_and_noise_from_hps(self, gp_cts_hps):
+    """ gp_core.py:506-538: (mean_func, its constant value or None, noise_var, remaining cts hps) """
+    mean_func_const_value = None
     if hasattr(self.options, 'mean_func') and self.options.mean_func is not None:
       mean_func = self.options.mean_func
     else:
@@ -365,25 +367,36 @@ class EuclideanGPFitter(object):
       noise_var = self.options.noise_var_label * (self.Y.std() ** 2)
     else:
       noise_var = self.options.noise_var_value
+    return mean_func, mean_func_const_value, noise_var, gp_cts_hps
+
+  def build_gp(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None, *args, **kwargs):
+    """ gp_core.py:501-543 """
+    if self.num_hps != len(gp_cts_hps) + len(gp_dscr_hps):
+      raise ValueError('gp_hyperparams should be of length %d. Given length: %d.'%(
+          self.num_hps, len(gp_cts_hps) + len(gp_dscr_hps)))
+    mean_func, _, noise_var, gp_cts_hps = self._mean_and_noise_from_hps(gp_cts_hps)
     ret_gp, ret_cts_hps, ret_dscr_hps = self._child_build_gp(mean_func, noise_var, \
        gp_cts_hps, gp_dscr_hps, other_gp_params=other_gp_params, *args, **kwargs)
     assert len(ret_cts_hps) == 0
     assert len(ret_dscr_hps) == 0
     return ret_gp
 
-  def _child_build_gp(self, mean_func, noise_var, gp_cts_hps, gp_dscr_hps,
-                      other_gp_params=None, *args, **kwargs):
-    """ euclidean_gp.py:325-339 """
+  def _kernel_from_hps(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None):
+    """ euclidean_gp.py:325-336: the kernel of a candidate, and the left-over hyper-parameters. """
     kernel_hyperparams = prep_euclidean_integral_kernel_hyperparams(self.kernel_type,
                                                                     self.options, self.dim)
     add_gp_groupings = None
     if self.options.use_additive_gp:
       gp_dscr_hps = gp_dscr_hps[:-1]
       add_gp_groupings = other_gp_params.add_gp_groupings
-    kernel, gp_cts_hps, gp_dscr_hps = \
-      get_euclidean_integral_gp_kernel(self.kernel_type, kernel_hyperparams, gp_cts_hps,
-                                       gp_dscr_hps, self.options.use_same_bandwidth,
-                                       add_gp_groupings)
+    return get_euclidean_integral_gp_kernel(self.kernel_type, kernel_hyperparams, gp_cts_hps,
+                                            gp_dscr_hps, self.options.use_same_bandwidth,
+                                            add_gp_groupings)
+
+  def _child_build_gp(self, mean_func, noise_var, gp_cts_hps, gp_dscr_hps,
+                      other_gp_params=None, *args, **kwargs):
+    """ euclidean_gp.py:325-339 """
+    kernel, gp_cts_hps, gp_dscr_hps = self._kernel_from_hps(gp_cts_hps, gp_dscr_hps, other_gp_params)
     build_posterior = kwargs.pop('build_posterior', True)
     ret_gp = EuclideanGP(self.X, self.Y, kernel, mean_func, noise_var, *args,
                          build_posterior=False, **kwargs)
@@ -401,13 +414,40 @@ class EuclideanGPFitter(object):
     built_gp._invalidate()     # pylint: disable=protected-access
     return ret
 
+  def _tuning_objective_batch(self, cts_hps_list, dscr_hps, other_gp_params=None):
+    """ The tuning objective (gp_core.py:551-564) for a list of candidates: one dfh_gp_lml_batch
+        call (include/dfhip.h).  dscr_hps is one list shared by all candidates or one list per
+        candidate.  Returns an ndarray of log marginal likelihoods, in candidate order. """
+    num = len(cts_hps_list)
+    per_cand_dscr = len(dscr_hps) > 0 and isinstance(dscr_hps[0], (list, tuple, np.ndarray))
+    if num == 0:
+      return np.zeros((0,))
+    if not self.batch_lml or (hasattr(self.options, 'mean_func') and self.options.mean_func is not None):
+      # a user mean function is an arbitrary host callable: one fit per candidate
+      return np.array([self._tuning_objective(cts, list(dscr_hps[i]) if per_cand_dscr else list(dscr_hps),
+                                              other_gp_params=other_gp_params)
+                       for i, cts in enumerate(cts_hps_list)])
+    specs, mean_consts, noise_vars = [], [], []
+    for i, cts in enumerate(cts_hps_list):
+      dscr = list(dscr_hps[i]) if per_cand_dscr else list(dscr_hps)
+      if self.num_hps != len(cts) + len(dscr):
+        raise ValueError('gp_hyperparams should be of length %d. Given length: %d.'%(
+            self.num_hps, len(cts) + len(dscr)))
+      _, mean_const, noise_var, rest = self._mean_and_noise_from_hps(cts)
+      kernel, left_cts, left_dscr = self._kernel_from_hps(rest, dscr, other_gp_params)
+      assert len(left_cts) == 0 and len(left_dscr) == 0
+      specs.append(kernel.to_spec(self.dim))
+      mean_consts.append(float(mean_const))
+      noise_vars.append(float(noise_var))
+    return get_engine().gp_lml_batch(specs, self._device_X(), self.Y, mean_consts, noise_vars)
+
   def _optimise_cts_hps_for_given_dscr_hps(self, given_dscr_hps):
     """ gp_core.py:576-583 / euclidean_gp.py:303-313 """
     if self.options.use_additive_gp:
       return optimise_cts_hps_for_given_dscr_hps_in_add_model(list(given_dscr_hps), \
         self.options.num_groups_per_group_size, self.dim, self.hp_tune_max_evals, \
-        self.cts_hp_optimise, self._tuning_objective)
-    cts_tuning_obj = lambda arg: self._tuning_objective(arg, list(given_dscr_hps))
+        self.cts_hp_optimise, self._tuning_objective_batch)
+    cts_tuning_obj = lambda arg: self._tuning_objective_batch(arg, list(given_dscr_hps))
     opt_cts_val, opt_cts_hps, _ = self.cts_hp_optimise(cts_tuning_obj, self.hp_tune_max_evals)
     return opt_cts_val, opt_cts_hps, None
 
@@ -438,7 +478,7 @@ class EuclideanGPFitter(object):
     if self.options.use_additive_gp:
       raise NotImplementedError('rand_exp_sampling with additive GPs: use ml_hp_tune_opt="rand".')
     sample_cts_hps, sample_dscr_hps, sample_probs = \
-      self.hp_sampler(self._tuning_objective, self.hp_tune_max_evals)
+      self.hp_sampler(self._tuning_objective_batch, self.hp_tune_max_evals)
     sample_other_gp_params = [None] * len(sample_cts_hps)
     return ('sample_hps_with_probs', sample_cts_hps, sample_dscr_hps,
             sample_other_gp_params, sample_probs)

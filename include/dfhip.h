@@ -149,7 +149,21 @@ int dfh_gp_free(dfh_gp* gp);
 
 #define DFH_GET_L        0   /* n x n lower factor (GP.L)                                     */
 #define DFH_GET_ALPHA    1   /* n (GP.alpha)                                                  */
-#define DFH_GET_K        2   /* n x n kernel matrix without noise (GP.K_trtr_wo_noise)        */
+#define DFH_GET_K        2   /* Hyper-parameter tuning inner loop: log marginal likelihoods of `nb` candidate settings on the
+ * same data.  Replaces a loop of GPFitter._tuning_objective calls (gp/gp_core.py:551-564: build_gp
+ * -> GP.build_posterior :155-163 -> compute_log_marginal_likelihood :222-227), as issued by
+ * random_maximise / random_sample_cts_dscr for the 'rand' and 'rand_exp_sampling' tuners
+ * (utils/oper_utils.py:70-80, 100-112; gp_core.py:435-445).  descs[c], mean_consts[c] (NULL = 0),
+ * noise_vars[c] describe candidate c; y holds the raw labels (the constant mean is subtracted on
+ * the device).  Gram matrices of a group of candidates are factored in lock-step; a candidate that
+ * needs the stable_cholesky ladder gets it individually (jitter_powers[c], INT32_MIN = none).
+ * Errors as dfh_gp_fit (DFH_ERR_NOT_PD with DFH_FIT_NO_JITTER, DFH_ERR_JITTER when the ladder is
+ * exhausted, utils/general_utils.py:200).                                                        */
+int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* X, int64_t n,
+                     int64_t d, const double* y, const double* mean_consts, const double* noise_vars,
+                     int flags, double* lml_out /* [nb] */, int32_t* jitter_powers /* [nb] or NULL */);
+
+/* n x n kernel matrix without noise (GP.K_trtr_wo_noise)        */
 int dfh_gp_get(dfh_gp* gp, int what, double* out);
 int64_t dfh_gp_n(dfh_gp* gp);
 

@@ -1,0 +1,113 @@
+"""MI355X: the hyper-parameter-tuning inner loop as one device call (SURVEY.md section 8f-1,
+dfh_gp_lml_batch): batched log marginal likelihoods against the oracle and against one fit per
+candidate, including candidates that need the stable_cholesky ladder, groups larger than one
+lock-step batch, and the fitter's random-search tuners."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _candidates(rs, d, nb, y_var):
+  from dragonfly_amd.engine import KernelSpec
+  specs, ospecs, means, noises = [], [], [], []
+  for c in range(nb):
+    scale = float(np.exp(rs.uniform(np.log(0.1 * y_var), np.log(10 * y_var))))
+    bw = np.exp(rs.uniform(np.log(0.05), np.log(5.0), size=d))
+    if c % 3 == 2:
+      nu = [0.5, 1.5, 2.5][(c // 3) % 3]
+      specs.append(KernelSpec('matern', d, scale, bw, nu=nu))
+      ospecs.append(O.KernelSpec('matern', d, scale, bw, nu=nu))
+    else:
+      specs.append(KernelSpec('se', d, scale, bw))
+      ospecs.append(O.KernelSpec('se', d, scale, bw))
+    means.append(float(rs.randn()))
+    noises.append(float(np.exp(rs.uniform(np.log(0.005 * y_var), np.log(0.2 * y_var)))))
+  return specs, ospecs, means, noises
+
+
+@pytest.mark.parametrize('n,d,nb', [(45, 3, 7), (200, 2, 150), (700, 6, 9), (1500, 4, 5)])
+def test_lml_batch_matches_oracle_and_single_fits(engine, n, d, nb):
+  rs = np.random.RandomState(n + nb)
+  X = rs.rand(n, d)
+  Y = np.sin(4 * X.sum(axis=1)) + 0.1 * rs.randn(n)
+  specs, ospecs, means, noises = _candidates(rs, d, nb, float(Y.var()))
+  lml, powers = engine.gp_lml_batch(specs, X, Y, means, noises, return_powers=True)
+  assert lml.shape == (nb,)
+  check = range(nb) if nb <= 20 else list(range(0, nb, 11)) + [63, 64, 65, nb - 1]
+  for c in check:
+    ref = O.GPOracle(X, Y, ospecs[c], means[c], noises[c]).lml()
+    assert abs(lml[c] - ref) <= TOL * abs(ref), (c, lml[c], ref)
+    one = engine.gp_fit(specs[c], X, Y - means[c], noises[c])
+    assert abs(lml[c] - one.lml) <= 1e-12 * abs(one.lml) and powers[c] == one.jitter_power
+    one.free()
+
+
+def test_lml_batch_jitter_ladder_per_candidate(engine):
+  """ duplicated training points and a vanishing noise variance: the Gram matrix of some
+      candidates is numerically singular -> those (and only those) go through the ladder """
+  from dragonfly_amd.engine import KernelSpec
+  rs = np.random.RandomState(77)
+  n, d = 300, 2
+  X = rs.rand(n, d)
+  X[150:] = X[:150]
+  Y = np.cos(3 * X[:, 0]) + X[:, 1]
+  specs = [KernelSpec('se', d, 1.0, np.full(d, bw)) for bw in (0.3, 2.0, 0.5, 3.0, 0.2)]
+  ospecs = [O.KernelSpec('se', d, 1.0, np.full(d, bw)) for bw in (0.3, 2.0, 0.5, 3.0, 0.2)]
+  noises = [1e-3, 0.0, 1e-2, 1e-18, 1e-3]
+  lml, powers = engine.gp_lml_batch(specs, X, Y, None, noises, return_powers=True)
+  assert powers[0] is None and powers[2] is None and powers[4] is None
+  assert powers[1] is not None and powers[3] is not None
+  for c in range(5):
+    og = O.GPOracle(X, Y, ospecs[c], 0.0, noises[c])
+    assert og.jitter_power == powers[c]
+    ref = og.lml()
+    # after the ladder K + 1e-11 max(diag) I still has cond ~1e11-1e13: y^T alpha amplifies the
+    # 1e-16 differences between two correct factorisations to ~1e-5 relative
+    tol = TOL if powers[c] is None else 1e-4
+    assert abs(lml[c] - ref) <= tol * abs(ref), (c, lml[c], ref)
+    one = engine.gp_fit(specs[c], X, Y, noises[c])
+    assert one.jitter_power == powers[c] and abs(one.lml - lml[c]) <= 1e-12 * abs(one.lml)
+  with pytest.raises(np.linalg.LinAlgError):
+    engine.gp_lml_batch(specs, X, Y, None, noises, allow_jitter=False)
+
+
+@pytest.mark.parametrize('kt', ['se', 'matern'])
+def test_fitter_batched_and_per_candidate_tuning_agree(engine, kt):
+  from dragonfly_amd.euclidean_gp import EuclideanGPFitter
+  g = load_golden('fitter_d3_n45')
+  out = []
+  for batch in (True, False):
+    opts = Namespace(kernel_type=kt, ml_hp_tune_opt='rand', hp_tune_max_evals=60, hp_tune_criterion='ml')
+    np.random.seed(4242)
+    fitter = EuclideanGPFitter(list(g['X']), list(g['Y']), options=opts)
+    fitter.batch_lml = batch
+    kind, gp, hps = fitter.fit_gp()
+    out.append((np.array(hps[0], dtype=float), list(hps[1]), gp.compute_log_marginal_likelihood()))
+  assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+  assert np.array_equal(out[0][0], g[kt + '_cts_hps'])          # the reference's own choice
+  assert abs(out[0][2] - out[1][2]) <= 1e-12 * abs(out[1][2])
+
+
+def test_fitter_rand_exp_sampling_probabilities(engine):
+  from dragonfly_amd.euclidean_gp import EuclideanGPFitter
+  g = load_golden('fitter_d3_n45')
+  res = []
+  for batch in (True, False):
+    opts = Namespace(kernel_type='matern', matern_nu=-1.0, ml_hp_tune_opt='rand_exp_sampling',
+                     hp_tune_max_evals=40, hp_tune_criterion='ml')
+    np.random.seed(99)
+    fitter = EuclideanGPFitter(list(g['X']), list(g['Y']), options=opts)
+    fitter.batch_lml = batch
+    ret = fitter.fit_gp()
+    assert ret[0] == 'sample_hps_with_probs'
+    res.append(ret)
+  assert np.array_equal(np.asarray(res[0][1]), np.asarray(res[1][1])) and res[0][2] == res[1][2]
+  assert np.allclose(res[0][4], res[1][4], rtol=1e-9, atol=1e-300)
+  assert abs(res[0][4].sum() - 1.0) < 1e-12

@@ -331,7 +331,49 @@ def stage_fit16k():
   print('STAGE fit16k DONE')
 
 
-STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k']
+def stage_hptune():
+  """ hyper-parameter tuning inner loop: batched lml vs one fit per candidate vs the CPU oracle """
+  from dragonfly_amd.engine import Engine, KernelSpec
+  from oracle import ref_numpy as O
+  eng = Engine()
+  for (n, d, nb) in [(50, 3, 512), (200, 6, 512), (1000, 6, 256), (4096, 6, 64), (16384, 32, 12)]:
+    rs = np.random.RandomState(n)
+    X = rs.rand(n, d)
+    Y = np.sin(4 * X.sum(axis=1)) + 0.1 * rs.randn(n)
+    yv = float(Y.var())
+    specs = [KernelSpec('se', d, yv * np.exp(rs.randn()), np.exp(rs.uniform(np.log(0.3), np.log(3.0), size=d)))
+             for _ in range(nb)]
+    means = list(rs.randn(nb) * 0.1)
+    noises = list(yv * np.exp(rs.uniform(np.log(0.005), np.log(0.2), size=nb)))
+    Xd = eng.to_device(X)
+    eng.gp_lml_batch(specs[:8], Xd, Y, means[:8], noises[:8])
+    eng.sync()
+    t0 = time.time()
+    lml = eng.gp_lml_batch(specs, Xd, Y, means, noises)
+    tb = time.time() - t0
+    k = min(nb, 64)
+    t0 = time.time()
+    one = []
+    for c in range(k):
+      g = eng.gp_fit(specs[c], Xd, Y - means[c], noises[c])
+      one.append(g.lml)
+      g.free()
+    ts = (time.time() - t0) / k
+    kc = min(nb, 4 if n > 4000 else 16)
+    if n > 8192:
+      kc = 0
+    t0 = time.time()
+    ref = [O.GPOracle(X, Y, O.KernelSpec('se', d, specs[c].scale, specs[c].bandwidths), means[c], noises[c]).lml()
+           for c in range(kc)]
+    tc = (time.time() - t0) / max(kc, 1)
+    err1 = max(abs(lml[c] - one[c]) / abs(one[c]) for c in range(k))
+    err2 = max([abs(lml[c] - ref[c]) / abs(ref[c]) for c in range(kc)] or [0.0])
+    print('hp-tune n=%5d d=%2d nb=%3d: batched %.3f ms/cand | single fits %.3f ms/cand | oracle %.2f ms/cand '
+          '| err vs single %.1e vs oracle %.1e' % (n, d, nb, tb * 1e3 / nb, ts * 1e3, tc * 1e3, err1, err2))
+  print('STAGE hptune PASS')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune']
 
 if __name__ == '__main__':
   if len(sys.argv) == 3 and sys.argv[1] == '--run':
