@@ -64,6 +64,8 @@ SIGNATURES = {
   'dfh_gp_lml_batch': (C.c_int, [C.c_void_p, C.POINTER(KernelDesc), C.c_int32, C.c_void_p, C.c_int64,
                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p]),
+  'dfh_gp_append': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                              C.POINTER(C.c_void_p), c_double_p, c_int32_p]),
   'dfh_gp_free': (C.c_int, [C.c_void_p]),
   'dfh_gp_get': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
   'dfh_gp_n': (C.c_int64, [C.c_void_p]),

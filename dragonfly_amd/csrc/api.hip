@@ -526,7 +526,7 @@ extern "C" int dfh_solve_triangular(dfh_ctx* ctx, const double* L, int64_t n, in
 // ---------------------------------------------------------------------------------------------
 extern "C" int dfh_gp_free(dfh_gp* gp) {
   if (!gp) return DFH_OK;
-  if (gp->ctx) {
+  if (gp->ctx && ctx_is_live(gp->ctx)) {      // the context may already be gone (teardown order)
     (void)hipSetDevice(gp->ctx->device);
     (void)hipStreamSynchronize(gp->ctx->stream);
   }
@@ -541,6 +541,20 @@ extern "C" int dfh_gp_free(dfh_gp* gp) {
 }
 
 extern "C" int64_t dfh_gp_n(dfh_gp* gp) { return gp ? gp->n : -1; }
+
+// alpha = L^T \ (L \ y_centred) (gp_core.py:161-163) and the log marginal likelihood (:224-226)
+static int gp_alpha_and_lml(dfh_gp* gp, const double* dy, double* lml) {
+  dfh_ctx* ctx = gp->ctx;
+  const int64_t n = gp->n;
+  SectionTimer t(ctx, DFH_T_SOLVE);
+  DFH_HIP(hipMemcpyAsync(gp->alpha, dy, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  DFH_TRY(trsv_forward(ctx, gp->L, n, n, gp->inv, gp->alpha));
+  DFH_TRY(trsv_backward(ctx, gp->L, n, n, gp->inv, gp->alpha));
+  double logdet = 0.0, dot = 0.0;
+  DFH_TRY(logdet_and_dot(ctx, gp->L, n, n, dy, gp->alpha, &logdet, &dot));
+  if (lml) *lml = -0.5 * dot - logdet - 0.5 * (double)n * log(2.0 * M_PI);
+  return DFH_OK;
+}
 
 extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* X, int64_t n, int64_t d,
                           const double* y_centred, double noise_var, int flags, dfh_gp** out,
@@ -578,22 +592,104 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
       DFH_TRY(stable_cholesky_device(ctx, gp->L, n, gp->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
                                      jitter_power, &gp->diag_jitter));
     }
-    {
-      SectionTimer t(ctx, DFH_T_SOLVE);
-      // alpha = L^T \ (L \ y_centred)      (gp_core.py:161-163)
-      DFH_HIP(hipMemcpyAsync(gp->alpha, dy, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      DFH_TRY(trsv_forward(ctx, gp->L, n, n, gp->inv, gp->alpha));
-      DFH_TRY(trsv_backward(ctx, gp->L, n, n, gp->inv, gp->alpha));
-      double logdet = 0.0, dot = 0.0;
-      DFH_TRY(logdet_and_dot(ctx, gp->L, n, n, dy, gp->alpha, &logdet, &dot));
-      if (lml) *lml = -0.5 * dot - logdet - 0.5 * (double)n * log(2.0 * M_PI);   // gp_core.py:224-226
-    }
-    return DFH_OK;
+    return gp_alpha_and_lml(gp, dy, lml);
   };
   int rc = body();
   if (rc != DFH_OK) { dfh_gp_free(gp); return rc; }
   DFH_HIP(hipStreamSynchronize(ctx->stream));
   *out = gp;
+  return DFH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Incremental posterior update.  GP.add_data_multiple (gp_core.py:139-146)
+// extends X, Y and rebuilds the posterior from scratch -- O((n+q)^3).  With the same kernel,
+// noise and data order the factor of the extended matrix is
+//     L' = [ L  0 ; B  Ls ],  B = K(Xnew, X) L^-T,  Ls = chol(K(Xnew,Xnew) + noise I - B B^T)
+// (the Cholesky factor is unique), which costs O(n^2 q).  A NEW handle is returned; `gp` is left
+// untouched (shallow copies of a GP share the handle).  When the reference's rebuild would leave
+// the plain-Cholesky branch -- the existing fit needed the stable_cholesky ladder, or the Schur
+// complement is not positive definite -- the extended matrix is rebuilt and factored from
+// scratch with the ladder, exactly what build_posterior would do.
+extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const double* y_centred, int flags,
+                             dfh_gp** out, double* lml, int32_t* jitter_power) {
+  DFH_ARG(gp && out && q >= 1 && Xnew && y_centred);
+  *out = nullptr;
+  if (jitter_power) *jitter_power = INT32_MIN;
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int64_t n = gp->n, n2 = gp->n + q, d = gp->d, NB = CHOL_NB;
+  dfh_gp* g2 = new dfh_gp();
+  g2->ctx = ctx; g2->n = n2; g2->d = d; g2->noise_var = gp->noise_var;
+  g2->nblk = (n2 + NB - 1) / NB;
+  auto body = [&]() -> int {
+    DFH_TRY(kerndev_clone(ctx, gp->kd, &g2->kd));
+    const KernDev& kd = g2->kd;
+    const int64_t P = kd.P, parts = kd.n_parts;
+    DFH_HIP(hipMalloc(&g2->Xp, (size_t)n2 * P * 8));
+    DFH_HIP(hipMalloc(&g2->Np, (size_t)n2 * parts * 8));
+    DFH_HIP(hipMalloc(&g2->L, (size_t)n2 * n2 * 8));
+    DFH_HIP(hipMalloc(&g2->inv, (size_t)g2->nblk * NB * NB * 8));
+    DFH_HIP(hipMalloc(&g2->alpha, (size_t)n2 * 8));
+    const double *dXn = nullptr, *dy = nullptr;
+    DFH_TRY(to_device(ctx, Xnew, (size_t)q * d * 8, SCR_STAGE_A, &dXn));
+    DFH_TRY(to_device(ctx, y_centred, (size_t)n2 * 8, SCR_STAGE_B, &dy));
+    double* Xpn = g2->Xp + n * P; double* Npn = g2->Np + n * parts;
+    {
+      SectionTimer t(ctx, DFH_T_KERNMAT);
+      DFH_HIP(hipMemcpyAsync(g2->Xp, gp->Xp, (size_t)n * P * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      DFH_HIP(hipMemcpyAsync(g2->Np, gp->Np, (size_t)n * parts * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      DFH_TRY(pack_scaled(ctx, kd, 0, parts, false, dXn, q, d, Xpn, Npn));
+    }
+    auto full_refit = [&]() -> int {             // what build_posterior does: K' + noise I, ladder
+      auto build_M = [&]() -> int {
+        SectionTimer t(ctx, DFH_T_KERNMAT);
+        return kernmat_packed(ctx, kd, 0, parts, true, g2->Xp, g2->Np, n2, g2->Xp, g2->Np, n2, true,
+                              g2->noise_var, g2->L, n2);
+      };
+      DFH_TRY(build_M());
+      SectionTimer t(ctx, DFH_T_CHOL);
+      return stable_cholesky_device(ctx, g2->L, n2, g2->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
+                                    jitter_power, &g2->diag_jitter);
+    };
+    bool appended = false;
+    if (gp->diag_jitter == 0.0) {
+      double* Bm = g2->L + n * n2;               // rows n.., columns 0..n-1
+      double* S = g2->L + n * n2 + n;            // the new diagonal block (ld n2)
+      DFH_TRY(copy_matrix(ctx, gp->L, n, g2->L, n2, n, n));
+      {
+        SectionTimer t(ctx, DFH_T_CROSS);
+        DFH_TRY(kernmat_packed(ctx, kd, 0, parts, true, Xpn, Npn, q, g2->Xp, g2->Np, n, false, 0.0, Bm, n2));
+      }
+      {
+        SectionTimer t(ctx, DFH_T_TRSM);
+        DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Bm, q, n2));
+      }
+      {
+        SectionTimer t(ctx, DFH_T_CHOL);
+        DFH_TRY(kernmat_packed(ctx, kd, 0, parts, true, Xpn, Npn, q, Xpn, Npn, q, true, g2->noise_var, S, n2));
+        DFH_TRY(gemm_f64(ctx, GEMM_LOWER, q, q, n, -1.0, Bm, n2, Bm, n2, 1.0, S, n2, S, n2));
+        int64_t piv = 0;
+        const int rc = cholesky_device(ctx, S, q, n2, nullptr, &piv);
+        if (rc == DFH_OK) {
+          // inverses of the 512-blocks: untouched blocks are copied, the rest recomputed from L'
+          const int64_t kb0 = n / NB;            // first diagonal block that contains a new row
+          if (kb0 > 0)
+            DFH_HIP(hipMemcpyAsync(g2->inv, gp->inv, (size_t)kb0 * NB * NB * 8, hipMemcpyDeviceToDevice, ctx->stream));
+          DFH_TRY(tri_block_inverses(ctx, g2->L + kb0 * NB * (n2 + 1), n2 - kb0 * NB, n2, g2->inv + kb0 * NB * NB));
+          appended = true;
+        } else if (rc != DFH_ERR_NOT_PD) {
+          return rc;
+        }
+      }
+    }
+    if (!appended) DFH_TRY(full_refit());
+    return gp_alpha_and_lml(g2, dy, lml);
+  };
+  int rc = body();
+  if (rc != DFH_OK) { dfh_gp_free(g2); return rc; }
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  *out = g2;
   return DFH_OK;
 }
 

@@ -106,6 +106,7 @@ enum ScratchSlot {
 
 // returns a device pointer with at least `bytes` capacity (contents undefined)
 int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out);
+bool ctx_is_live(const dfh_ctx* ctx);    // false once dfh_ctx_destroy ran (or for a foreign pointer)
 
 // Resolve a user pointer: if it is a host pointer, copy `bytes` to scratch slot `slot` and
 // return the device copy; if it is a device pointer return it unchanged.
@@ -186,6 +187,7 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* out);
 size_t kerndev_blob_bytes(const KernDev& kd);
 int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, size_t blob_bytes);
 int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* out);
+int kerndev_clone(dfh_ctx* ctx, const KernDev& src, KernDev* out);   // deep copy with its own device image
 void kerndev_free(KernDev* kd);
 double kerndev_part_kxx(const KernDev& kd, int part);
 

@@ -595,6 +595,12 @@ int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* kd) {
   return upload(ctx, kd);
 }
 
+int kerndev_clone(dfh_ctx* ctx, const KernDev& src, KernDev* out) {
+  *out = src;
+  out->d_blob = nullptr; out->d_parts = nullptr; out->d_cols = nullptr; out->d_lcols = nullptr; out->d_bw = nullptr;
+  return upload(ctx, out);
+}
+
 void kerndev_free(KernDev* kd) {
   if (!kd) return;
   if (kd->d_blob) (void)hipFree(kd->d_blob);

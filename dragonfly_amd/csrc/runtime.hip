@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <mutex>
+#include <set>
 
 static thread_local char g_err[1024] = "";
 
@@ -28,6 +30,14 @@ extern "C" int dfh_device_count(int* count) {
   }
   *count = c;
   return DFH_OK;
+}
+
+// live contexts: a dfh_gp released after its context was destroyed must not touch the context
+static std::mutex g_live_mu;
+static std::set<const dfh_ctx*> g_live_ctx;
+bool ctx_is_live(const dfh_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return g_live_ctx.count(ctx) != 0;
 }
 
 extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
@@ -70,12 +80,20 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
   DFH_HIP(hipMalloc(&ctx->d_info, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
   DFH_HIP(hipMemset(ctx->d_info, 0, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
   DFH_HIP(hipHostMalloc(&ctx->h_info, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_ctx.insert(ctx);
+  }
   *out = ctx;
   return DFH_OK;
 }
 
 extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (!g_live_ctx.erase(ctx)) return;          // not (or no longer) a live context
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& b : ctx->scratch)
@@ -118,9 +136,8 @@ extern "C" int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr) {
 }
 
 extern "C" int dfh_free(dfh_ctx* ctx, void* dptr) {
-  DFH_ARG(ctx != nullptr);
   if (!dptr) return DFH_OK;
-  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx && ctx_is_live(ctx)) DFH_HIP(hipStreamSynchronize(ctx->stream));   // else: context already destroyed
   DFH_HIP(hipFree(dptr));
   return DFH_OK;
 }

@@ -85,6 +85,17 @@ class KernelSpec(object):
     self.sub_bandwidths = sub_bandwidths
     self._keep = []
 
+  def signature(self):
+    """ Hashable value identifying the kernel exactly (used to decide whether a cached posterior
+        was built with the same kernel). """
+    def _t(a):
+      return None if a is None else tuple(np.ravel(np.asarray(a, dtype=float)).tolist())
+    groups = None if self.groups is None else tuple(tuple(int(c) for c in g) for g in self.groups)
+    subs = None if self.sub_bandwidths is None else tuple(_t(b) for b in self.sub_bandwidths)
+    kinds = None if self.sub_kinds is None else tuple(self.sub_kinds)
+    return (self.kind, self.dim, self.scale, self.nu, _t(self.bandwidths), groups, kinds,
+            _t(self.sub_scales), _t(self.sub_nus), subs)
+
   def to_desc(self):
     """ Builds the ctypes struct (keeps the backing arrays alive on self). """
     d = KernelDesc()
@@ -327,6 +338,31 @@ class FittedGP(object):
     self.handle = h
     self.lml = lml.value
     self.jitter_power = None if jp.value == INT32_MIN else jp.value
+
+  def append(self, X_new, y_centred_all, allow_jitter=True):
+    """ Posterior extended by the rows of X_new (dfh_gp_append): a NEW FittedGP, this one stays
+        valid.  y_centred_all: all n+q centred labels, old observations first. """
+    Xn = _f64(X_new)
+    if Xn.ndim == 1:
+      Xn = Xn.reshape(1, -1)
+    q = Xn.shape[0]
+    if Xn.shape[1] != self.d:
+      raise ValueError('append: new points have %d columns, the GP has %d.' % (Xn.shape[1], self.d))
+    yh = _f64(y_centred_all).reshape(-1)
+    if yh.shape[0] != self.n + q:
+      raise ValueError('append: need %d centred labels, got %d.' % (self.n + q, yh.shape[0]))
+    h = C.c_void_p()
+    lml = C.c_double(0)
+    jp = C.c_int32(INT32_MIN)
+    check(self.engine.lib.dfh_gp_append(self.handle, _ptr(Xn), q, _ptr(yh),
+                                        0 if allow_jitter else _lib.FIT_NO_JITTER,
+                                        C.byref(h), C.byref(lml), C.byref(jp)))
+    new = FittedGP.__new__(FittedGP)
+    new.engine, new.spec, new.handle = self.engine, self.spec, h
+    new.n, new.d = self.n + q, self.d
+    new.lml = lml.value
+    new.jitter_power = None if jp.value == INT32_MIN else jp.value
+    return new
 
   def free(self):
     if self.handle is not None:

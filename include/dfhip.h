@@ -149,7 +149,18 @@ int dfh_gp_free(dfh_gp* gp);
 
 #define DFH_GET_L        0   /* n x n lower factor (GP.L)                                     */
 #define DFH_GET_ALPHA    1   /* n (GP.alpha)                                                  */
-#define DFH_GET_K        2   /* Hyper-parameter tuning inner loop: log marginal likelihoods of `nb` candidate settings on the
+#define DFH_GET_K        2   /* Incremental posterior update: the posterior of `gp` extended by q new observations, as a NEW
+ * handle (`gp` stays valid and unchanged).  Replaces the rebuild of GP.add_data_multiple
+ * (gp/gp_core.py:139-146: X.extend, Y.extend, build_posterior) with a block-row append of the
+ * Cholesky factor, O(n^2 q) instead of O((n+q)^3); same kernel, noise variance and data order,
+ * so L, alpha and lml equal the rebuilt ones up to rounding.  y_centred holds all n+q centred
+ * labels (old ones first).  If the existing fit used the stable_cholesky ladder or the appended
+ * block is not positive definite, the extended matrix is rebuilt and factored from scratch with
+ * the ladder (utils/general_utils.py:166-204), as the reference's rebuild would.               */
+int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const double* y_centred, int flags,
+                  dfh_gp** out, double* lml, int32_t* jitter_power);
+
+/* Hyper-parameter tuning inner loop: log marginal likelihoods of `nb` candidate settings on the
  * same data.  Replaces a loop of GPFitter._tuning_objective calls (gp/gp_core.py:551-564: build_gp
  * -> GP.build_posterior :155-163 -> compute_log_marginal_likelihood :222-227), as issued by
  * random_maximise / random_sample_cts_dscr for the 'rand' and 'rand_exp_sampling' tuners

@@ -373,7 +373,37 @@ def stage_hptune():
   print('STAGE hptune PASS')
 
 
-STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune']
+def stage_append():
+  """ incremental posterior update vs full refit """
+  from dragonfly_amd.engine import Engine, KernelSpec
+  eng = Engine()
+  for (n, d) in [(1000, 6), (4096, 6), (16384, 32)]:
+    rs = np.random.RandomState(n)
+    X = rs.rand(n + 64, d)
+    Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n + 64)
+    spec = KernelSpec('se', d, float(Y.var()), 0.2 * np.sqrt(d) * np.ones(d))
+    noise = float(Y.var() / 20)
+    base = eng.gp_fit(spec, X[:n], Y[:n], noise)
+    for q in (1, 8, 64):
+      ext = base.append(X[n:n + q], Y[:n + q]); ext.free()
+      t0 = time.time()
+      for _ in range(3):
+        ext = base.append(X[n:n + q], Y[:n + q]); ext.free()
+      ta = (time.time() - t0) / 3
+      full = eng.gp_fit(spec, X[:n + q], Y[:n + q], noise); full.free()
+      t0 = time.time()
+      full = eng.gp_fit(spec, X[:n + q], Y[:n + q], noise)
+      tf = time.time() - t0
+      ext = base.append(X[n:n + q], Y[:n + q])
+      err = np.abs(ext.get_alpha() - full.get_alpha()).max() / np.abs(full.get_alpha()).max()
+      print('append n=%5d q=%2d: append %.3f ms | full refit %.3f ms | alpha diff %.1e lml diff %.1e'
+            % (n, q, ta * 1e3, tf * 1e3, err, abs(ext.lml - full.lml) / abs(full.lml)))
+      ext.free(); full.free()
+    base.free()
+  print('STAGE append PASS')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append']
 
 if __name__ == '__main__':
   if len(sys.argv) == 3 and sys.argv[1] == '--run':
