@@ -509,7 +509,16 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       const double* A31 = A + (k0 + nbk + NB) * lda + k0;                // rows k+2.. of the panel
       double* A33 = A + (k0 + nbk + NB) * lda + (k0 + nbk + NB);
       DFH_HIP(hipStreamWaitEvent(M, e_trsm, 0));
-      DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rem2, rem2, nbk, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda, &bA));
+      {
+        // DFH_CHOL_HALF_OCC=1: trailing update at one workgroup per CU, leaving slots for the
+        // latency-bound panel kernels of the look-ahead stream
+        static const bool half = []() { const char* e = getenv("DFH_CHOL_HALF_OCC"); return e && atoi(e) != 0; }();
+        const bool old = ctx->gemm_half_occupancy;
+        if (half) ctx->gemm_half_occupancy = true;
+        const int rc_t = gemm_f64(ctx, GEMM_LOWER, rem2, rem2, nbk, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda, &bA);
+        ctx->gemm_half_occupancy = old;
+        DFH_TRY(rc_t);
+      }
       DFH_HIP(hipEventRecord(e_trail, M));
     } else {
       // nothing for M to do: keep the event chain well-formed for the next panel's wait
