@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, lo
                                                       long strideInv, long strideL) {
   __shared__ double S[PB * PBP];
   D += (long)blockIdx.y * strideD;
-  inv += (long)blockIdx.y * strideInv;
+  if (inv) inv += (long)blockIdx.y * strideInv;
   if (Lscr) Lscr += (long)blockIdx.y * strideL;
   const int tid = threadIdx.x;
   const int k = tid & 63, w = tid >> 6;
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, lo
       a[r] = src[i * PB + k];
       if (i < nb && k < nb) A[i * lda + k] = a[r];
     }
+    if (!inv) return;                 // commit of the factor only (no inverses wanted)
   } else {
     load_block64(A, lda, nb, w, k, a);
   }
@@ -425,19 +426,21 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   if (n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
   long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
-  hipStream_t M = ctx->stream, P = ctx->side;
+  // Three streams.  P (high priority): the dependent chain -- 64-wide pivot steps over the panel,
+  // each solving ALL rows below it by substitution, then the update of the next block column.
+  // M (the caller's stream): the big trailing updates.  X (aux): everything the chain does not
+  // need -- moving the pivot-block factors into place and the explicit 512-block inverses kept
+  // for the triangular solves of the posterior.
+  hipStream_t M = ctx->stream, P = ctx->side, X = ctx->aux;
   DFH_HIP(hipMemsetAsync(d_info, 0, 8 * (size_t)nbatch, M));
 
-  const int64_t strideInv = keep_inv ? strideKeep : NB * NB;   // between the batch matrices' inverse blocks
-  const int64_t strideT = NB * NB + (NB / PB) * PB * PB;
-  const int64_t strideW = (n > NB) ? (n - NB) * NB : 0;
-  double* inv_scratch = nullptr;
-  if (!keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * strideInv * 8, (void**)&inv_scratch));
+  const int64_t strideInv = keep_inv ? strideKeep : 0;          // between the batch matrices' inverse blocks
+  const int64_t strideL = 2 * (NB / PB) * PB * PB;               // factor scratch: [parity][8][64][64] per matrix
+  const int64_t strideT = NB * NB;
+  double* Lscr_all = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * strideL * 8, (void**)&Lscr_all));
   double* T = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
-  double* Lscr = T + NB * NB;                 // factors of the pivot blocks of the current panel
-  double* W = nullptr;
-  if (n > NB) DFH_TRY(scratch_get(ctx, SCR_CHOLW, (size_t)nbatch * strideW * 8, (void**)&W));
+  if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
   GemmBatch bA;                               // every operand inside the batch matrices
   bA.count = nbatch; bA.sA = bA.sB = bA.sCin = bA.sCout = strideA;
 
@@ -448,67 +451,77 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     attr_set = true;
   }
   const int64_t nblk = (n + NB - 1) / NB;
-  DFH_ARG(2 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
+  DFH_ARG(3 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
   hipEvent_t ev_start, ev_done;
   DFH_TRY(ctx_event(ctx, 0, &ev_start));
   DFH_TRY(ctx_event(ctx, 1, &ev_done));
   DFH_HIP(hipEventRecord(ev_start, M));
   DFH_HIP(hipStreamWaitEvent(P, ev_start, 0));
+  DFH_HIP(hipStreamWaitEvent(X, ev_start, 0));
 
   for (int64_t kb = 0; kb < nblk; ++kb) {
     const int64_t k0 = kb * NB;
     const int64_t nbk = (n - k0 < NB) ? n - k0 : NB;
-    double* Linv = keep_inv ? keep_inv + kb * NB * NB : inv_scratch;
+    double* Linv = keep_inv ? keep_inv + kb * NB * NB : nullptr;
     double* D = A + k0 * lda + k0;
+    double* Lscr = Lscr_all + (kb & 1) * (NB / PB) * PB * PB;
     const int64_t rem = n - k0 - nbk;
-    hipEvent_t e_trsm, e_trail, e_trail_prev = nullptr;
-    DFH_TRY(ctx_event(ctx, 2 + 2 * kb, &e_trsm));
-    DFH_TRY(ctx_event(ctx, 3 + 2 * kb, &e_trail));
-    if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 2 * (kb - 1), &e_trail_prev));
+    hipEvent_t e_panel, e_trail, e_aux, e_trail_prev = nullptr, e_aux_prev2 = nullptr;
+    DFH_TRY(ctx_event(ctx, 2 + 3 * kb, &e_panel));
+    DFH_TRY(ctx_event(ctx, 3 + 3 * kb, &e_trail));
+    DFH_TRY(ctx_event(ctx, 4 + 3 * kb, &e_aux));
+    if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 3 * (kb - 1), &e_trail_prev));
+    if (kb >= 2) DFH_TRY(ctx_event(ctx, 4 + 3 * (kb - 2), &e_aux_prev2));
     {
       StreamSwap on_p(ctx, P);
-      for (int b = 0; b < nbatch; ++b) DFH_HIP(hipMemsetAsync(Linv + b * strideInv, 0, (size_t)NB * NB * 8, P));
-      // ---- factor the diagonal block with 64-wide steps -----------------------------------
+      if (e_aux_prev2) DFH_HIP(hipStreamWaitEvent(P, e_aux_prev2, 0));     // factor scratch of this parity is free again
+      // ---- 64-wide pivot steps: factor, solve every row below, update the rest of the panel ----
       for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
         const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
         double* Djj = D + j0 * lda + j0;
-        const int64_t rows = nbk - j0 - w;
+        const int64_t cols_left = nbk - j0 - w;            // panel columns still to be factored
+        const int64_t rows = cols_left + rem;              // every row below the pivot block
         const unsigned nwg = 1 + (unsigned)((rows + PB - 1) / PB);
         hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg, (unsigned)nbatch), dim3(256), DIAG_STEP_SMEM, P, Djj,
                            (long)lda, w, (int)rows, (long)(k0 + j0), d_info, Lscr + (j0 / PB) * PB * PB,
-                           (long)strideA, (long)strideT);
+                           (long)strideA, (long)strideL);
         DFH_LAUNCH_CHECK();
-        if (rows > 0) {
+        if (cols_left > 0) {
+          // A[r, c] -= L[r, j] L[c, j]^T for the rows below and the panel columns to the right
+          // (the part above the diagonal of the block is scratch: only the lower triangle is L)
           double* Pn = D + (j0 + w) * lda + j0;                      // rows x w, already solved
           double* D22 = D + (j0 + w) * lda + (j0 + w);
-          DFH_TRY(gemm_f64(ctx, GEMM_LOWER, rows, rows, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda, &bA));
+          DFH_TRY(gemm_f64(ctx, 0, rows, cols_left, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda, &bA));
         }
       }
-      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, P,
-                         D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
-                         (long)strideT);
-      DFH_LAUNCH_CHECK();
-      DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
-      // ---- panel solve, then the next block column --------------------------------------
+      DFH_HIP(hipEventRecord(e_panel, P));
+      // ---- the next block column, so that the next panel can start before the trailing update ----
       if (rem > 0) {
-        double* A21 = A + (k0 + nbk) * lda + k0;          // rem x nbk
-        for (int b = 0; b < nbatch; ++b)
-          DFH_TRY(copy_matrix(ctx, A21 + b * strideA, lda, W + b * strideW, NB, rem, nbk));
-        GemmBatch bt;
-        bt.count = nbatch; bt.sA = strideW; bt.sB = strideInv; bt.sCout = strideA;
-        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, rem, nbk, nbk, 1.0, W, NB, Linv, NB, 0.0, nullptr, 0, A21, lda, &bt));
-        DFH_HIP(hipEventRecord(e_trsm, P));
+        const double* A21 = A + (k0 + nbk) * lda + k0;    // rem x nbk, final
         if (e_trail_prev) DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
         const int64_t nb1 = rem < NB ? rem : NB;
         double* C1 = A + (k0 + nbk) * lda + (k0 + nbk);   // rows k+1.., block column k+1
         DFH_TRY(gemm_f64(ctx, 0, rem, nb1, nbk, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
       }
     }
+    {
+      // ---- off the chain: factor blocks into place, 64-block inverses, 512-block inverse ----
+      StreamSwap on_x(ctx, X);
+      DFH_HIP(hipStreamWaitEvent(X, e_panel, 0));
+      if (Linv)
+        for (int b = 0; b < nbatch; ++b) DFH_HIP(hipMemsetAsync(Linv + b * strideInv, 0, (size_t)NB * NB * 8, X));
+      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, X,
+                         D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
+                         (long)strideL);
+      DFH_LAUNCH_CHECK();
+      if (Linv) DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
+      DFH_HIP(hipEventRecord(e_aux, X));
+    }
     if (rem > NB) {
       const int64_t rem2 = rem - NB;
       const double* A31 = A + (k0 + nbk + NB) * lda + k0;                // rows k+2.. of the panel
       double* A33 = A + (k0 + nbk + NB) * lda + (k0 + nbk + NB);
-      DFH_HIP(hipStreamWaitEvent(M, e_trsm, 0));
+      DFH_HIP(hipStreamWaitEvent(M, e_panel, 0));
       {
         // DFH_CHOL_HALF_OCC=1: trailing update at one workgroup per CU, leaving slots for the
         // latency-bound panel kernels of the look-ahead stream
@@ -527,6 +540,11 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   }
   DFH_HIP(hipEventRecord(ev_done, P));
   DFH_HIP(hipStreamWaitEvent(M, ev_done, 0));
+  {
+    hipEvent_t e_aux_last;
+    DFH_TRY(ctx_event(ctx, 4 + 3 * (nblk - 1), &e_aux_last));
+    DFH_HIP(hipStreamWaitEvent(M, e_aux_last, 0));
+  }
 
   DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8 * (size_t)nbatch, hipMemcpyDeviceToHost, M));
   DFH_HIP(hipStreamSynchronize(M));

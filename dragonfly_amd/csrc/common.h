@@ -52,6 +52,7 @@ struct dfh_ctx {
   hipStream_t main_stream = nullptr; // (== stream except inside StreamSwap scopes)
   hipStream_t side = nullptr;        // high-priority panel stream of the look-ahead Cholesky
   hipStream_t bulk = nullptr;        // low-priority stream: next chunk's cross kernel + TRSM (TS)
+  hipStream_t aux = nullptr;         // off-critical-path work of the factorisation (block inverses)
   std::vector<hipEvent_t> evpool;    // untimed events for cross-stream ordering
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)

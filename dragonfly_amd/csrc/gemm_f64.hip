@@ -389,6 +389,7 @@ extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out)
     DFH_HIP(hipStreamSynchronize(ctx->main_stream));
     DFH_HIP(hipStreamSynchronize(ctx->side));
     DFH_HIP(hipStreamSynchronize(ctx->bulk));
+    DFH_HIP(hipStreamSynchronize(ctx->aux));
     std::vector<std::pair<float, float>> iv[8];
     for (size_t i = 0; i < ctx->gemm_used; ++i) {
       float ms = 0.f, t0 = 0.f;
@@ -418,6 +419,7 @@ extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out)
     DFH_HIP(hipStreamSynchronize(ctx->main_stream));
     DFH_HIP(hipStreamSynchronize(ctx->side));
     DFH_HIP(hipStreamSynchronize(ctx->bulk));
+    DFH_HIP(hipStreamSynchronize(ctx->aux));
     DFH_HIP(hipEventRecord(ctx->gemm_base, ctx->main_stream));
   }
   return DFH_OK;

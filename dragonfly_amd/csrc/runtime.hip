@@ -69,6 +69,7 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     DFH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     DFH_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
     DFH_HIP(hipStreamCreateWithPriority(&ctx->bulk, hipStreamNonBlocking, least));
+    DFH_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
   }
   DFH_HIP(hipEventCreate(&ctx->ev0));
   DFH_HIP(hipEventCreate(&ctx->ev1));
@@ -110,6 +111,7 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   for (auto& r : ctx->gemm_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->bulk) (void)hipStreamDestroy(ctx->bulk);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
 }
@@ -119,6 +121,7 @@ extern "C" int dfh_sync(dfh_ctx* ctx) {
   DFH_HIP(hipStreamSynchronize(ctx->stream));
   DFH_HIP(hipStreamSynchronize(ctx->side));
   DFH_HIP(hipStreamSynchronize(ctx->bulk));
+  DFH_HIP(hipStreamSynchronize(ctx->aux));
   return DFH_OK;
 }
 
@@ -210,6 +213,8 @@ int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out) {
       DFH_HIP(hipStreamSynchronize(ctx->main_stream));
       DFH_HIP(hipStreamSynchronize(ctx->side));
       DFH_HIP(hipStreamSynchronize(ctx->bulk));
+      DFH_HIP(hipStreamSynchronize(ctx->aux));
+  DFH_HIP(hipStreamSynchronize(ctx->aux));
       DFH_HIP(hipFree(b.p));
       b.p = nullptr; b.bytes = 0;
     }
