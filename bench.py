@@ -53,10 +53,11 @@ def make_problem(rank):
 
 def cpu_baseline(X, Y, bw, mean_c, noise, budget_note=True):
   """ The oracle (NumPy/SciPy restatement of the reference path) on a bounded sample, all host
-      cores through OpenBLAS: fit at n_s = 6144 and one Thompson block of 2048 candidates, each
+      cores through OpenBLAS: fit at n_s = 12288 and one full Thompson block of 4096 candidates
+      (about 10-20 s of CPU work), each
       stage scaled to the full step by its algorithmic work (SURVEY.md section 8d formulas). """
   from oracle import ref_numpy as O
-  n_s, b_s = 6144, 2048
+  n_s, b_s = 12288, 4096
   Xs, Ys = X[:n_s], Y[:n_s]
   kern = O.KernelSpec('se', DIM, float(Y.var()), bw)
   t = {}
@@ -113,7 +114,7 @@ def cpu_baseline(X, Y, bw, mean_c, noise, budget_note=True):
 
 def pmc_traffic():
   """ HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over
-      this same command (profiles/r01_pmc_traffic.json, written by tools/rocpd_pmc.py); None when
+      this same command (profiles/r01_pmc_traffic.json, written by tools/rocpd_pmc_traffic.py); None when
       that file is absent.  Counters cannot be collected inside the timed run itself. """
   path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
   try:
