@@ -25,7 +25,22 @@ constexpr int KM_BM = 128;
 constexpr int KM_KC = 32;          // packed columns per LDS chunk
 constexpr int KM_KP = 34;          // LDS row stride (doubles); 34 = 2 mod 32 -> conflict-free b64 frag reads
 
+// exp_fast's constants travel as kernel arguments (scalar loads into SGPR pairs, unknown to the
+// compiler): with literal coefficients the compiler emits v_fmac_f64 and re-materialises every
+// 64-bit constant with two v_mov_b32 per Horner step -- 18 extra VALU instructions per element,
+// over a third of the VALU-bound epilogue.
+struct ExpConsts {
+  double log2e, ln2_hi, ln2_lo;
+  double c[12];
+};
+static const ExpConsts kExpConsts = {
+    1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    {0x1.af631d0059becp-26, 0x1.28b4057f44145p-22, 0x1.71ddf5749d126p-19, 0x1.a01991ac8730ap-16,
+     0x1.a01a01b14378fp-13, 0x1.6c16c187fbe02p-10, 0x1.111111110f225p-7, 0x1.555555554f0cfp-5,
+     0x1.555555555555ap-3, 0x1.0000000000011p-1, 1.0, 1.0}};
+
 struct KmArgs {
+  ExpConsts ec;
   const double* Xp1; const double* Np1;
   const double* Xp2; const double* Np2;
   int n1, n2, P, n_parts_total;
@@ -47,35 +62,26 @@ __device__ __forceinline__ double ipow(double m, int k) {
 // x = n ln2 + r, |r| <= ln2/2, degree-11 polynomial (Chebyshev-node interpolant of exp on that
 // interval: 4e-18 approximation error, ~0.7 ulp after Horner in fp64), scaled by v_ldexp_f64.
 // 17 fp64 VALU ops -- the epilogue of the kernel-matrix build is VALU-bound, so this is the lever.
-__device__ __forceinline__ double exp_fast(double x) {
-  const double n = rint(x * 1.4426950408889634);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
-  r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = 0x1.af631d0059becp-26;
-  p = fma(p, r, 0x1.28b4057f44145p-22);
-  p = fma(p, r, 0x1.71ddf5749d126p-19);
-  p = fma(p, r, 0x1.a01991ac8730ap-16);
-  p = fma(p, r, 0x1.a01a01b14378fp-13);
-  p = fma(p, r, 0x1.6c16c187fbe02p-10);
-  p = fma(p, r, 0x1.111111110f225p-7);
-  p = fma(p, r, 0x1.555555554f0cfp-5);
-  p = fma(p, r, 0x1.555555555555ap-3);
-  p = fma(p, r, 0x1.0000000000011p-1);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
+__device__ __forceinline__ double exp_fast(double x, const ExpConsts& ec) {
+  const double n = rint(x * ec.log2e);
+  double r = fma(-n, ec.ln2_hi, x);
+  r = fma(-n, ec.ln2_lo, r);
+  double p = ec.c[0];
+#pragma unroll
+  for (int i = 1; i < 12; ++i) p = fma(p, r, ec.c[i]);
   // |x| beyond the double exponent range: n saturates, ldexp returns 0 / inf; NaN propagates
   return ldexp(p, (int)fmax(fmin(n, 4000.0), -4000.0));
 }
 
-__device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq) {
+__device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq, const ExpConsts& ec) {
   if (pd.kind == DFH_KERNEL_SE) {
-    return pd.scale_c * exp_fast(-dsq / 2);                // kernel.py:176
+    return pd.scale_c * exp_fast(-dsq / 2, ec);                // kernel.py:176
   } else if (pd.kind == DFH_KERNEL_MATERN) {
     const double dist = sqrt(dsq);                         // kernel.py:296
     const double mult = pd.s8 * dist;                      // kernel.py:265
     double u = 0.0;
     for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * ipow(mult, pd.p - i);   // kernel.py:266
-    u *= (pd.gfac * exp_fast(-pd.s2 * dist));              // kernel.py:268-269
+    u *= (pd.gfac * exp_fast(-pd.s2 * dist, ec));              // kernel.py:268-269
     return pd.scale_c * u;                                 // kernel.py:298
   }
   return dsq;                                              // DFH_KERNEL_DIST
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
     }
 
     // distances -> kernel values for this part
+    const ExpConsts& ec = p.ec;                  // kernel arguments: scalar loads, SGPR-resident
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
           const int lc = wn * TJ * 16 + j * 16 + l15;
           double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];     // general_utils.py:66-68
           dsq = dsq < 0.0 ? 0.0 : dsq;                           // np.clip(.,0,inf), NaN kept
-          const double kv = kern_eval(pd, dsq);
+          const double kv = kern_eval(pd, dsq, ec);
           if (MULTI) res[i][j][r] += kv;                          // kernel.py:493
           else acc[i][j][r] = kv;
         }
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
   // kernel.py:176).  The diagonal term only exists in diagonal tiles.
   const bool se = (pd.kind == DFH_KERNEL_SE);
   const bool diag_tile = SYM && (ti == tj);
+  const ExpConsts& ec = p.ec;                    // kernel arguments: scalar loads, SGPR-resident
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -308,11 +316,11 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
         if (se) {
           double t = acc[i][j][r] - (0.5 * nb[lc] + 0.5 * nai);
           t = t > 0.0 ? 0.0 : t;
-          kv = pd.scale_c * exp_fast(t);
+          kv = pd.scale_c * exp_fast(t, ec);
         } else {
           double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];
           dsq = dsq < 0.0 ? 0.0 : dsq;
-          kv = kern_eval(pd, dsq);
+          kv = kern_eval(pd, dsq, ec);
         }
         if (diag_tile && lr == lc) kv += p.diag_add;
         acc[i][j][r] = kv;
@@ -638,6 +646,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   if (n1 <= 0 || n2 <= 0) return DFH_OK;
   DFH_ARG(n1 < (1LL << 31) && n2 < (1LL << 31));
   KmArgs a;
+  a.ec = kExpConsts;
   a.Xp1 = Xp1; a.Np1 = Np1; a.Xp2 = Xp2; a.Np2 = Np2;
   a.n1 = (int)n1; a.n2 = (int)n2; a.P = kd.P; a.n_parts_total = kd.n_parts;
   a.parts = kd.d_parts; a.part_lo = part_lo; a.part_hi = part_hi;
