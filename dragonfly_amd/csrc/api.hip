@@ -428,24 +428,26 @@ extern "C" int dfh_cholesky(dfh_ctx* ctx, double* A, int64_t n, int64_t* info_pi
 // when a retry is needed (the failed factorisation destroys it).
 template <typename Rebuild>
 static int stable_cholesky_device(dfh_ctx* ctx, double* dL, int64_t n, double* keep_inv, bool allow_jitter,
-                                  Rebuild rebuild, int32_t* jitter_power, double* jitter_added) {
+                                  Rebuild rebuild, int32_t* jitter_power, double* jitter_added,
+                                  int64_t ld = 0) {
+  if (ld == 0) ld = n;
   if (jitter_power) *jitter_power = INT32_MIN;
   if (jitter_added) *jitter_added = 0.0;
   int64_t piv = 0;
-  int rc = cholesky_device(ctx, dL, n, n, keep_inv, &piv);
+  int rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv);
   if (rc != DFH_ERR_NOT_PD || !allow_jitter) return rc;
   // general_utils.py:183-203
   DFH_TRY(rebuild());
   double max_M = 0.0;
-  DFH_TRY(diag_max(ctx, dL, n, n, &max_M));
+  DFH_TRY(diag_max(ctx, dL, n, ld, &max_M));
   bool first = true;
   for (int p = -11; p < 5; ++p) {
     double diag_noise;
     ladder_pow(p, max_M, &diag_noise);
     if (!first) DFH_TRY(rebuild());
     first = false;
-    DFH_TRY(add_diag(ctx, dL, n, n, diag_noise));       // M + diag_noise * np.eye(n)
-    rc = cholesky_device(ctx, dL, n, n, keep_inv, &piv);
+    DFH_TRY(add_diag(ctx, dL, n, ld, diag_noise));      // M + diag_noise * np.eye(n)
+    rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv);
     if (rc == DFH_OK) {
       if (jitter_power) *jitter_power = p;
       if (jitter_added) *jitter_added = diag_noise;
@@ -707,6 +709,45 @@ __global__ void k_centre(const double* __restrict__ y, double c, double* __restr
   if (i < n) { const double v = y[i] - c; out[i] = v; out2[i] = v; }
 }
 
+// n <= CHOL_NB (one diagonal block): the whole solve stage of a candidate in one workgroup --
+// yc = y - m, z = L^-1 yc, alpha = L^-T z through the explicit block inverse, then
+// out = {sum log L_ii, yc . alpha}.  blockIdx.x = candidate.
+__global__ __launch_bounds__(256) void k_lml_finish_small(const double* __restrict__ L, long sL, long ldl,
+                                                          const double* __restrict__ inv, long sInv,
+                                                          const double* __restrict__ y,
+                                                          const double* __restrict__ means, int n,
+                                                          double* __restrict__ out2) {
+  __shared__ double yc[CHOL_NB], z[CHOL_NB], red[8];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  L += (long)c * sL;
+  inv += (long)c * sInv;
+  const double mean = means[c];
+  for (int i = tid; i < n; i += 256) yc[i] = y[i] - mean;
+  __syncthreads();
+  for (int i = wave; i < n; i += 4) {                       // z = Linv yc (lower triangle), wave per row
+    const double* row = inv + (long)i * CHOL_NB;
+    double s = 0.0;
+    for (int j = lane; j <= i; j += 64) s = fma(row[j], yc[j], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) z[i] = s;
+  }
+  __syncthreads();
+  double ld = 0.0, dt = 0.0;
+  for (int j = tid; j < n; j += 256) {                      // alpha_j = sum_{i >= j} Linv[i][j] z[i]
+    double s = 0.0;
+    for (int i = j; i < n; ++i) s = fma(inv[(long)i * CHOL_NB + j], z[i], s);
+    dt = fma(yc[j], s, dt);
+    ld += log(L[(long)j * ldl + j]);
+  }
+  for (int off = 32; off > 0; off >>= 1) { ld += __shfl_down(ld, off, 64); dt += __shfl_down(dt, off, 64); }
+  if (lane == 0) { red[wave] = ld; red[4 + wave] = dt; }
+  __syncthreads();
+  if (tid == 0) {
+    out2[2 * c] = (red[0] + red[1]) + (red[2] + red[3]);
+    out2[2 * c + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+
 extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* X,
                                 int64_t n, int64_t d, const double* y, const double* mean_consts,
                                 const double* noise_vars, int flags, double* lml_out,
@@ -717,7 +758,8 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   DFH_HIP(hipSetDevice(ctx->device));
   const int64_t NB = CHOL_NB;
   const int64_t nblk = (n + NB - 1) / NB;
-  const int64_t strideK = n * n, strideInv = nblk * NB * NB;
+  const int64_t ldK = (n + 1) & ~(int64_t)1;                 // even leading dimension: 16-byte row starts
+  const int64_t strideK = n * ldK, strideInv = nblk * NB * NB;
   // group size: up to CHOL_MAX_BATCH matrices and (DFH_LML_GROUP_GIB, default 8) GiB of Gram
   // matrices at a time.  Measured ms per candidate at 2 / 8 GiB: n=4096 1.55 / 1.07, n=16384
   // 42.6 (one at a time) / 30.0 (four in lock-step: the panel chains of the four interleave).
@@ -725,88 +767,106 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   const int64_t by_mem = std::max<int64_t>(1, (int64_t)(group_gib * 1073741824.0 / ((double)strideK * 8.0)));
   const int G = (int)std::min<int64_t>(std::min<int64_t>(nb, CHOL_MAX_BATCH), by_mem);
   std::vector<KernDev> kds((size_t)G);       // device images live in one scratch blob: nothing to free
-  auto body = [&]() -> int {
-    const double *dX = nullptr, *dy = nullptr;
-    DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
-    DFH_TRY(to_device(ctx, y, (size_t)n * 8, SCR_STAGE_B, &dy));
-    double *Kb = nullptr, *invb = nullptr, *vecs = nullptr, *red = nullptr;
-    DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * strideK * 8, (void**)&Kb));
-    DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)G * strideInv * 8, (void**)&invb));
-    DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)G * n * 8 * 2, (void**)&vecs));
-    DFH_TRY(scratch_get(ctx, SCR_OUT2, (size_t)std::max(256, G * 16), (void**)&red));   // SCR_RED belongs to the gemv partials
-    std::vector<double> hred((size_t)G * 2);
-    for (int c0 = 0; c0 < nb; c0 += G) {
-      const int g = std::min(G, nb - c0);
-      // packed inputs of the group's candidates (pad-to-4 columns per kernel part)
-      int64_t Pmax = 0, parts_max = 0;
-      size_t blob_bytes = 0;
-      for (int c = 0; c < g; ++c) {
-        kds[c] = KernDev();
-        DFH_TRY(kerndev_build_host(&descs[c0 + c], &kds[c]));
-        Pmax = std::max<int64_t>(Pmax, kds[c].P);
-        parts_max = std::max<int64_t>(parts_max, kds[c].n_parts);
-        blob_bytes += kerndev_blob_bytes(kds[c]);
-      }
-      void* blob = nullptr;
-      DFH_TRY(scratch_get(ctx, SCR_AUG2, blob_bytes, &blob));
-      DFH_TRY(kerndev_upload_many(ctx, kds.data(), g, blob, blob_bytes));
-      double *Xpb = nullptr, *Npb = nullptr;
-      DFH_TRY(scratch_get(ctx, SCR_XS, (size_t)g * n * Pmax * 8, (void**)&Xpb));
-      DFH_TRY(scratch_get(ctx, SCR_XS2, (size_t)g * n * parts_max * 8, (void**)&Npb));
-      auto build_M = [&](int c) -> int {           // K + noise_var * I     (gp_core.py:843)
-        double* Xp = Xpb + (int64_t)c * n * Pmax; double* Np = Npb + (int64_t)c * n * parts_max;
-        return kernmat_packed(ctx, kds[c], 0, kds[c].n_parts, true, Xp, Np, n, Xp, Np, n, true,
-                              noise_vars[c0 + c], Kb + c * strideK, n);
-      };
-      {
-        SectionTimer t(ctx, DFH_T_KERNMAT);
+  const double *dX = nullptr, *dy = nullptr;
+  DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
+  DFH_TRY(to_device(ctx, y, (size_t)n * 8, SCR_STAGE_B, &dy));
+  double *Kb = nullptr, *invb = nullptr, *vecs = nullptr, *red = nullptr, *dpar = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * strideK * 8, (void**)&Kb));
+  DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)G * strideInv * 8, (void**)&invb));
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)G * n * 8 * 2, (void**)&vecs));
+  DFH_TRY(scratch_get(ctx, SCR_OUT2, (size_t)std::max(256, G * 16), (void**)&red));   // SCR_RED belongs to the gemv partials
+  DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)std::max(256, G * 16), (void**)&dpar));   // per candidate {noise, mean}
+  std::vector<double> hred((size_t)G * 2), hpar((size_t)G * 2);
+  for (int c0 = 0; c0 < nb; c0 += G) {
+    const int g = std::min(G, nb - c0);
+    // packed inputs of the group's candidates (pad-to-4 columns per kernel part)
+    int64_t Pmax = 0, parts_max = 0;
+    size_t blob_bytes = 0;
+    bool uniform = true;                     // structurally identical single-part kernels
+    for (int c = 0; c < g; ++c) {
+      kds[c] = KernDev();
+      DFH_TRY(kerndev_build_host(&descs[c0 + c], &kds[c]));
+      Pmax = std::max<int64_t>(Pmax, kds[c].P);
+      parts_max = std::max<int64_t>(parts_max, kds[c].n_parts);
+      blob_bytes += kerndev_blob_bytes(kds[c]);
+      uniform = uniform && !kds[c].multi && kds[c].n_parts == 1 && kds[c].P == kds[0].P &&
+                kerndev_blob_bytes(kds[c]) == kerndev_blob_bytes(kds[0]);
+    }
+    void* blob = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_AUG2, blob_bytes, &blob));
+    DFH_TRY(kerndev_upload_many(ctx, kds.data(), g, blob, blob_bytes));
+    double *Xpb = nullptr, *Npb = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_XS, (size_t)g * n * Pmax * 8, (void**)&Xpb));
+    DFH_TRY(scratch_get(ctx, SCR_XS2, (size_t)g * n * parts_max * 8, (void**)&Npb));
+    const int64_t sXp = n * Pmax, sNp = n * parts_max;
+    for (int c = 0; c < g; ++c) {
+      hpar[c] = noise_vars[c0 + c];
+      hpar[g + c] = mean_consts ? mean_consts[c0 + c] : 0.0;
+    }
+    DFH_HIP(hipMemcpyAsync(dpar, hpar.data(), (size_t)g * 16, hipMemcpyHostToDevice, ctx->stream));
+    auto build_M = [&](int c) -> int {           // K + noise_var * I     (gp_core.py:843)
+      double* Xp = Xpb + c * sXp; double* Np = Npb + c * sNp;
+      return kernmat_packed(ctx, kds[c], 0, kds[c].n_parts, true, Xp, Np, n, Xp, Np, n, true,
+                            noise_vars[c0 + c], Kb + c * strideK, ldK);
+    };
+    {
+      SectionTimer t(ctx, DFH_T_KERNMAT);
+      if (uniform) {
+        // one launch each for the whole group: pack, norms, Gram matrices
+        const int64_t sBlob = (int64_t)kerndev_blob_bytes(kds[0]);
+        DFH_TRY(pack_scaled(ctx, kds[0], 0, 1, false, dX, n, d, Xpb, Npb, g, sBlob, sXp, sNp));
+        DFH_TRY(kernmat_sym_batch(ctx, kds[0], g, sBlob, Xpb, sXp, Npb, sNp, n, dpar, Kb, strideK, ldK));
+      } else {
         for (int c = 0; c < g; ++c) {
-          DFH_TRY(pack_scaled(ctx, kds[c], 0, kds[c].n_parts, false, dX, n, d, Xpb + (int64_t)c * n * Pmax,
-                              Npb + (int64_t)c * n * parts_max));
+          DFH_TRY(pack_scaled(ctx, kds[c], 0, kds[c].n_parts, false, dX, n, d, Xpb + c * sXp, Npb + c * sNp));
           DFH_TRY(build_M(c));
         }
       }
-      {
-        SectionTimer t(ctx, DFH_T_CHOL);
-        int64_t piv[CHOL_MAX_BATCH] = {0};
-        int rc = cholesky_device(ctx, Kb, n, n, invb, piv, g, strideK, strideInv);
-        if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
-        for (int c = 0; c < g; ++c) {
-          if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;
-          if (piv[c] == 0) continue;
-          if (flags & DFH_FIT_NO_JITTER) {
-            dfh_set_error("Matrix is not positive definite (candidate %d, pivot %lld)", c0 + c, (long long)piv[c]);
-            return DFH_ERR_NOT_PD;
-          }
-          auto rebuild = [&]() -> int { return build_M(c); };
-          DFH_TRY(rebuild());
-          int32_t jp = INT32_MIN;
-          DFH_TRY(stable_cholesky_device(ctx, Kb + c * strideK, n, invb + c * strideInv, true, rebuild, &jp, nullptr));
-          if (jitter_powers) jitter_powers[c0 + c] = jp;
+    }
+    {
+      SectionTimer t(ctx, DFH_T_CHOL);
+      int64_t piv[CHOL_MAX_BATCH] = {0};
+      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv);
+      if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
+      for (int c = 0; c < g; ++c) {
+        if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;
+        if (piv[c] == 0) continue;
+        if (flags & DFH_FIT_NO_JITTER) {
+          dfh_set_error("Matrix is not positive definite (candidate %d, pivot %lld)", c0 + c, (long long)piv[c]);
+          return DFH_ERR_NOT_PD;
         }
+        auto rebuild = [&]() -> int { return build_M(c); };
+        DFH_TRY(rebuild());
+        int32_t jp = INT32_MIN;
+        DFH_TRY(stable_cholesky_device(ctx, Kb + c * strideK, n, invb + c * strideInv, true, rebuild, &jp, nullptr, ldK));
+        if (jitter_powers) jitter_powers[c0 + c] = jp;
       }
-      {
-        SectionTimer t(ctx, DFH_T_SOLVE);
+    }
+    {
+      SectionTimer t(ctx, DFH_T_SOLVE);
+      if (n <= NB) {
+        hipLaunchKernelGGL(k_lml_finish_small, dim3((unsigned)g), dim3(256), 0, ctx->stream, Kb, (long)strideK,
+                           (long)ldK, invb, (long)strideInv, dy, dpar + g, (int)n, red);
+        DFH_LAUNCH_CHECK();
+      } else {
         for (int c = 0; c < g; ++c) {
           double* yc = vecs + (int64_t)c * 2 * n;
           double* alpha = yc + n;
-          const double mc = mean_consts ? mean_consts[c0 + c] : 0.0;
-          hipLaunchKernelGGL(k_centre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dy, mc, yc, alpha, (long)n);
+          hipLaunchKernelGGL(k_centre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dy, hpar[g + c], yc, alpha, (long)n);
           DFH_LAUNCH_CHECK();
           // alpha = L^T \ (L \ (y - m))      (gp_core.py:161-163)
-          DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, n, invb + c * strideInv, alpha));
-          DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, n, invb + c * strideInv, alpha));
-          DFH_TRY(logdet_and_dot_device(ctx, Kb + c * strideK, n, n, yc, alpha, red + 2 * c));
+          DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha));
+          DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha));
+          DFH_TRY(logdet_and_dot_device(ctx, Kb + c * strideK, n, ldK, yc, alpha, red + 2 * c));
         }
-        DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
-        DFH_HIP(hipStreamSynchronize(ctx->stream));
-        for (int c = 0; c < g; ++c)     // gp_core.py:224-226
-          lml_out[c0 + c] = -0.5 * hred[2 * c + 1] - hred[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);
       }
+      DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipStreamSynchronize(ctx->stream));
+      for (int c = 0; c < g; ++c)     // gp_core.py:224-226
+        lml_out[c0 + c] = -0.5 * hred[2 * c + 1] - hred[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);
     }
-    return DFH_OK;
-  };
-  return body();
+  }
+  return DFH_OK;
 }
 
 extern "C" int dfh_gp_get(dfh_gp* gp, int what, double* out) {

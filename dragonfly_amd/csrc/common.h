@@ -195,8 +195,14 @@ double kerndev_part_kxx(const KernDev& kd, int part);
 // Xp[n][P] / Np[n][n_parts] for parts [part_lo, part_hi) (other parts' columns untouched).
 // pre_gathered: X holds only the columns of part_lo (ldx >= |cols|), as in add-UCB group
 // candidates (gpb_acquisitions.py:164-166).
+// count > 1: a lock-step batch -- kernel images sBlob bytes apart (kd is the first), outputs sXp /
+// sNp doubles apart.
 int pack_scaled(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool pre_gathered,
-                const double* X, int64_t n, int64_t ldx, double* Xp, double* Np);
+                const double* X, int64_t n, int64_t ldx, double* Xp, double* Np, int count = 1,
+                int64_t sBlob = 0, int64_t sXp = 0, int64_t sNp = 0);
+int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob, const double* Xp,
+                      int64_t sXp, const double* Np, int64_t sNp, int64_t n, const double* d_diag_adds,
+                      double* K, int64_t sK, int64_t ldk);
 
 // K[n1 x n2] (ldk) = sum over parts [part_lo,part_hi) of k_part (times outer scale if multi).
 // symmetric: Xp2/Np2 == Xp1/Np1 and diag_add is added on the diagonal.

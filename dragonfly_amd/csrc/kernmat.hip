@@ -50,6 +50,11 @@ struct KmArgs {
   int apply_outer, symmetric;
   double diag_add;
   double* K; long ldk;
+  // lock-step batch over blockIdx.z (symmetric single-part kernel only): element strides of the
+  // packed inputs / output, byte stride between the device images of the kernels, one diagonal
+  // term per batch element (NULL: diag_add)
+  long sXp, sNp, sK, sBlob;
+  const double* diag_adds;
 };
 
 __device__ __forceinline__ double ipow(double m, int k) {
@@ -246,9 +251,14 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
     ti = blockIdx.y; tj = blockIdx.x;
   }
   const long m0 = (long)ti * TS, n0 = (long)tj * TS;
-  const PartDev& pd = p.parts[p.part_lo];
-  const double* __restrict__ XpB = SYM ? p.Xp1 : p.Xp2;
-  const double* __restrict__ NpB = SYM ? p.Np1 : p.Np2;
+  const long bz = SYM ? (long)blockIdx.z : 0;       // batch element (strides are 0 for a single matrix)
+  const PartDev& pd = reinterpret_cast<const PartDev*>(reinterpret_cast<const char*>(p.parts) + bz * p.sBlob)[p.part_lo];
+  const double* __restrict__ XpA = p.Xp1 + bz * p.sXp;
+  const double* __restrict__ NpA = p.Np1 + bz * p.sNp;
+  double* __restrict__ Kout = p.K + bz * p.sK;
+  const double diag_add = p.diag_adds ? p.diag_adds[bz] : p.diag_add;
+  const double* __restrict__ XpB = SYM ? XpA : p.Xp2;
+  const double* __restrict__ NpB = SYM ? NpA : p.Np2;
   const long nB = SYM ? p.n1 : p.n2;
 
   double4_t acc[WT][WT];
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
       const int r = idx / kh, c2 = (idx - r * kh) * 2;
       const long rowa = m0 + r, rowb = n0 + r;
       double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
-      if (rowa < p.n1) va = *reinterpret_cast<const double2_t*>(p.Xp1 + rowa * p.P + pd.poff + k0 + c2);
+      if (rowa < p.n1) va = *reinterpret_cast<const double2_t*>(XpA + rowa * p.P + pd.poff + k0 + c2);
       if (rowb < nB) vb = *reinterpret_cast<const double2_t*>(XpB + rowb * p.P + pd.poff + k0 + c2);
       *reinterpret_cast<double2_t*>(As + r * KP + c2) = va;
       *reinterpret_cast<double2_t*>(Bs + r * KP + c2) = vb;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
     if (k0 == 0) {
       if (tid < TS) {
         const long row = m0 + tid;
-        na[tid] = row < p.n1 ? p.Np1[row * p.n_parts_total + p.part_lo] : 0.0;
+        na[tid] = row < p.n1 ? NpA[row * p.n_parts_total + p.part_lo] : 0.0;
       } else if (tid - TS < TS) {
         const long row = n0 + tid - TS;
         nb[tid - TS] = row < nB ? NpB[row * p.n_parts_total + p.part_lo] : 0.0;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
           dsq = dsq < 0.0 ? 0.0 : dsq;
           kv = kern_eval(pd, dsq, ec);
         }
-        if (diag_tile && lr == lc) kv += p.diag_add;
+        if (diag_tile && lr == lc) kv += diag_add;
         acc[i][j][r] = kv;
       }
     }
@@ -357,11 +367,11 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
       const long row = row_base + r, col = col_base + c2;
       const long nrow = mirror ? nB : p.n1, ncol = mirror ? p.n1 : nB;
       if (row < nrow && col + 1 < ncol) {
-        *reinterpret_cast<double2_t*>(p.K + row * p.ldk + col) =
+        *reinterpret_cast<double2_t*>(Kout + row * p.ldk + col) =
             *reinterpret_cast<const double2_t*>(St + r * SP + c2);
       } else if (row < nrow && col < ncol) {
-        p.K[row * p.ldk + col] = St[r * SP + c2];
-        if (col + 1 < ncol) p.K[row * p.ldk + col + 1] = St[r * SP + c2 + 1];
+        Kout[row * p.ldk + col] = St[r * SP + c2];
+        if (col + 1 < ncol) Kout[row * p.ldk + col + 1] = St[r * SP + c2 + 1];
       }
     }
   }
@@ -370,7 +380,11 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
 // ---- packing -----------------------------------------------------------------------------
 __global__ void k_pack_cols(const double* __restrict__ X, long n, long ldx, int P, int c_lo, int c_hi,
                             const int* __restrict__ cols, const double* __restrict__ bw,
-                            double* __restrict__ Xp) {
+                            double* __restrict__ Xp, long sBlob, long sXp) {
+  // batch element blockIdx.y: its kernel image sits sBlob bytes further, its output sXp doubles
+  cols = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cols) + (long)blockIdx.y * sBlob);
+  bw = reinterpret_cast<const double*>(reinterpret_cast<const char*>(bw) + (long)blockIdx.y * sBlob);
+  Xp += (long)blockIdx.y * sXp;
   const int w = c_hi - c_lo;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = n * w;
@@ -402,7 +416,12 @@ __device__ double np_sumsq(const double* a, int n) {
 
 __global__ void k_pack_norms(const double* __restrict__ Xp, long n, int P, int n_parts_total,
                              const PartDev* __restrict__ parts, const int* __restrict__ cols,
-                             int part_lo, int part_hi, double* __restrict__ Np) {
+                             int part_lo, int part_hi, double* __restrict__ Np, long sBlob, long sXp,
+                             long sNp) {
+  parts = reinterpret_cast<const PartDev*>(reinterpret_cast<const char*>(parts) + (long)blockIdx.y * sBlob);
+  cols = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cols) + (long)blockIdx.y * sBlob);
+  Xp += (long)blockIdx.y * sXp;
+  Np += (long)blockIdx.y * sNp;
   const int np = part_hi - part_lo;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = n * np;
@@ -619,8 +638,9 @@ void kerndev_free(KernDev* kd) {
 double kerndev_part_kxx(const KernDev& kd, int part) { return part_value_at_zero(kd.parts[part]); }
 
 int pack_scaled(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool pre_gathered,
-                const double* X, int64_t n, int64_t ldx, double* Xp, double* Np) {
-  if (n <= 0) return DFH_OK;
+                const double* X, int64_t n, int64_t ldx, double* Xp, double* Np, int count,
+                int64_t sBlob, int64_t sXp, int64_t sNp) {
+  if (n <= 0 || count <= 0) return DFH_OK;
   DFH_ARG(part_lo >= 0 && part_hi <= kd.n_parts && part_lo < part_hi);
   DFH_ARG(!pre_gathered || part_hi == part_lo + 1);
   const int c_lo = kd.parts[part_lo].poff;
@@ -629,12 +649,39 @@ int pack_scaled(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool 
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   // pre-gathered input: local column index c - poff ; d_lcols holds that mapping
-  hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, (long)n,
-                     (long)ldx, kd.P, c_lo, c_hi, pre_gathered ? kd.d_lcols : kd.d_cols, kd.d_bw, Xp);
+  hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, ctx->stream, X, (long)n,
+                     (long)ldx, kd.P, c_lo, c_hi, pre_gathered ? kd.d_lcols : kd.d_cols, kd.d_bw, Xp,
+                     (long)sBlob, (long)sXp);
   DFH_LAUNCH_CHECK();
   const int64_t tn = n * (part_hi - part_lo);
-  hipLaunchKernelGGL(k_pack_norms, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, ctx->stream,
-                     Xp, (long)n, kd.P, kd.n_parts, kd.d_parts, kd.d_cols, part_lo, part_hi, Np);
+  hipLaunchKernelGGL(k_pack_norms, dim3((unsigned)((tn + 255) / 256), (unsigned)count), dim3(256), 0, ctx->stream,
+                     Xp, (long)n, kd.P, kd.n_parts, kd.d_parts, kd.d_cols, part_lo, part_hi, Np,
+                     (long)sBlob, (long)sXp, (long)sNp);
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
+
+// `count` symmetric Gram matrices of structurally identical single-part kernels in one launch
+// (blockIdx.z): kernel images sBlob bytes apart starting at kd's, packed inputs sXp / sNp doubles
+// apart, outputs sK doubles apart, diag_adds[count] on the device.  Needs an even ldk.
+int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob, const double* Xp,
+                      int64_t sXp, const double* Np, int64_t sNp, int64_t n, const double* d_diag_adds,
+                      double* K, int64_t sK, int64_t ldk) {
+  if (n <= 0 || count <= 0) return DFH_OK;
+  DFH_ARG(!kd.multi && kd.n_parts == 1 && (ldk & 1) == 0 && (sK & 1) == 0 &&
+          (reinterpret_cast<uintptr_t>(K) & 15) == 0 && count <= 65535);
+  KmArgs a;
+  a.ec = kExpConsts;
+  a.Xp1 = Xp; a.Np1 = Np; a.Xp2 = Xp; a.Np2 = Np;
+  a.n1 = (int)n; a.n2 = (int)n; a.P = kd.P; a.n_parts_total = kd.n_parts;
+  a.parts = kd.d_parts; a.part_lo = 0; a.part_hi = 1;
+  a.outer = kd.outer_scale; a.apply_outer = 1; a.symmetric = 1; a.diag_add = 0.0;
+  a.K = K; a.ldk = ldk;
+  a.sXp = sXp; a.sNp = sNp; a.sK = sK; a.sBlob = sBlob; a.diag_adds = d_diag_adds;
+  const int64_t T = (n + 63) / 64;
+  const int smem = ((2 * 64 * (16 + 2) > 32 * (64 + 2) ? 2 * 64 * (16 + 2) : 32 * (64 + 2)) + 2 * 64) * 8;
+  hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7, true>), dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)count),
+                     dim3(256), smem, ctx->stream, a);
   DFH_LAUNCH_CHECK();
   return DFH_OK;
 }
@@ -647,6 +694,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   DFH_ARG(n1 < (1LL << 31) && n2 < (1LL << 31));
   KmArgs a;
   a.ec = kExpConsts;
+  a.sXp = a.sNp = a.sK = a.sBlob = 0; a.diag_adds = nullptr;
   a.Xp1 = Xp1; a.Np1 = Np1; a.Xp2 = Xp2; a.Np2 = Np2;
   a.n1 = (int)n1; a.n2 = (int)n2; a.P = kd.P; a.n_parts_total = kd.n_parts;
   a.parts = kd.d_parts; a.part_lo = part_lo; a.part_hi = part_hi;
