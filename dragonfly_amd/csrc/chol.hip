@@ -16,6 +16,7 @@
 //   solve (trsm_rows) and the alpha solves (trsv_*) reuse them, which turns every triangular
 //   solve on the hot path into GEMM / GEMV work.
 #include "common.h"
+#include <utility>
 #include <math.h>
 
 namespace {
@@ -190,6 +191,117 @@ __device__ __forceinline__ bool factor64(double (&a)[16], int nb, int w, int k, 
   return true;
 }
 
+// Single-wave factorisation of the 64 x 64 block: lane i holds row i in registers (a[j] = A[i][j]).
+// Column step k: the pivot is read from lane k (v_readlane), every lane scales its column-k
+// element, the column is published through a 64-double LDS vector (a wave's LDS operations
+// execute in order, so no barrier is needed) and read back as broadcasts for the rank-1 update.
+// The dependent chain per column is readlane -> rsqrt (Newton) -> scale -> LDS round trip ->
+// first FMA; the other FMAs of the update overlap the next column's chain.  No workgroup barrier
+// inside the 64 steps (the 256-thread rank-4 version needed 16 and did every row solve 64 times).
+// colbuf: [2][64].  Returns the failing column (uniform) or -1.  diag_out: L[lane][lane].
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// one column step of factor64_wave (K is a template parameter so that every register index is a
+// compile-time constant: a partially unrolled loop would put the 64-double row into scratch)
+template <int K>
+__device__ __forceinline__ void f64w_step(double (&a)[PB], int lane, double* colbuf, double& my_diag,
+                                          int& bad, double& lprev) {
+  constexpr int k = K;
+    const double* cbp = colbuf + ((k + 1) & 1) * PB;       // column published by step k-1
+    constexpr int jb = k + 1;                                  // first deferred column
+    constexpr int ngroups = (k >= 1) ? (PB - jb + 7) / 8 : 0;  // groups of 8 columns jb + 8g ...
+    double c0[8], c1[8];
+#define LOAD_GROUP(g, arr)                                                                      \
+    if ((g) < ngroups) {                                                                          \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
+        const int j = jb + 8 * (g) + t;                                                           \
+        arr[t] = (j < PB) ? cbp[j] : 0.0;                                                         \
+      }                                                                                           \
+    }
+#define FMA_GROUP(g, arr)                                                                       \
+    if ((g) < ngroups) {                                                                          \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
+        const int j = jb + 8 * (g) + t;                                                           \
+        if (j < PB) a[j] = fma(-lprev, arr[t], a[j]);                                             \
+      }                                                                                           \
+    }
+    // group 0 holds column k+1, which the eager update below needs: it is consumed first
+    LOAD_GROUP(0, c0);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(a[k]), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(a[k]), k);
+    const double d = __hiloint2double(hi, lo);
+    bad = (bad < 0 && !(d > 0.0)) ? k : bad;               // uniform: d is the same in every lane
+    SB();
+    LOAD_GROUP(1, c1);
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    SB();
+    FMA_GROUP(0, c0); LOAD_GROUP(2, c0);
+    double t1 = h * y;
+    SB();
+    FMA_GROUP(1, c1); LOAD_GROUP(3, c1);
+    double e = fma(-t1, y, 0.5);
+    SB();
+    FMA_GROUP(2, c0); LOAD_GROUP(4, c0);
+    y = fma(y, e, y);
+    SB();
+    FMA_GROUP(3, c1); LOAD_GROUP(5, c1);
+    t1 = h * y;
+    SB();
+    FMA_GROUP(4, c0); LOAD_GROUP(6, c0);
+    e = fma(-t1, y, 0.5);
+    SB();
+    FMA_GROUP(5, c1); LOAD_GROUP(7, c1);
+    y = fma(y, e, y);
+    SB();
+    FMA_GROUP(6, c0);
+    double sq = d * y;
+    SB();
+    FMA_GROUP(7, c1);
+    const double res = fma(-sq, sq, d);
+    const double hy = 0.5 * y;
+    SB();
+    sq = fma(res, hy, sq);                                  // sqrt(d)
+    const double e2 = fma(-sq, y, 1.0);
+    const double r = fma(e2, y, y);                         // 1/sqrt(d), consistent with sq
+    const double l = (lane == k) ? sq : a[k] * r;
+    my_diag = (lane == k) ? sq : my_diag;
+    a[k] = (lane >= k) ? l : 0.0;                           // column k is final (zero above the diagonal)
+    if (k + 1 < PB) {
+      colbuf[(k & 1) * PB + lane] = l;                      // published for the deferred update in step k+1
+      const int slo = __builtin_amdgcn_readlane(__double2loint(l), k + 1);
+      const int shi = __builtin_amdgcn_readlane(__double2hiint(l), k + 1);
+      a[k + 1] = fma(-l, __hiloint2double(shi, slo), a[k + 1]);      // eager: next pivot column
+    }
+    lprev = l;
+    SB();
+}
+#undef SB
+#undef LOAD_GROUP
+#undef FMA_GROUP
+
+template <int... Ks>
+__device__ __forceinline__ void f64w_run(double (&a)[PB], int lane, double* colbuf, double& my_diag, int& bad,
+                                         double& lprev, std::integer_sequence<int, Ks...>) {
+  (f64w_step<Ks>(a, lane, colbuf, my_diag, bad, lprev), ...);
+}
+
+__device__ __forceinline__ int factor64_wave(double (&a)[PB], int lane, double* colbuf, double* diag_out) {
+  // Software pipeline: the rank-1 update of step k-1 for the columns beyond k is deferred into
+  // step k, where it is independent of pivot k's dependent chain
+  //   readlane a[k] -> rsqrt (Newton) -> scale -> readlane L[k+1][k] -> FMA into column k+1.
+  // The deferred columns are processed in groups of 8 (four broadcast ds_read_b128 each); group g
+  // is loaded before chain operation g and consumed after chain operation g+1, so LDS latency
+  // and the chain's issue stalls hide each other.  sched_barriers pin that interleaving -- left
+  // alone the compiler serialises every LDS read behind an s_waitcnt (measured: 86k cycles for
+  // the 64 steps instead of ~30k).  Branch-free: a bad pivot only raises a flag.
+  double my_diag = 1.0;
+  int bad = -1;
+  double lprev = 0.0;
+  f64w_run(a, lane, colbuf, my_diag, bad, lprev, std::make_integer_sequence<int, PB>{});
+  *diag_out = my_diag;
+  return bad;
+}
+
 // sum over the four lanes of a quad, in every lane (DPP quad_perm, no LDS crossbar)
 __device__ __forceinline__ double quad_sum(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -225,44 +337,58 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   const int tid = threadIdx.x;
   const int k = tid & 63, w = tid >> 6;
 
-  double a[16];
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  load_block64(D, lda, nb, w, k, a);
-  int fail_j = 0;
-  double my_diag = 1.0;
+  // stage the pivot block (identity padding beyond nb, zero above the diagonal), coalesced; it
+  // sits in the Sp region, which wave 0 overwrites with the factor image only after reading it
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = w + 4 * r;
+    double v = (i == k) ? 1.0 : 0.0;
+    if (i < nb && k < nb) v = (k <= i) ? D[i * lda + k] : 0.0;
+    Sp[i * SPP + k] = v;
+  }
+  __shared__ int s_bad;
+  __syncthreads();
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  const bool fok = factor64(a, nb, w, k, colbuf, &fail_j, &my_diag);
+  double* rdiag = colbuf + 2 * PB;                 // 1 / L[c][c]
+  const int r0 = ((int)blockIdx.x - 1) * PB;
+  double* Pn = D + (long)(nb + r0) * lda;
+  if (w == 0) {
+    double a[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) a[j] = Sp[k * SPP + j];      // lane k <- row k
+    double my_diag = 1.0;
+    const int bad = factor64_wave(a, k, colbuf, &my_diag);
+    if (k == 0) s_bad = bad;
+    if (bad < 0) {
+      // factor image for the row solves: Sp[row][perm16(col)], and the reciprocal diagonal
+#pragma unroll
+      for (int j = 0; j < PB; ++j) Sp[k * SPP + perm16(j)] = a[j];
+      rdiag[k] = fast_div(1.0, my_diag, fast_rcp(my_diag));
+    }
+  } else if (blockIdx.x > 0) {
+    // meanwhile waves 1-3 stage this workgroup's 64 panel rows (coalesced along the row)
+    for (int idx = tid - 64; idx < PB * PB; idx += 192) {
+      const int i = idx >> 6, kk = idx & 63;
+      R[i * PBP + kk] = (r0 + i < rows_below && kk < nb) ? Pn[i * lda + kk] : 0.0;
+    }
+  }
+  __syncthreads();
   const unsigned long long t2 = __builtin_amdgcn_s_memtime();
   if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) { info_dbg[2] = (long long)(t1 - t0); info_dbg[3] = (long long)(t2 - t1); }
-  if (!fok) {
-    if (blockIdx.x == 0 && tid == 0 && info[0] == 0) info[0] = pivot_base + fail_j + 1;
+  if (s_bad >= 0) {
+    if (blockIdx.x == 0 && tid == 0 && info[0] == 0) info[0] = pivot_base + s_bad + 1;
     return;
   }
   if (blockIdx.x == 0) {
     // The factor goes to a scratch block (64 x 64, ld 64), NOT back into D: the other workgroups
     // of this launch re-read the unfactored pivot block from D and may start arbitrarily later.
     // trtri64_kernel moves it into place once the whole diagonal block is done.
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Lout[(w + 4 * r) * PB + k] = a[r];
-    return;
-  }
-  {
     const int pk = perm16(k);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Sp[(w + 4 * r) * SPP + pk] = a[r];
+    for (int r = 0; r < 16; ++r) Lout[(w + 4 * r) * PB + k] = Sp[(w + 4 * r) * SPP + pk];
+    return;
   }
-  double* rdiag = colbuf;                          // 1 / L[c][c]  (colbuf is free after factor64)
-  __syncthreads();                                 // every thread is done reading colbuf
-  if (w == 0) rdiag[k] = fast_div(1.0, my_diag, fast_rcp(my_diag));
-  // stage this workgroup's 64 panel rows (coalesced along k)
-  const int r0 = (blockIdx.x - 1) * PB;
-  double* Pn = D + (long)(nb + r0) * lda;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = w + 4 * r;
-    R[i * PBP + k] = (r0 + i < rows_below && k < nb) ? Pn[i * lda + k] : 0.0;
-  }
-  __syncthreads();
   {
     // forward substitution x L^T = p, four lanes per row: lane q of a quad accumulates the terms
     // kk = q (mod 4) (its 16 values of row c of L are contiguous in Sp), two quad shuffles combine
@@ -291,10 +417,16 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
         rdn = rdiag[c + 1];
       }
       LDS_FENCE();
-      double s = ((c & 3) == q) ? rq[c / 4] : 0.0;
+      // four independent partial sums: the dependent FMA chain is c/16 + 1 long instead of c/4 + 1
+      double s0 = ((c & 3) == q) ? rq[c / 4] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int t = 0; t <= c / 4; ++t) s = fma(-xq[t], sv[t], s);
-      s = quad_sum(s);
+      for (int t = 0; t <= c / 4; ++t) {
+        if ((t & 3) == 0) s0 = fma(-xq[t], sv[t], s0);
+        else if ((t & 3) == 1) s1 = fma(-xq[t], sv[t], s1);
+        else if ((t & 3) == 2) s2 = fma(-xq[t], sv[t], s2);
+        else s3 = fma(-xq[t], sv[t], s3);
+      }
+      double s = quad_sum((s0 + s1) + (s2 + s3));
       const double xc = s * rd;
       if ((c & 3) == q) xq[c / 4] = xc;
 #pragma unroll
