@@ -116,6 +116,16 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   delete ctx;
 }
 
+extern "C" int dfh_mem_info(dfh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+  DFH_ARG(ctx != nullptr);
+  DFH_HIP(hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  DFH_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (uint64_t)f;
+  if (total_bytes) *total_bytes = (uint64_t)t;
+  return DFH_OK;
+}
+
 extern "C" int dfh_sync(dfh_ctx* ctx) {
   DFH_ARG(ctx != nullptr);
   DFH_HIP(hipStreamSynchronize(ctx->stream));

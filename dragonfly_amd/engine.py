@@ -183,6 +183,12 @@ class Engine(object):
   def empty(self, shape):
     return DeviceArray(self, shape)
 
+  def mem_info(self):
+    """ (free, total) HBM bytes of this engine's device. """
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    check(self.lib.dfh_mem_info(self.ctx, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
   def timer_begin(self):
     check(self.lib.dfh_timer_begin(self.ctx))
 

@@ -81,6 +81,8 @@ void dfh_ctx_destroy(dfh_ctx* ctx);
 int  dfh_sync(dfh_ctx* ctx);
 const char* dfh_last_error(void);
 int  dfh_device_name(dfh_ctx* ctx, char* buf, size_t buflen);
+/* Free / total HBM of the context's device in bytes (hipMemGetInfo); plumbing for leak checks. */
+int  dfh_mem_info(dfh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
 int  dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);
 int  dfh_free(dfh_ctx* ctx, void* dptr);

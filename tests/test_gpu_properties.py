@@ -136,3 +136,33 @@ def test_fit_is_bitwise_repeatable_under_concurrent_load(engine, fitted):
     v2 = gp0.thompson(Xc, U, block=4096, mean_const=fitted['mean_c'])
     assert v1 == v2
     gp.free()
+
+
+def test_no_device_memory_growth_over_repeated_calls(engine):
+  """ fit / append / predict / Thompson / batched lml in a loop: handles are released and the
+      workspaces are reused, so free HBM settles after the first pass """
+  from dragonfly_amd.engine import KernelSpec
+  rs = np.random.RandomState(3)
+  n, d = 700, 5
+  X, Y = rs.rand(n + 40, d), rs.randn(n + 40)
+  Xs, U = rs.rand(2000, d), rs.randn(2000)
+  specs = [KernelSpec('se', d, 1.0 + 0.1 * i, 0.5 + rs.rand(d)) for i in range(20)]
+
+  def one_pass():
+    gp = engine.gp_fit(specs[0], X[:n], Y[:n], 0.1)
+    ext = gp.append(X[n:], Y)
+    ext.predict(Xs)
+    ext.acq_argmax('ei', Xs, params=(1.0, 0.0))
+    ext.thompson(Xs, U, block=500)
+    engine.gp_lml_batch(specs, X[:n], Y[:n], None, [0.1] * len(specs))
+    gp.free()
+    ext.free()
+
+  one_pass()
+  engine.sync()
+  free0 = engine.mem_info()[0]
+  for _ in range(25):
+    one_pass()
+  engine.sync()
+  free1 = engine.mem_info()[0]
+  assert free0 - free1 < 8 * 2 ** 20, (free0, free1)
