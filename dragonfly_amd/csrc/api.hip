@@ -963,7 +963,7 @@ extern "C" int dfh_gp_acq_argmax(dfh_gp* gp, int acq, const double* params, cons
 extern "C" int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, const double* Xg, int64_t m,
                                     double* vals_out, double* best_val, int64_t* best_idx) {
   DFH_ARG(gp && Xg && m >= 1);
-  DFH_ARG(gp->kd.multi && group >= 0 && group < gp->kd.n_parts);
+  DFH_ARG(gp->kd.multi && !gp->kd.product && group >= 0 && group < gp->kd.n_parts);   // additive kernels only
   const PartDev& pd = gp->kd.parts[group];
   int gdim = 0;
   for (int c = 0; c < pd.kc; ++c) gdim += gp->kd.cols[pd.poff + c] >= 0;

@@ -168,7 +168,8 @@ struct PartDev {
 };
 struct KernDev {
   int kind = 0, dim = 0, n_parts = 0, P = 0;
-  bool multi = false;          // additive: sum over parts then outer scale
+  bool multi = false;          // additive: sum over parts then outer scale; product: scale * prod over parts
+  bool product = false;        // (multi only) combine the parts by multiplication (kernel.py:584-588)
   double outer_scale = 1.0;
   std::vector<PartDev> parts;
   std::vector<int> cols;       // [P] source column per packed column (-1 = padding)

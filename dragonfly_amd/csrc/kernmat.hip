@@ -48,6 +48,7 @@ struct KmArgs {
   int part_lo, part_hi;
   double outer;
   int apply_outer, symmetric;
+  int product;                 // MULTI: parts are multiplied (CoordinateProductKernel) instead of summed
   double diag_add;
   double* K; long ldk;
   // lock-step batch over blockIdx.z (symmetric single-part kernel only): element strides of the
@@ -108,10 +109,13 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
 
   double4_t res[4][TJ];
   if (MULTI) {
+    // additive: 0 + k_1 + k_2 ...; product: scale * k_1 * k_2 ... in the reference's order
+    // (kernel.py:584-588: K = scale * ones; K *= kernel(...))
+    const double r0 = p.product ? p.outer : 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) res[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < TJ; ++j) res[i][j] = (double4_t){r0, r0, r0, r0};
   }
 
   for (int part = p.part_lo; part < p.part_hi; ++part) {
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
           double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];     // general_utils.py:66-68
           dsq = dsq < 0.0 ? 0.0 : dsq;                           // np.clip(.,0,inf), NaN kept
           const double kv = kern_eval(pd, dsq, ec);
-          if (MULTI) res[i][j][r] += kv;                          // kernel.py:493
+          if (MULTI) res[i][j][r] = p.product ? res[i][j][r] * kv : res[i][j][r] + kv;   // kernel.py:493 / :588
           else acc[i][j][r] = kv;
         }
       }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
         const long col = n0 + wn * TJ * 16 + j * 16 + l15;
         if (row < p.n1 && col < p.n2) {
           double v = res[i][j][r];
-          if (MULTI && p.apply_outer) v = p.outer * v;            // kernel.py:494
+          if (MULTI && p.apply_outer && !p.product) v = p.outer * v;   // kernel.py:494
           if (p.symmetric && row == col) v += p.diag_add;         // gp_core.py:843
           p.K[row * p.ldk + col] = v;
         }
@@ -552,11 +556,12 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
     for (int i = 0; i < k->dim; ++i) ident[i] = i;
     add_part_cols(kd, pd, ident.data(), k->bw, k->dim);
     kd->parts.push_back(pd);
-    kd->multi = false; kd->outer_scale = 1.0;
+    kd->multi = false; kd->product = false; kd->outer_scale = 1.0;
     kd->kxx = part_value_at_zero(pd);
-  } else if (k->kind == DFH_KERNEL_ADDITIVE) {
+  } else if (k->kind == DFH_KERNEL_ADDITIVE || k->kind == DFH_KERNEL_PRODUCT) {
     DFH_ARG(k->n_groups >= 1 && k->group_off && k->group_dims && k->sub_kind && k->sub_scale && k->sub_bw);
-    double acc = 0.0;
+    const bool product = (k->kind == DFH_KERNEL_PRODUCT);
+    double acc = product ? k->scale : 0.0;
     for (int g = 0; g < k->n_groups; ++g) {
       const int lo = k->group_off[g], hi = k->group_off[g + 1];
       DFH_ARG(hi > lo);
@@ -566,10 +571,11 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
       DFH_TRY(fill_part(pd, k->sub_kind[g], k->sub_scale[g], k->sub_nu ? k->sub_nu[g] : 0.0));
       add_part_cols(kd, pd, k->group_dims + lo, k->sub_bw + lo, hi - lo);
       kd->parts.push_back(pd);
-      acc += part_value_at_zero(pd);          // result += kernel(...)   kernel.py:493
+      if (product) acc *= part_value_at_zero(pd);     // K *= kernel(...)        kernel.py:588
+      else acc += part_value_at_zero(pd);             // result += kernel(...)   kernel.py:493
     }
-    kd->multi = true; kd->outer_scale = k->scale;
-    kd->kxx = k->scale * acc;                 // kernel.py:494
+    kd->multi = true; kd->product = product; kd->outer_scale = k->scale;
+    kd->kxx = product ? acc : k->scale * acc;        // kernel.py:494
   } else {
     dfh_set_error("unknown kernel kind %d", k->kind);
     return DFH_ERR_BAD_ARG;
@@ -675,7 +681,7 @@ int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob,
   a.Xp1 = Xp; a.Np1 = Np; a.Xp2 = Xp; a.Np2 = Np;
   a.n1 = (int)n; a.n2 = (int)n; a.P = kd.P; a.n_parts_total = kd.n_parts;
   a.parts = kd.d_parts; a.part_lo = 0; a.part_hi = 1;
-  a.outer = kd.outer_scale; a.apply_outer = 1; a.symmetric = 1; a.diag_add = 0.0;
+  a.outer = kd.outer_scale; a.apply_outer = 1; a.symmetric = 1; a.diag_add = 0.0; a.product = 0;
   a.K = K; a.ldk = ldk;
   a.sXp = sXp; a.sNp = sNp; a.sK = sK; a.sBlob = sBlob; a.diag_adds = d_diag_adds;
   const int64_t T = (n + 63) / 64;
@@ -698,7 +704,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   a.Xp1 = Xp1; a.Np1 = Np1; a.Xp2 = Xp2; a.Np2 = Np2;
   a.n1 = (int)n1; a.n2 = (int)n2; a.P = kd.P; a.n_parts_total = kd.n_parts;
   a.parts = kd.d_parts; a.part_lo = part_lo; a.part_hi = part_hi;
-  a.outer = kd.outer_scale; a.apply_outer = apply_outer ? 1 : 0;
+  a.outer = kd.outer_scale; a.apply_outer = apply_outer ? 1 : 0; a.product = kd.product ? 1 : 0;
   a.symmetric = symmetric ? 1 : 0; a.diag_add = diag_add;
   a.K = K; a.ldk = ldk;
   const bool multi = kd.multi;

@@ -10,7 +10,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import (ACQ_EI, ACQ_MEAN, ACQ_PI, ACQ_STD, ACQ_TTEI, ACQ_UCB, GET_ALPHA, GET_K, GET_L,
-                   INT32_MIN, KERNEL_ADDITIVE, KERNEL_MATERN, KERNEL_SE, KernelDesc, check)
+                   INT32_MIN, KERNEL_ADDITIVE, KERNEL_MATERN, KERNEL_PRODUCT, KERNEL_SE, KernelDesc,
+                   check)
 
 ACQ_IDS = {'mean': ACQ_MEAN, 'ucb': ACQ_UCB, 'ei': ACQ_EI, 'pi': ACQ_PI, 'ttei': ACQ_TTEI,
            'std': ACQ_STD}
@@ -69,7 +70,8 @@ class DeviceArray(object):
 
 class KernelSpec(object):
   """ Host-side description of a Euclidean kernel, convertible to struct dfh_kernel_desc.
-      kind: 'se' | 'matern' | 'additive'. """
+      kind: 'se' | 'matern' | 'additive' | 'product' (coordinate-wise product of SE / Matern
+      kernels, kernel.py:541). """
 
   def __init__(self, kind, dim, scale, bandwidths=None, nu=0.0, groups=None, sub_kinds=None,
                sub_scales=None, sub_nus=None, sub_bandwidths=None):
@@ -111,8 +113,8 @@ class KernelSpec(object):
       self._keep.append(bw)
       d.bw = bw.ctypes.data_as(_lib.c_double_p)
       d.n_groups = 0
-    elif self.kind == 'additive':
-      d.kind = KERNEL_ADDITIVE
+    elif self.kind in ('additive', 'product'):
+      d.kind = KERNEL_ADDITIVE if self.kind == 'additive' else KERNEL_PRODUCT
       d.dim = self.dim
       d.scale = self.scale
       ng = len(self.groups)

@@ -13,6 +13,13 @@ edited):
   S2/S3 GP     dragonfly.gp.euclidean_gp.EuclideanGP -> dragonfly_amd.euclidean_gp.EuclideanGP
                (every Euclidean fitter constructs its GP through this module global,
                dragonfly/gp/euclidean_gp.py:338)
+  S2' MF GP    (only with install(multi_fidelity=True)) dragonfly.gp.euclidean_gp.EuclideanMFGP ->
+               dragonfly_amd.mf_gp.EuclideanMFGP: the coordinate-product kernel scale * k_fidel *
+               k_domain on the device for SE / Matern factors; the MF fitter constructs its GP
+               through this module global (dragonfly/gp/euclidean_gp.py:707).  Opt-in because there
+               is no way back to the reference class once the name is rebound (the reference's
+               __init__ calls super(EuclideanMFGP, self)), so poly / expdecay fidelity kernels
+               then raise TypeError.
   S4 acquisitions  the fused callables are written into the namespaces
                dragonfly.opt.gpb_acquisitions.asy / syn / seq (looked up with getattr at
                dragonfly/opt/gp_bandit.py:490,510,651,681)
@@ -22,13 +29,13 @@ now runs on the device, through `external_maximise_with_method`.
 _saved = []     # (object, attribute name, original value)
 
 
-def install():
+def install(multi_fidelity=False):
   """ Rebinds the names listed above; returns the list of patched attributes. """
   import dragonfly.gp.kernel as ref_kernel
   import dragonfly.gp.euclidean_gp as ref_egp
   import dragonfly.opt.gpb_acquisitions as ref_acq
   from dragonfly.exd.exd_utils import maximise_with_method
-  from . import kernel, euclidean_gp, gpb_acquisitions
+  from . import kernel, euclidean_gp, gpb_acquisitions, mf_gp
   patched = []
   def _set(mod, name, new):
     _saved.append((mod, name, getattr(mod, name)))
@@ -37,6 +44,9 @@ def install():
   for name in ('SEKernel', 'MaternKernel', 'AdditiveKernel'):
     _set(ref_kernel, name, getattr(kernel, name))
   _set(ref_egp, 'EuclideanGP', euclidean_gp.EuclideanGP)
+
+  if multi_fidelity:
+    _set(ref_egp, 'EuclideanMFGP', mf_gp.EuclideanMFGP)
   for ns_name in ('asy', 'syn', 'seq'):
     ref_ns = getattr(ref_acq, ns_name)
     our_ns = getattr(gpb_acquisitions, ns_name)

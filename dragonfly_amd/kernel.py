@@ -182,6 +182,28 @@ class MaternKernel(_EuclideanDeviceKernel):
     return 'Matern: ' + nu_str + ' ' + scale_str + ' ' + bw_str
 
 
+def _grouped_spec(kind, kernel, groupings, in_dim):
+  """ KernelSpec of a kernel made of SE / Matern sub-kernels on coordinate groups. """
+  kinds, scales, nus, bws = [], [], [], []
+  for kern in kernel.kernel_list:
+    if isinstance(kern, SEKernel):
+      kinds.append('se')
+      nus.append(0.0)
+    elif isinstance(kern, MaternKernel):
+      kinds.append('matern')
+      nus.append(kern.hyperparams['nu'])
+    else:
+      raise TypeError('%s on the device supports SE/Matern sub-kernels only, got %s.'
+                      % (type(kernel).__name__, type(kern)))
+    scales.append(kern.hyperparams['scale'])
+    bws.append(np.ravel(np.asarray(kern.hyperparams['dim_bandwidths'], dtype=float)))
+  groups = [[int(i) for i in grp] for grp in groupings]
+  if in_dim is None:
+    in_dim = max(max(max(g) for g in groups) + 1, kernel.dim)
+  return KernelSpec(kind, in_dim, kernel.hyperparams['scale'], groups=groups,
+                    sub_kinds=kinds, sub_scales=scales, sub_nus=nus, sub_bandwidths=bws)
+
+
 class AdditiveKernel(_EuclideanDeviceKernel):
   """ Additive kernel on Euclidean spaces with non-overlapping groups (kernel.py:461-501). The
       sub-kernels must be SEKernel / MaternKernel objects. """
@@ -202,27 +224,49 @@ class AdditiveKernel(_EuclideanDeviceKernel):
     raise NotImplementedError('Not defined for additive kernels.')
 
   def to_spec(self, in_dim=None):
-    kinds, scales, nus, bws = [], [], [], []
-    for kern in self.kernel_list:
-      if isinstance(kern, SEKernel):
-        kinds.append('se')
-        nus.append(0.0)
-      elif isinstance(kern, MaternKernel):
-        kinds.append('matern')
-        nus.append(kern.hyperparams['nu'])
-      else:
-        raise TypeError('AdditiveKernel on the device supports SE/Matern sub-kernels only, got %s.'
-                        % (type(kern)))
-      scales.append(kern.hyperparams['scale'])
-      bws.append(np.ravel(np.asarray(kern.hyperparams['dim_bandwidths'], dtype=float)))
-    groups = [[int(i) for i in grp] for grp in self.groupings]
-    if in_dim is None:
-      in_dim = max(max(max(g) for g in groups) + 1, self.dim)
-    return KernelSpec('additive', in_dim, self.hyperparams['scale'], groups=groups,
-                      sub_kinds=kinds, sub_scales=scales, sub_nus=nus, sub_bandwidths=bws)
+    return _grouped_spec('additive', self, self.groupings, in_dim)
 
   def __str__(self):
     kernels_str_list = ['%s(%s)'%(grp, kern) for (grp, kern) in
                         zip(self.groupings, self.kernel_list)]
     kernels_str = ', '.join(kernels_str_list)
     return 'ADD scale=%0.2f, '%(self.hyperparams['scale']) + kernels_str
+
+
+class CoordinateProductKernel(_EuclideanDeviceKernel):
+  """ Coordinate-wise product kernel scale * prod_i k_i(X[:, coordinate_list[i]])
+      (kernel.py:541-591); the kernel of a Euclidean multi-fidelity GP (fidelity x domain).
+      The sub-kernels must be SEKernel / MaternKernel objects. """
+
+  def __init__(self, dim, scale, kernel_list=None, coordinate_list=None):
+    super(CoordinateProductKernel, self).__init__()
+    self.dim = dim
+    self.add_hyperparams(scale=scale)
+    self.kernel_list = kernel_list
+    self.coordinate_list = coordinate_list
+
+  def set_kernel_list(self, kernel_list):
+    self.kernel_list = kernel_list
+
+  def is_guaranteed_psd(self):
+    return all([kern.is_guaranteed_psd() for kern in self.kernel_list])
+
+  def set_new_kernel(self, kernel_idx, new_kernel):
+    self.kernel_list[kernel_idx] = new_kernel
+
+  def set_kernel_hyperparams(self, kernel_idx, **kwargs):
+    self.kernel_list[kernel_idx].set_hyperparams(**kwargs)
+
+  def get_scaled_repr(self, X):
+    raise NotImplementedError('Not defined for product kernels.')
+
+  def to_spec(self, in_dim=None):
+    if len(self.kernel_list) != len(self.coordinate_list):
+      raise ValueError("number of kernels do not correspond to number of coordinate groups.")
+    return _grouped_spec('product', self, self.coordinate_list, in_dim if in_dim is not None else self.dim)
+
+  def __str__(self):
+    kernels_str_list = ['%s(%s)'%(grp, kern) for (grp, kern) in
+                        zip(self.coordinate_list, self.kernel_list)]
+    kernels_str = ', '.join(kernels_str_list)
+    return 'CoordProd scale=%0.2f, '%(self.hyperparams['scale']) + kernels_str

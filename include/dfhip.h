@@ -41,6 +41,8 @@ extern "C" {
 #define DFH_KERNEL_SE       0 /* dragonfly/gp/kernel.py:132 SEKernel                         */
 #define DFH_KERNEL_MATERN   1 /* dragonfly/gp/kernel.py:225 MaternKernel, nu in {.5,1.5,2.5} */
 #define DFH_KERNEL_ADDITIVE 2 /* dragonfly/gp/kernel.py:461 AdditiveKernel over SE/Matern    */
+#define DFH_KERNEL_PRODUCT  3 /* dragonfly/gp/kernel.py:541 CoordinateProductKernel over SE/Matern
+                               * (scale * prod_g k_g(X[:, coords_g]); same group fields as ADDITIVE) */
 
 /* One Euclidean kernel.  For SE / MATERN: `dim`, `scale`, `nu`, `bw[dim]` (dim_bandwidths).
  * For ADDITIVE: `scale` is the outer scale, and the n_groups sub-kernels are described by the

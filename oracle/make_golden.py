@@ -231,9 +231,41 @@ def gen_c1_case():
   print('wrote c1_branin (x_next %s)' % (x_next,))
 
 
+def gen_mfgp_case():
+  """ EuclideanMFGP (euclidean_gp.py:347-412) with the coordinate-product kernel
+      scale * SE(z) * Matern-2.5(x): posterior, hallucinated std, a joint sample. """
+  from dragonfly.gp.euclidean_gp import EuclideanMFGP
+  from dragonfly.gp import kernel as rk
+  rs = np.random.RandomState(909)
+  n, fd, dd, m = 70, 1, 3, 31
+  ZZ, XX = rs.random_sample((n, fd)), rs.random_sample((n, dd))
+  YY = np.sin(3 * XX.sum(axis=1)) * (0.5 + ZZ[:, 0]) + 0.05 * rs.randn(n)
+  fbw, dbw = np.array([0.6]), np.array([0.35, 0.5, 0.8])
+  scale, noise, mean_c = 1.7, float(YY.var() / 20), float(np.median(YY))
+  fidel_kernel = rk.SEKernel(fd, 1.0, fbw)
+  domain_kernel = rk.MaternKernel(dd, 2.5, 1.0, dbw)
+  mean_func = lambda x: np.array([mean_c] * len(x))
+  gp = EuclideanMFGP(list(ZZ), list(XX), list(YY), None, scale, fidel_kernel, domain_kernel,
+                     mean_func, noise)
+  Zs, Xs = rs.random_sample((m, fd)), rs.random_sample((m, dd))
+  mu, sd = gp.eval_at_fidel(list(Zs), list(Xs), 'std')
+  _, cov = gp.eval_at_fidel(list(Zs), list(Xs), 'covar')
+  Zh, Xh = rs.random_sample((4, fd)), rs.random_sample((4, dd))
+  _, sdh = gp.eval_at_fidel_with_hallucinated_observations(list(Zs), list(Xs), list(Zh), list(Xh), 'std')
+  np.savez_compressed(os.path.join(OUT, 'mfgp_f1_d3_n70.npz'), ZZ=ZZ, XX=XX, YY=YY, fbw=fbw, dbw=dbw,
+                      scale=scale, noise=noise, mean_c=mean_c, K=gp.K_trtr_wo_noise, L=gp.L,
+                      alpha=gp.alpha, lml=gp.compute_log_marginal_likelihood(), Zs=Zs, Xs=Xs, mu=mu,
+                      sd=sd, cov=cov, Zh=Zh, Xh=Xh, sdh=sdh)
+  print('wrote mfgp_f1_d3_n70')
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   import_reference()
+  if len(sys.argv) > 1 and sys.argv[1] == 'mfgp':
+    gen_mfgp_case()
+    sys.exit(0)
   gen_gp_cases()
   gen_fitter_case()
   gen_c1_case()
+  gen_mfgp_case()

@@ -154,8 +154,10 @@ def test_install_rebinds_reference_names():
   import dragonfly.opt.gpb_acquisitions as ref_acq
   from dragonfly_amd import install, euclidean_gp, gpb_acquisitions
   orig_se, orig_gp, orig_ucb = ref_kernel.SEKernel, ref_egp.EuclideanGP, ref_acq.asy.ucb
+  orig_mfgp = ref_egp.EuclideanMFGP
   patched = install.install()
   try:
+    assert ref_egp.EuclideanMFGP is orig_mfgp              # multi-fidelity rebinding is opt-in
     assert ref_kernel.SEKernel is K.SEKernel and ref_kernel.AdditiveKernel is K.AdditiveKernel
     assert ref_egp.EuclideanGP is euclidean_gp.EuclideanGP
     assert ref_acq.asy.ucb is gpb_acquisitions.asy_ucb and ref_acq.syn.ts is gpb_acquisitions.syn_ts
@@ -167,3 +169,11 @@ def test_install_rebinds_reference_names():
   finally:
     install.uninstall()
   assert ref_kernel.SEKernel is orig_se and ref_egp.EuclideanGP is orig_gp and ref_acq.asy.ucb is orig_ucb
+  assert ref_egp.EuclideanMFGP is orig_mfgp
+  from dragonfly_amd import mf_gp
+  install.install(multi_fidelity=True)
+  try:
+    assert ref_egp.EuclideanMFGP is mf_gp.EuclideanMFGP
+  finally:
+    install.uninstall()
+  assert ref_egp.EuclideanMFGP is orig_mfgp

@@ -123,3 +123,26 @@ def test_argmax_first_semantics():
   assert O.argmax_first(np.array([1.0, 3.0, 3.0, 2.0])) == (3.0, 1)
   v, i = O.argmax_first(np.array([1.0, np.nan, 5.0, np.nan]))
   assert i == 1 and v != v
+
+
+def _mfgp_oracle(g):
+  fd, dd = g['ZZ'].shape[1], g['XX'].shape[1]
+  subs = [O.KernelSpec('se', fd, 1.0, g['fbw']), O.KernelSpec('matern', dd, 1.0, g['dbw'], nu=2.5)]
+  groups = [list(range(fd)), list(range(fd, fd + dd))]
+  spec = O.KernelSpec('product', fd + dd, float(g['scale']), groups=groups, subs=subs)
+  ZX = np.concatenate([g['ZZ'], g['XX']], axis=1)
+  return spec, ZX, O.GPOracle(ZX, g['YY'], spec, float(g['mean_c']), float(g['noise']))
+
+
+def test_oracle_product_kernel_matches_reference_mfgp():
+  """ EuclideanMFGP of the real reference (coordinate-product kernel, euclidean_gp.py:347-412) """
+  g = load_golden('mfgp_f1_d3_n70')
+  spec, ZX, og = _mfgp_oracle(g)
+  assert relerr(spec(ZX), g['K']) < 1e-12
+  assert relerr(og.L, g['L']) < 1e-10 and relerr(og.alpha, g['alpha']) < 1e-10
+  assert abs(og.lml() - float(g['lml'])) <= 1e-10 * abs(float(g['lml']))
+  ZXs = np.concatenate([g['Zs'], g['Xs']], axis=1)
+  mu, sd = og.eval(ZXs, 'std')
+  assert relerr(mu, g['mu']) < 1e-10 and relerr(sd, g['sd']) < 1e-9
+  _, sdh = og.eval_with_hallucinated_observations(ZXs, np.concatenate([g['Zh'], g['Xh']], axis=1), 'std')
+  assert relerr(sdh, g['sdh']) < 1e-9
