@@ -1,6 +1,7 @@
 """Bring-up checks on a real MI355X: each stage runs in its own process (a faulting kernel must
-not hide the later stages).  Usage:  python tools/gpu_check.py [stage ...]   (no args = all)
-Writes a log per stage under gpurun_out/check/.
+not hide the later stages).  Usage:  python tests/gpu_check.py [stage ...]   (no args = all)
+Writes a log per stage under gpurun_out/check/.  Test infrastructure (it lives under tests/ because
+some stages compare with oracle/, which only tests may import); not collected by pytest.
 """
 import os
 import subprocess
