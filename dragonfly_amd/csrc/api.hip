@@ -25,9 +25,11 @@ struct dfh_gp {
 namespace {
 
 int64_t pick_chunk(int64_t n, int64_t m) {
-  // candidate rows per posterior chunk: keep the m_c x n cross matrix near 2 GiB
-  int64_t mc = (int64_t)(1LL << 28) / (n > 0 ? n : 1);
-  mc = std::max<int64_t>(512, std::min<int64_t>(mc, 32768));
+  // candidate rows per posterior chunk: keep the m_c x n cross matrix near DFH_CHUNK_GIB (4) GiB
+  // (measured on the bench step: 2 GiB 1465 ms, 4 GiB 1434 ms, 8 GiB 1439 ms -- eight TS blocks per batch)
+  static const double chunk_gib = []() { const char* e = getenv("DFH_CHUNK_GIB"); double v = e ? atof(e) : 4.0; return v > 0.0 ? v : 4.0; }();
+  int64_t mc = (int64_t)(chunk_gib * (double)(1LL << 27)) / (n > 0 ? n : 1);
+  mc = std::max<int64_t>(512, std::min<int64_t>(mc, 65536));
   mc = (mc / 512) * 512;
   if (mc > m) mc = m;
   return mc;
@@ -1034,8 +1036,8 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   double* vec[2] = {nullptr, nullptr};
   DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 2, (void**)&vec[0]));
   DFH_TRY(scratch_get(ctx, SCR_VECB, (size_t)mc_max * 8 * 2, (void**)&vec[1]));
-  // up to 6 blocks of a chunk are factored as one batch (cholesky_device's batch limit)
-  static const int ts_batch = []() { const char* e = getenv("DFH_TS_BATCH"); int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 6 ? 6 : v); }();
+  // up to DFH_TS_BATCH (8) blocks of a chunk are factored as one lock-step batch
+  static const int ts_batch = []() { const char* e = getenv("DFH_TS_BATCH"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
   const int64_t lb_slots = std::max<int64_t>(1, std::min<int64_t>(ts_batch, mc_max / block));
   double* Lb = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)lb_slots * block * block * 8, (void**)&Lb));
