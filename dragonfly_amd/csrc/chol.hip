@@ -576,7 +576,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   GemmBatch bA;                               // every operand inside the batch matrices
   bA.count = nbatch; bA.sA = bA.sB = bA.sCin = bA.sCout = strideA;
 
-  static bool attr_set = false;
+  static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
+  bool& attr_set = attr_set_dev[ctx->device];
   if (!attr_set) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(diag_step64_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));

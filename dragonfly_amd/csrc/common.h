@@ -45,6 +45,8 @@ struct DevBuf {
 
 // matrices factored in lock-step by one batched cholesky_device call (one pivot flag each)
 constexpr int CHOL_MAX_BATCH = 64;
+// function attributes (dynamic LDS limits) are per device: the "already set" flags are indexed by it
+constexpr int DFH_MAX_DEVICES = 64;
 
 struct dfh_ctx {
   int device = 0;

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 
 template <bool TRANSB, bool EDGE, int WT>
 int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
-  static bool attr_set = false;
+  static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
+  bool& attr_set = attr_set_dev[ctx->device];
   auto kern = gemm_f64_kernel<TRANSB, EDGE, WT>;
   constexpr int HALF_OCC_SMEM = 84 * 1024;            // two of these do not fit in 160 KB
   constexpr int MAX_SMEM = (WT == 4) ? HALF_OCC_SMEM : Geo<WT>::SMEM_BYTES;

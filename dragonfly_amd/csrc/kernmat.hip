@@ -708,7 +708,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   a.symmetric = symmetric ? 1 : 0; a.diag_add = diag_add;
   a.K = K; a.ldk = ldk;
   const bool multi = kd.multi;
-  static bool attr_set = false;
+  static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
+  bool& attr_set = attr_set_dev[ctx->device];
   constexpr int SM4 = ((KM_BM + 128) * KM_KP + KM_BM + 128) * 8;
   constexpr int SM2 = ((KM_BM + 64) * KM_KP + KM_BM + 64) * 8;
   if (!attr_set) {
@@ -729,7 +730,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
     };
     if (symmetric) {
       if (sym_cfg == 2) {
-        static bool attr = false;
+        static bool attr_dev[DFH_MAX_DEVICES] = {false};
+        bool& attr = attr_dev[ctx->device];
         if (!attr) { DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_sym_kernel<128, 32, 64, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(128, 32, 64))); attr = true; }
         const int64_t T = (n1 + 127) / 128;
         hipLaunchKernelGGL((kernmat_sym_kernel<128, 32, 64, 2, true>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(128, 32, 64), ctx->stream, a);

@@ -45,7 +45,7 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
   *out = nullptr;
   int count = 0;
   DFH_HIP(hipGetDeviceCount(&count));
-  if (device < 0 || device >= count) {
+  if (device < 0 || device >= count || device >= DFH_MAX_DEVICES) {
     dfh_set_error("dfh_ctx_create: device %d out of range (found %d HIP devices)", device, count);
     return DFH_ERR_BAD_ARG;
   }
