@@ -25,15 +25,11 @@ constexpr int PB = 64;       // pivot block
 constexpr int PBP = 65;      // LDS row stride
 
 // ---------------------------------------------------------------------------------------------
-// 64 x 64 pivot-block kernels.
-//
-// factor64(): the block lives in registers, thread (w = tid>>6, k = tid&63) owns column k of rows
-// w, w+4, ..., w+60.  Step j: the four owners of column j publish it (unscaled) through a
-// double-buffered 64-double LDS vector, one barrier, then every thread of a column k > j applies
-// a[i][k] -= a[i][j] * (a[k][j] / d_j) to its 16 rows.  Columns are divided by sqrt(d_k) once,
-// after the loop.  Returns false (uniformly) on a non-positive / NaN pivot.
-// (A single-wave v_readlane formulation with no barriers at all was measured slower on gfx950:
-//  ~29 cycles per readlane-pair + FMA; see profiles/r01_notes.md.)
+// 64 x 64 pivot-block kernels.  The block is factored by ONE wave (factor64_wave below: a row per
+// lane, columns published through LDS, deferred rank-1 updates); history of the alternatives
+// measured on gfx950: a 256-thread column-per-thread version with one barrier per column (100 us),
+// its rank-4 blocked form with 16 barriers (58k cycles), a single-wave all-v_readlane form
+// (~29 cycles per readlane pair + FMA: slower), the present one (36k cycles).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_block64(const double* __restrict__ A, long lda, int nb, int w,
                                               int k, double (&a)[16]) {
@@ -62,8 +58,8 @@ __device__ __forceinline__ double fast_div(double n, double d, double r) {
   return fma(fma(-d, q, n), r, q);
 }
 
-// LDS image of a published column: element i sits at perm16(i) so that the 16 rows a thread owns
-// (w, w+4, ..., w+60) are 16 consecutive doubles -> ds_read_b128 instead of 16 scalar reads.
+// LDS image of a factor row: column j sits at perm16(j) so that the 16 columns of a residue class
+// j = q (mod 4) a lane of the row substitution reads are 16 consecutive doubles (ds_read_b128).
 __device__ __forceinline__ int perm16(int i) { return (i & 3) * 16 + (i >> 2); }
 
 #define LDS_FENCE() asm volatile("" ::: "memory")   // keeps every LDS load above it, every use below
@@ -84,121 +80,6 @@ __device__ __forceinline__ void fast_rsqrt_sqrt(double d, double* rs, double* sq
   *sq = s;
 }
 
-// Rank-4 blocked factorisation of the register-resident 64 x 64 block: 16 super-steps instead of
-// 64 column steps.  Super-step s (columns j0 = 4s .. j0+3): the owners of those four columns
-// publish them (raw) through a double-buffered LDS panel, one barrier, then EVERY thread
-//   - factors the raw 4 x 4 diagonal block (identical arithmetic in all threads -> uniform),
-//   - forward-substitutes the raw 4-vectors of its own 16 rows and of row k against it, and
-//   - applies the rank-4 update a[i][k] -= sum_c L[i][j0+c] L[k][j0+c] to its 16 elements
-// (column owners instead keep the transformed values: their column is final).  The redundant
-// 4 x 4 work costs ~250 fp64 ops per thread per super-step but removes three of every four
-// barrier + LDS round trips, which is what the column-at-a-time version spent its time on.
-// colbuf: [2][4][64] doubles.  Returns false (uniformly) on a non-positive / NaN pivot.
-__device__ __forceinline__ bool factor64(double (&a)[16], int nb, int w, int k, double* colbuf,
-                                         int* fail_j, double* diag_out) {
-  const int pk = perm16(k);
-  double my_diag = 1.0;
-  const int nsuper = (nb + 3) >> 2;
-  for (int sidx = 0; sidx < nsuper; ++sidx) {
-    const int j0 = sidx * 4;
-    double* cb = colbuf + (sidx & 1) * 4 * PB;
-    if (k >= j0 && k < j0 + 4) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cb[(k - j0) * PB + w * 16 + r] = a[r];
-    }
-    __syncthreads();
-    // every LDS read of the super-step up front
-    double D[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) D[rr][c] = (c <= rr) ? cb[c * PB + perm16(j0 + rr)] : 0.0;
-    double pkv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pkv[c] = cb[c * PB + pk];
-    double pr[4][16];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pr[c][r] = cb[c * PB + w * 16 + r];
-    LDS_FENCE();
-
-    // 4 x 4 Cholesky of the raw diagonal block.  Branch-free: a bad pivot only raises a flag that
-    // is tested once per super-step, so the whole super-step is one basic block and the scheduler
-    // can interleave the row solves below with the reciprocal-sqrt latency chains.
-    double r0, r1, r2, r3, l00, l11, l22, l33;
-    int bad = -1;
-    bad = (!(D[0][0] > 0.0)) ? 0 : bad;
-    fast_rsqrt_sqrt(D[0][0], &r0, &l00);
-    const double l10 = D[1][0] * r0, l20 = D[2][0] * r0, l30 = D[3][0] * r0;
-    const double d1 = fma(-l10, l10, D[1][1]);
-    bad = (bad < 0 && !(d1 > 0.0)) ? 1 : bad;
-    fast_rsqrt_sqrt(d1, &r1, &l11);
-    const double l21 = fma(-l20, l10, D[2][1]) * r1, l31 = fma(-l30, l10, D[3][1]) * r1;
-    const double d2 = fma(-l21, l21, fma(-l20, l20, D[2][2]));
-    bad = (bad < 0 && !(d2 > 0.0)) ? 2 : bad;
-    fast_rsqrt_sqrt(d2, &r2, &l22);
-    const double l32 = fma(-l31, l21, fma(-l30, l20, D[3][2])) * r2;
-    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, D[3][3])));
-    bad = (bad < 0 && !(d3 > 0.0)) ? 3 : bad;
-    fast_rsqrt_sqrt(d3, &r3, &l33);
-
-    // x L4^T = p for row k and for the thread's 16 rows
-    auto solve4 = [&](double p0, double p1, double p2, double p3, double (&x)[4]) {
-      x[0] = p0 * r0;
-      x[1] = fma(-x[0], l10, p1) * r1;
-      x[2] = fma(-x[1], l21, fma(-x[0], l20, p2)) * r2;
-      x[3] = fma(-x[2], l32, fma(-x[1], l31, fma(-x[0], l30, p3))) * r3;
-    };
-    double xk[4];
-    solve4(pkv[0], pkv[1], pkv[2], pkv[3], xk);
-    // One divergence-free update for every lane:  a[r] <- base + sum_c xi[c] * coef[c]
-    //   trailing column (k >= j0+4): base = a[r], coef = -x_k            (rank-4 update)
-    //   panel column    (k = j0+kc): base = 0,    coef = e_kc            (the column becomes final)
-    //   finished column (k <  j0)  : base = a[r], coef = 0               (unchanged)
-    // Rows of this thread are i = w + 4r: rows below the panel are r > sidx, the row inside the
-    // 4 x 4 diagonal block is r == sidx (i - j0 = w), rows above are r < sidx.
-    const bool trailing = k >= j0 + 4;
-    const bool owner = (k >= j0) && !trailing;
-    const int kc = k - j0;
-    double coef[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) coef[c] = trailing ? -xk[c] : ((owner && kc == c) ? 1.0 : 0.0);
-    // L4[w][kc]: the owner's value in the diagonal block row (wave-uniform row w, per-lane column kc)
-    const double l4row[4] = {(w == 0) ? l00 : (w == 1) ? l10 : (w == 2) ? l20 : l30,
-                             (w == 1) ? l11 : (w == 2) ? l21 : (w == 3) ? l31 : 0.0,
-                             (w == 2) ? l22 : (w == 3) ? l32 : 0.0,
-                             (w == 3) ? l33 : 0.0};
-    const double l4wk = (kc == 0) ? l4row[0] : (kc == 1) ? l4row[1] : (kc == 2) ? l4row[2] : l4row[3];
-    if (owner) my_diag = (kc == 0) ? l00 : (kc == 1) ? l11 : (kc == 2) ? l22 : l33;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double xi[4];
-      solve4(pr[0][r], pr[1][r], pr[2][r], pr[3][r], xi);
-      const double base = owner ? 0.0 : a[r];
-      const double res = fma(xi[3], coef[3], fma(xi[2], coef[2], fma(xi[1], coef[1], fma(xi[0], coef[0], base))));
-      const double in_or_above = owner ? ((r == sidx) ? l4wk : 0.0) : a[r];
-      a[r] = (r > sidx) ? res : in_or_above;
-    }
-    if (bad >= 0) { *fail_j = j0 + bad; return false; }      // uniform: identical data in every thread
-  }
-  *diag_out = my_diag;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = w + 4 * r;
-    if (k < nb && i < k) a[r] = 0.0;             // strict upper part
-  }
-  return true;
-}
-
-// Single-wave factorisation of the 64 x 64 block: lane i holds row i in registers (a[j] = A[i][j]).
-// Column step k: the pivot is read from lane k (v_readlane), every lane scales its column-k
-// element, the column is published through a 64-double LDS vector (a wave's LDS operations
-// execute in order, so no barrier is needed) and read back as broadcasts for the rank-1 update.
-// The dependent chain per column is readlane -> rsqrt (Newton) -> scale -> LDS round trip ->
-// first FMA; the other FMAs of the update overlap the next column's chain.  No workgroup barrier
-// inside the 64 steps (the 256-thread rank-4 version needed 16 and did every row solve 64 times).
-// colbuf: [2][64].  Returns the failing column (uniform) or -1.  diag_out: L[lane][lane].
 #define SB() __builtin_amdgcn_sched_barrier(0)
 // one column step of factor64_wave (K is a template parameter so that every register index is a
 // compile-time constant: a partially unrolled loop would put the 64-double row into scratch)
