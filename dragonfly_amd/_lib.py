@@ -67,6 +67,12 @@ SIGNATURES = {
   'dfh_gp_append': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                               C.POINTER(C.c_void_p), c_double_p, c_int32_p]),
   'dfh_mem_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+  'dfh_gp_fit_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_int,
+                                C.POINTER(C.c_void_p), c_double_p, c_int32_p]),
+  'dfh_gp_predict_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+  'dfh_gp_predict_covar_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
   'dfh_gp_free': (C.c_int, [C.c_void_p]),
   'dfh_gp_get': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
   'dfh_gp_n': (C.c_int64, [C.c_void_p]),

@@ -20,6 +20,7 @@ struct dfh_gp {
   double* inv = nullptr;         // [nblk][NB][NB] inverses of the diagonal blocks of L
   double* alpha = nullptr;       // [n]
   bool upper_zeroed = false;
+  bool gram = false;             // built from a host-evaluated Gram matrix: no kernel, no packed inputs
 };
 
 namespace {
@@ -606,6 +607,137 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Posterior for an arbitrary positive semi-definite kernel evaluated by the caller:
+// GP.build_posterior with the Gram matrix coming from the documented override hook
+// GP._get_training_kernel_matrix (gp_core.py:149-163), and GP.eval with the caller's K(X*, X)
+// (gp_core.py:165-190).  The O(n^3) / O(n^2 m) linear algebra is the same device path as for the
+// built-in kernels; only the kernel evaluations stay with the caller.
+__global__ void k_sd_from_prior(const double* __restrict__ kss, const double* __restrict__ ss,
+                                double* __restrict__ sd, long m) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) sd[i] = sqrt(kss[i] - ss[i]);        // no clipping: NaN as in np.sqrt(np.diag(.)), gp_core.py:187
+}
+
+extern "C" int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const double* y_centred,
+                               double noise_var, int flags, dfh_gp** out, double* lml, int32_t* jitter_power) {
+  DFH_ARG(ctx && K && out && n >= 1 && y_centred);
+  *out = nullptr;
+  if (jitter_power) *jitter_power = INT32_MIN;
+  DFH_HIP(hipSetDevice(ctx->device));
+  dfh_gp* gp = new dfh_gp();
+  gp->ctx = ctx; gp->n = n; gp->d = 0; gp->noise_var = noise_var; gp->gram = true;
+  gp->nblk = (n + CHOL_NB - 1) / CHOL_NB;
+  auto body = [&]() -> int {
+    DFH_HIP(hipMalloc(&gp->L, (size_t)n * n * 8));
+    DFH_HIP(hipMalloc(&gp->inv, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8));
+    DFH_HIP(hipMalloc(&gp->alpha, (size_t)n * 8));
+    const double *dK = nullptr, *dy = nullptr;
+    DFH_TRY(to_device(ctx, K, (size_t)n * n * 8, SCR_KCT, &dK));
+    DFH_TRY(to_device(ctx, y_centred, (size_t)n * 8, SCR_STAGE_B, &dy));
+    auto build_M = [&]() -> int {     // K + noise_var * I     (gp_core.py:843)
+      DFH_TRY(copy_matrix(ctx, dK, n, gp->L, n, n, n));
+      return add_diag(ctx, gp->L, n, n, noise_var);
+    };
+    DFH_TRY(build_M());
+    {
+      SectionTimer t(ctx, DFH_T_CHOL);
+      DFH_TRY(stable_cholesky_device(ctx, gp->L, n, gp->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
+                                     jitter_power, &gp->diag_jitter));
+    }
+    return gp_alpha_and_lml(gp, dy, lml);
+  };
+  int rc = body();
+  if (rc != DFH_OK) { dfh_gp_free(gp); return rc; }
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  *out = gp;
+  return DFH_OK;
+}
+
+// mu = Kcross alpha (+ mean), sd = sqrt(kss - rowsumsq(Kcross L^-T)); Kcross is m x n, row i = k(x*_i, X)
+extern "C" int dfh_gp_predict_gram(dfh_gp* gp, const double* Kcross, int64_t m, const double* kss,
+                                   double mean_const, const double* mean_vals, double* mu_out, double* sd_out) {
+  DFH_ARG(gp && m >= 0 && (sd_out == nullptr || kss != nullptr));
+  if (m == 0) return DFH_OK;
+  DFH_ARG(Kcross && mu_out);
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int64_t n = gp->n;
+  const int64_t mc_max = pick_chunk(n, m);
+  const bool k_dev = is_device_ptr(Kcross), s_dev = kss ? is_device_ptr(kss) : true;
+  const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
+  double *vec = nullptr, *Kct = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 4, (void**)&vec));
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)mc_max * n * 8, (void**)&Kct));
+  double* mu = vec; double* ss = vec + mc_max; double* sd = vec + 2 * mc_max; double* ks = vec + 3 * mc_max;
+  for (int64_t i0 = 0; i0 < m; i0 += mc_max) {
+    const int64_t mc = std::min(mc_max, m - i0);
+    // the chunk of K(X*, X) is solved in place, so it always goes through the workspace
+    DFH_HIP(hipMemcpyAsync(Kct, Kcross + i0 * n, (size_t)mc * n * 8,
+                           k_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    {
+      SectionTimer t(ctx, DFH_T_CROSS);
+      DFH_TRY(gemv_rows(ctx, Kct, mc, n, n, gp->alpha, 1.0, nullptr, 0.0, mu));     // gp_core.py:174
+    }
+    const double* mv_c = nullptr;
+    if (mean_vals) {
+      if (mv_dev) mv_c = mean_vals + i0;
+      else DFH_TRY(to_device(ctx, mean_vals + i0, (size_t)mc * 8, SCR_STAGE_D, &mv_c));
+    }
+    hipLaunchKernelGGL(k_add_vec, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, mu, mv_c,
+                       mv_c ? 0.0 : mean_const, (long)mc);
+    DFH_LAUNCH_CHECK();
+    DFH_TRY(from_device(ctx, mu_out + i0, mu, (size_t)mc * 8));
+    if (sd_out) {
+      {
+        SectionTimer t(ctx, DFH_T_TRSM);
+        DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, mc, n));                  // gp_core.py:180
+      }
+      SectionTimer t(ctx, DFH_T_ACQ);
+      DFH_TRY(row_sumsq(ctx, Kct, mc, n, n, ss));
+      const double* ks_c = kss + i0;
+      if (!s_dev) {
+        DFH_HIP(hipMemcpyAsync(ks, kss + i0, (size_t)mc * 8, hipMemcpyHostToDevice, ctx->stream));
+        ks_c = ks;
+      }
+      hipLaunchKernelGGL(k_sd_from_prior, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, ks_c, ss, sd, (long)mc);
+      DFH_LAUNCH_CHECK();
+      DFH_TRY(from_device(ctx, sd_out + i0, sd, (size_t)mc * 8));
+    }
+    DFH_HIP(hipStreamSynchronize(ctx->stream));      // host source buffers may be reused by the caller
+  }
+  return DFH_OK;
+}
+
+// mu_out = Kcross alpha (raw, no mean), cov_out = Ktete - V^T V with V^T = Kcross L^-T  (gp_core.py:179-181)
+extern "C" int dfh_gp_predict_covar_gram(dfh_gp* gp, const double* Kcross, int64_t m, const double* Ktete,
+                                         double* mu_out, double* cov_out) {
+  DFH_ARG(gp && m >= 0);
+  if (m == 0) return DFH_OK;
+  DFH_ARG(Kcross && Ktete && mu_out && cov_out);
+  DFH_ARG((double)m * (double)gp->n * 8.0 < 64e9 && (double)m * (double)m * 8.0 < 64e9);
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int64_t n = gp->n;
+  double *vec = nullptr, *Kct = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)m * 8, (void**)&vec));
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)m * n * 8, (void**)&Kct));
+  DFH_HIP(hipMemcpyAsync(Kct, Kcross, (size_t)m * n * 8,
+                         is_device_ptr(Kcross) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  DFH_TRY(gemv_rows(ctx, Kct, m, n, n, gp->alpha, 1.0, nullptr, 0.0, vec));
+  DFH_TRY(from_device(ctx, mu_out, vec, (size_t)m * 8));
+  DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, m, n));
+  const bool dev_out = is_device_ptr(cov_out);
+  double* C = cov_out;
+  if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)m * m * 8, (void**)&C));
+  DFH_HIP(hipMemcpyAsync(C, Ktete, (size_t)m * m * 8,
+                         is_device_ptr(Ktete) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  DFH_TRY(gemm_f64(ctx, 0, m, m, n, -1.0, Kct, n, Kct, n, 1.0, C, m, C, m));
+  if (!dev_out) DFH_TRY(from_device(ctx, cov_out, C, (size_t)m * m * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Incremental posterior update.  GP.add_data_multiple (gp_core.py:139-146)
 // extends X, Y and rebuilds the posterior from scratch -- O((n+q)^3).  With the same kernel,
 // noise and data order the factor of the extended matrix is
@@ -618,6 +750,7 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
 extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const double* y_centred, int flags,
                              dfh_gp** out, double* lml, int32_t* jitter_power) {
   DFH_ARG(gp && out && q >= 1 && Xnew && y_centred);
+  DFH_ARG(!gp->gram);      // needs the kernel: this posterior was built from a Gram matrix
   *out = nullptr;
   if (jitter_power) *jitter_power = INT32_MIN;
   dfh_ctx* ctx = gp->ctx;
@@ -882,6 +1015,7 @@ extern "C" int dfh_gp_get(dfh_gp* gp, int what, double* out) {
     return from_device(ctx, out, gp->L, (size_t)n * n * 8);
   }
   if (what == DFH_GET_K) {
+    DFH_ARG(!gp->gram);      // the caller evaluated the Gram matrix and still has it
     const bool dev_out = is_device_ptr(out);
     double* Kd = out;
     if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n * n * 8, (void**)&Kd));
@@ -945,6 +1079,7 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
 extern "C" int dfh_gp_predict(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
                               double* mu_out, double* sd_out) {
   DFH_ARG(gp && m >= 0 && q >= 0);
+  DFH_ARG(!gp->gram);      // needs the kernel: this posterior was built from a Gram matrix
   if (m == 0) return DFH_OK;
   DFH_ARG(Xs && mu_out && (q == 0 || Xh));
   return gp_eval_driver(gp, DFH_ACQ_MEAN, nullptr, Xs, m, gp->d, 0, gp->kd.n_parts, false, gp->kd.kxx, Xh, q,
@@ -955,6 +1090,7 @@ extern "C" int dfh_gp_acq_argmax(dfh_gp* gp, int acq, const double* params, cons
                                  const double* Xh, int64_t q, double mean_const, const double* mean_vals,
                                  double* vals_out, double* best_val, int64_t* best_idx) {
   DFH_ARG(gp && m >= 1 && Xs && q >= 0 && (q == 0 || Xh));
+  DFH_ARG(!gp->gram);      // needs the kernel: this posterior was built from a Gram matrix
   DFH_ARG(acq >= DFH_ACQ_MEAN && acq <= DFH_ACQ_STD);
   DFH_ARG(params || acq == DFH_ACQ_MEAN || acq == DFH_ACQ_STD);
   const bool want_var = acq != DFH_ACQ_MEAN;
@@ -965,6 +1101,7 @@ extern "C" int dfh_gp_acq_argmax(dfh_gp* gp, int acq, const double* params, cons
 extern "C" int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, const double* Xg, int64_t m,
                                     double* vals_out, double* best_val, int64_t* best_idx) {
   DFH_ARG(gp && Xg && m >= 1);
+  DFH_ARG(!gp->gram);      // needs the kernel: this posterior was built from a Gram matrix
   DFH_ARG(gp->kd.multi && !gp->kd.product && group >= 0 && group < gp->kd.n_parts);   // additive kernels only
   const PartDev& pd = gp->kd.parts[group];
   int gdim = 0;
@@ -978,6 +1115,7 @@ extern "C" int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, cons
 extern "C" int dfh_gp_predict_covar(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
                                     double* mu_out, double* cov_out) {
   DFH_ARG(gp && m >= 0 && q >= 0);
+  DFH_ARG(!gp->gram);      // needs the kernel: this posterior was built from a Gram matrix
   if (m == 0) return DFH_OK;
   DFH_ARG(Xs && mu_out && cov_out && (q == 0 || Xh));
   DFH_ARG((double)m * (double)gp->n * 8.0 < 64e9);
@@ -1021,6 +1159,7 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
                          double mean_const, const double* mean_vals, double* samples_out, double* best_val,
                          int64_t* best_idx, int32_t* jitter_powers_out) {
   DFH_ARG(gp && Xs && U && m >= 1 && block >= 1);
+  DFH_ARG(!gp->gram);      // needs the kernel: this posterior was built from a Gram matrix
   dfh_ctx* ctx = gp->ctx;
   DFH_HIP(hipSetDevice(ctx->device));
   const KernDev& kd = gp->kd;

@@ -320,6 +320,11 @@ class Engine(object):
       return lml, [None if p == INT32_MIN else int(p) for p in jps]
     return lml
 
+  def gp_fit_gram(self, K, y_centred, noise_var, allow_jitter=True):
+    """ Posterior from a Gram matrix the caller evaluated (any PSD kernel): a FittedGP without a
+        kernel -- use predict_gram / predict_covar_gram with it. """
+    return FittedGP.from_gram(self, K, y_centred, noise_var, allow_jitter)
+
   def gp_fit(self, spec, X, y_centred, noise_var, allow_jitter=True):
     """ Returns a FittedGP (posterior resident in HBM). """
     return FittedGP(self, spec, X, y_centred, noise_var, allow_jitter)
@@ -346,6 +351,54 @@ class FittedGP(object):
     self.handle = h
     self.lml = lml.value
     self.jitter_power = None if jp.value == INT32_MIN else jp.value
+
+  @classmethod
+  def from_gram(cls, engine, K, y_centred, noise_var, allow_jitter=True):
+    Kh = K if isinstance(K, DeviceArray) else _f64(K)
+    n = Kh.shape[0]
+    if Kh.shape != (n, n):
+      raise ValueError('from_gram: the Gram matrix must be square.')
+    yh = _f64(y_centred).reshape(-1)
+    if yh.shape[0] != n:
+      raise ValueError('from_gram: need %d centred labels, got %d.' % (n, yh.shape[0]))
+    h = C.c_void_p()
+    lml = C.c_double(0)
+    jp = C.c_int32(INT32_MIN)
+    check(engine.lib.dfh_gp_fit_gram(engine.ctx, _ptr(Kh), n, _ptr(yh), float(noise_var),
+                                     0 if allow_jitter else _lib.FIT_NO_JITTER, C.byref(h),
+                                     C.byref(lml), C.byref(jp)))
+    new = cls.__new__(cls)
+    new.engine, new.spec, new.handle = engine, None, h
+    new.n, new.d = int(n), 0
+    new.lml = lml.value
+    new.jitter_power = None if jp.value == INT32_MIN else jp.value
+    return new
+
+  def predict_gram(self, K_cross, k_ss=None, mean_const=0.0, mean_vals=None):
+    """ (mu, sd) from the caller's cross matrix K(X*, X) [m x n] and prior variances k(x*, x*) [m]
+        (k_ss None: mean only). """
+    Kc = _f64(K_cross)
+    m = Kc.shape[0]
+    if Kc.ndim != 2 or Kc.shape[1] != self.n:
+      raise ValueError('predict_gram: the cross matrix must be m x %d.' % (self.n))
+    mu = np.empty(m, dtype=np.float64)
+    sd = np.empty(m, dtype=np.float64) if k_ss is not None else None
+    ks = None if k_ss is None else _f64(k_ss).reshape(-1)
+    mv = None if mean_vals is None else _f64(mean_vals).reshape(-1)
+    check(self.engine.lib.dfh_gp_predict_gram(self.handle, _ptr(Kc), m, _ptr(ks), float(mean_const),
+                                              _ptr(mv), _ptr(mu), _ptr(sd)))
+    return mu, sd
+
+  def predict_covar_gram(self, K_cross, K_tete):
+    """ (K_cross alpha, K_tete - V^T V) for the caller's kernel matrices. """
+    Kc, Kt = _f64(K_cross), _f64(K_tete)
+    m = Kc.shape[0]
+    if Kc.shape != (m, self.n) or Kt.shape != (m, m):
+      raise ValueError('predict_covar_gram: need an m x %d cross matrix and an m x m test matrix.' % (self.n))
+    mu = np.empty(m, dtype=np.float64)
+    cov = np.empty((m, m), dtype=np.float64)
+    check(self.engine.lib.dfh_gp_predict_covar_gram(self.handle, _ptr(Kc), m, _ptr(Kt), _ptr(mu), _ptr(cov)))
+    return mu, cov
 
   def append(self, X_new, y_centred_all, allow_jitter=True):
     """ Posterior extended by the rows of X_new (dfh_gp_append): a NEW FittedGP, this one stays

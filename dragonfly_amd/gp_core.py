@@ -47,13 +47,21 @@ class GP(object):
       self.build_posterior()
 
   def _set_up(self):
-    """ gp_core.py:112-118: only guaranteed-psd (Euclidean) kernels run on the device. """
+    """ gp_core.py:112-118: guaranteed-psd kernels only ('project_first' is an eigen-projection on
+        the host in the reference and stays there). """
     if not self.kernel.is_guaranteed_psd() or self.handle_non_psd_kernels != 'guaranteed_psd':
-      raise NotImplementedError('dragonfly_amd.GP handles guaranteed-psd Euclidean kernels '
+      raise NotImplementedError('dragonfly_amd.GP handles guaranteed-psd kernels '
                                 '(handle_non_psd_kernels="guaranteed_psd") only.')
-    if not hasattr(self.kernel, 'to_spec'):
-      raise TypeError('dragonfly_amd.GP needs a dragonfly_amd.kernel kernel (SE, Matern or '
-                      'Additive); got %s. There is no CPU fallback.' % (type(self.kernel)))
+
+  @property
+  def _generic(self):
+    """ True when the kernel is evaluated by the caller: a kernel object without a device
+        description (any Kernel with is_guaranteed_psd(), e.g. the reference's PolyKernel), or a
+        subclass that overrides the documented hook _get_training_kernel_matrix (gp_core.py:149).
+        The Gram / cross matrices then come from the host; Cholesky, solves and the posterior still
+        run on the device (dfh_gp_fit_gram, dfh_gp_predict_gram). """
+    return (not hasattr(self.kernel, 'to_spec')) or \
+           type(self)._get_training_kernel_matrix is not GP._get_training_kernel_matrix
 
   def _write_message(self, msg):
     if self.reporter:
@@ -89,7 +97,7 @@ class GP(object):
       # The reference rebuilds from scratch; with an unchanged kernel and noise variance the
       # extended posterior is a block-row append of the cached factor (dfh_gp_append, O(n^2 q)).
       if fitted is not None and len(X_new) > 0 and fitted.n == n_old and self.incremental_updates \
-         and fit_sig == self._posterior_signature(fitted.d):
+         and not self._generic and fit_sig == self._posterior_signature(fitted.d):
         Y_centred = np.asarray(self.Y, dtype=np.float64) - self.mean_func(self.X)
         self._fitted = fitted.append(_as_2d_array(X_new), Y_centred)
         self._fit_sig = fit_sig
@@ -114,6 +122,13 @@ class GP(object):
     """ gp_core.py:155-163: K, L = chol(K + noise I), alpha -- one device call. """
     self._invalidate()
     if self.num_tr_data == 0:
+      return
+    if self._generic:
+      Y_centred = np.asarray(self.Y, dtype=np.float64) - self.mean_func(self.X)
+      K = np.ascontiguousarray(self._get_training_kernel_matrix(), dtype=np.float64)
+      self._cache['K'] = K
+      self._fitted = get_engine().gp_fit_gram(K, Y_centred, self.noise_var)
+      self._fit_sig = None
       return
     hint = getattr(self, '_X_dev_hint', None)      # training inputs already resident in HBM
     X = hint if (hint is not None and hint.shape[0] == self.num_tr_data) else self._X_array()
@@ -155,7 +170,7 @@ class GP(object):
     if self.num_tr_data == 0 or self._fitted is None:
       return None
     if 'K' not in self._cache:
-      self._cache['K'] = self._fitted.get_K()
+      self._cache['K'] = self._get_training_kernel_matrix() if self._generic else self._fitted.get_K()
     return self._cache['K']
 
   @property
@@ -168,7 +183,7 @@ class GP(object):
     if uncert_form not in ('none', 'std', 'covar'):
       raise ValueError('uncert_form should be none, covar or std.')
     test_mean = self.mean_func(X_test)
-    Xt = _as_2d_array(X_test)
+    Xt = X_test if self._generic else _as_2d_array(X_test)   # a caller-evaluated kernel takes any objects
     if self.num_tr_data == 0:
       # no data: the posterior is the prior (K_tetr is n_test x 0 in the reference)
       pred_mean = test_mean + np.zeros(len(Xt))
@@ -177,6 +192,18 @@ class GP(object):
       K_tete = self.kernel(Xt, Xt)
       return pred_mean, (K_tete if uncert_form == 'covar' else np.sqrt(np.diag(K_tete)))
     fitted = self._need_fit()
+    if self._generic:
+      # gp_core.py:172-188 with the caller's kernel; the solves and products run on the device
+      K_tetr = np.ascontiguousarray(self.kernel(X_test, self.X), dtype=np.float64)
+      if uncert_form == 'none':
+        mu_raw, _ = fitted.predict_gram(K_tetr)
+        return test_mean + mu_raw, None
+      K_tete = np.ascontiguousarray(self.kernel(X_test, X_test), dtype=np.float64)
+      if uncert_form == 'covar':
+        mu_raw, covar = fitted.predict_covar_gram(K_tetr, K_tete)
+        return test_mean + mu_raw, covar
+      mu_raw, sd = fitted.predict_gram(K_tetr, np.diag(K_tete).copy())
+      return test_mean + mu_raw, sd
     if uncert_form == 'covar':
       mu_raw, covar = fitted.predict_covar(Xt)
       return test_mean + mu_raw, covar
@@ -191,16 +218,35 @@ class GP(object):
       return (pred_mean, None)
     if uncert_form not in ('std', 'covar'):
       raise ValueError('uncert_form should be none, covar or std.')
-    Xt = _as_2d_array(X_test)
-    Xh = _as_2d_array(X_halluc)
     if self.num_tr_data == 0:
       raise NotImplementedError('Hallucinated observations need at least one real observation.')
     fitted = self._need_fit()
+    if self._generic:
+      return (pred_mean, self._generic_hallucinated_uncert(X_test, X_halluc, uncert_form))
+    Xt = _as_2d_array(X_test)
+    Xh = _as_2d_array(X_halluc)
     if uncert_form == 'covar':
       _, covar = fitted.predict_covar(Xt, X_halluc=Xh)
       return (pred_mean, covar)
     _, sd = fitted.predict(Xt, want_std=True, X_halluc=Xh)
     return (pred_mean, sd)
+
+  def _generic_hallucinated_uncert(self, X_test, X_halluc, uncert_form):
+    """ gp_core.py:199-220 for a caller-evaluated kernel: the augmented factor is assembled block-
+        wise exactly as the reference does, every solve / factorisation on the device. """
+    from .general_utils import solve_lower_triangular, stable_cholesky
+    K_haltr = self.kernel(X_halluc, self.X)                       # gp_core.py:201
+    L = self.L
+    B = solve_lower_triangular(L, K_haltr.T).T                    # q x n
+    K_halhal = self.kernel(X_halluc, X_halluc) + self.noise_var * np.eye(len(X_halluc))
+    Lh = stable_cholesky(K_halhal - B.dot(B.T))
+    n, q = self.num_tr_data, len(X_halluc)
+    L_aug = np.zeros((n + q, n + q))
+    L_aug[:n, :n], L_aug[n:, :n], L_aug[n:, n:] = L, B, Lh
+    K_aug_te = np.vstack([self.kernel(self.X, X_test), self.kernel(X_halluc, X_test)])
+    V = solve_lower_triangular(L_aug, K_aug_te)
+    covar = self.kernel(X_test, X_test) - V.T.dot(V)
+    return covar if uncert_form == 'covar' else np.sqrt(np.diag(covar))
 
   def compute_log_marginal_likelihood(self):
     """ gp_core.py:222-227 (evaluated on the device together with the fit). """
@@ -219,7 +265,7 @@ class GP(object):
     """ gp_core.py:250-254.  A single joint draw at X_test runs fused on the device
         (covariance, stable_cholesky and L u never leave HBM); the standard normals are taken
         from the global np.random state exactly as draw_gaussian_samples does. """
-    if X_test is not None and num_samples == 1 and self.num_tr_data > 0:
+    if X_test is not None and num_samples == 1 and self.num_tr_data > 0 and not self._generic:
       Xt = _as_2d_array(X_test)
       test_mean = self.mean_func(X_test)
       U = np.random.normal(size=(len(Xt), 1))

@@ -40,6 +40,12 @@ def _is_rand_euclidean(anc_data):
          str(anc_data.acq_opt_method).lower().startswith('rand')
 
 
+def _can_fuse(gp, anc_data):
+  """ The fused candidates -> posterior -> acquisition -> arg-max call needs a device kernel; GPs
+      whose kernel the host evaluates take the reference's closure route (batched gp.eval). """
+  return _is_rand_euclidean(anc_data) and gp.num_tr_data > 0 and not getattr(gp, '_generic', False)
+
+
 def maximise_acquisition(acq_fn, anc_data, *args, **kwargs):
   """ gpb_acquisitions.py:23-40 for host-evaluated acquisition callables. """
   acq_opt_method = anc_data.acq_opt_method
@@ -126,7 +132,8 @@ def asy_ts(gp, anc_data):
     anc_data.acq_opt_method = 'rand'
     anc_data.max_evals = 4 * anc_data.max_evals
   Xh = _halluc_points(anc_data)
-  if Xh is None and gp.num_tr_data > 0 and anc_data.domain.get_type() == 'euclidean':
+  if Xh is None and gp.num_tr_data > 0 and anc_data.domain.get_type() == 'euclidean' and \
+     not getattr(gp, '_generic', False):
     # fused: covariance, stable_cholesky, L u and the arg-max stay on the device
     cands = _candidates(anc_data)
     test_mean = gp.mean_func(cands)
@@ -205,7 +212,7 @@ def _get_ucb_beta_th(dim, time_step):
 def asy_ucb(gp, anc_data):
   """ gpb_acquisitions.py:215-223 """
   beta_th = _get_ucb_beta_th(_get_gp_ucb_dim(gp), anc_data.t)
-  if _is_rand_euclidean(anc_data) and gp.num_tr_data > 0:
+  if _can_fuse(gp, anc_data):
     return _fused_argmax(gp, 'ucb', (beta_th, 0.0), anc_data)
   gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
   def _ucb_acq(x):
@@ -227,7 +234,7 @@ def _ndtr(x):
 def asy_pi(gp, anc_data):
   """ gpb_acquisitions.py:230-239 """
   curr_best = anc_data.curr_max_val
-  if _is_rand_euclidean(anc_data) and gp.num_tr_data > 0:
+  if _can_fuse(gp, anc_data):
     return _fused_argmax(gp, 'pi', (curr_best, 0.0), anc_data)
   gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
   def _pi_acq(x):
@@ -250,7 +257,7 @@ def _expected_improvement_for_norm_diff(norm_diff):
 def asy_ei(gp, anc_data):
   """ gpb_acquisitions.py:251-261 """
   curr_best = anc_data.curr_max_val
-  if _is_rand_euclidean(anc_data) and gp.num_tr_data > 0:
+  if _can_fuse(gp, anc_data):
     return _fused_argmax(gp, 'ei', (curr_best, 0.0), anc_data)
   gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
   def _ei_acq(x):
@@ -270,7 +277,7 @@ def _ttei(gp_eval, anc_data, ref_point, gp=None):
   ref_mean, ref_std = gp_eval([ref_point])
   ref_mean = float(np.ravel(ref_mean)[0])
   ref_std = float(np.ravel(ref_std)[0])
-  if gp is not None and _is_rand_euclidean(anc_data) and gp.num_tr_data > 0:
+  if gp is not None and _can_fuse(gp, anc_data):
     return _fused_argmax(gp, 'ttei', (ref_mean, ref_std), anc_data)
   def _tt_ei_acq(x):
     mu, sigma = gp_eval(x)

@@ -153,7 +153,23 @@ int dfh_gp_free(dfh_gp* gp);
 
 #define DFH_GET_L        0   /* n x n lower factor (GP.L)                                     */
 #define DFH_GET_ALPHA    1   /* n (GP.alpha)                                                  */
-#define DFH_GET_K        2   /* Incremental posterior update: the posterior of `gp` extended by q new observations, as a NEW
+#define DFH_GET_K        2   /* Posterior for ANY positive semi-definite kernel the caller evaluates itself: GP.build_posterior
+ * (gp/gp_core.py:155-163) with the Gram matrix from the documented override hook
+ * GP._get_training_kernel_matrix (:149-153), and GP.eval (:165-190) with the caller's cross matrix.
+ * K is n x n (kernel(X, X), without noise); the handle keeps L, alpha and the block inverses, no
+ * kernel: it works with dfh_gp_predict_gram / dfh_gp_predict_covar_gram, dfh_gp_get (L, alpha),
+ * dfh_gp_n, dfh_gp_free; the kernel-based entry points return DFH_ERR_BAD_ARG for it.            */
+int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const double* y_centred, double noise_var,
+                    int flags, dfh_gp** out, double* lml, int32_t* jitter_power);
+/* mu = Kcross alpha + mean, sd = sqrt(kss - rowsumsq(Kcross L^-T)) (no clipping: NaN as NumPy).
+ * Kcross [m x n], row i = kernel(x*_i, X); kss [m] = kernel(x*_i, x*_i) (NULL with sd_out NULL).  */
+int dfh_gp_predict_gram(dfh_gp* gp, const double* Kcross, int64_t m, const double* kss, double mean_const,
+                        const double* mean_vals, double* mu_out, double* sd_out);
+/* mu_out = Kcross alpha (no mean added), cov_out [m x m] = Ktete - V^T V  (gp_core.py:179-181).   */
+int dfh_gp_predict_covar_gram(dfh_gp* gp, const double* Kcross, int64_t m, const double* Ktete,
+                              double* mu_out, double* cov_out);
+
+/* Incremental posterior update: the posterior of `gp` extended by q new observations, as a NEW
  * handle (`gp` stays valid and unchanged).  Replaces the rebuild of GP.add_data_multiple
  * (gp/gp_core.py:139-146: X.extend, Y.extend, build_posterior) with a block-row append of the
  * Cholesky factor, O(n^2 q) instead of O((n+q)^3); same kernel, noise variance and data order,

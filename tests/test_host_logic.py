@@ -101,13 +101,20 @@ def test_reduce_argmax_numpy_semantics():
     assert (v != v) if np.isnan(vals[i]) else v == vals[i]
 
 
-def test_gp_rejects_foreign_kernels_and_bad_lengths():
+def test_gp_kernel_modes_and_bad_lengths():
   from dragonfly_amd.gp_core import GP
-  class Foreign(object):
+  class Foreign(object):                     # a kernel the host evaluates (no device description)
     def is_guaranteed_psd(self):
       return True
-  with pytest.raises(TypeError):
-    GP([np.zeros(2)], [0.0], Foreign(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
+  class NotPsd(Foreign):
+    def is_guaranteed_psd(self):
+      return False
+  g = GP([np.zeros(2)], [0.0], Foreign(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
+  assert g._generic
+  g2 = GP([np.zeros(2)], [0.0], K.SEKernel(2, 1.0, [1, 1]), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
+  assert not g2._generic
+  with pytest.raises(NotImplementedError):
+    GP([np.zeros(2)], [0.0], NotPsd(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
   with pytest.raises(ValueError):
     GP([np.zeros(2)], [0.0, 1.0], K.SEKernel(2, 1.0, [1, 1]), lambda x: np.zeros(len(x)), 0.1,
        build_posterior=False)
