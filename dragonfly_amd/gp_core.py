@@ -60,7 +60,9 @@ class GP(object):
         subclass that overrides the documented hook _get_training_kernel_matrix (gp_core.py:149).
         The Gram / cross matrices then come from the host; Cholesky, solves and the posterior still
         run on the device (dfh_gp_fit_gram, dfh_gp_predict_gram). """
-    return (not hasattr(self.kernel, 'to_spec')) or \
+    has_spec = hasattr(self.kernel, 'to_spec') and \
+               getattr(self.kernel, 'has_device_spec', lambda: True)()
+    return (not has_spec) or \
            type(self)._get_training_kernel_matrix is not GP._get_training_kernel_matrix
 
   def _write_message(self, msg):

@@ -14,12 +14,13 @@ edited):
                (every Euclidean fitter constructs its GP through this module global,
                dragonfly/gp/euclidean_gp.py:338)
   S2' MF GP    (only with install(multi_fidelity=True)) dragonfly.gp.euclidean_gp.EuclideanMFGP ->
-               dragonfly_amd.mf_gp.EuclideanMFGP: the coordinate-product kernel scale * k_fidel *
-               k_domain on the device for SE / Matern factors; the MF fitter constructs its GP
-               through this module global (dragonfly/gp/euclidean_gp.py:707).  Opt-in because there
-               is no way back to the reference class once the name is rebound (the reference's
-               __init__ calls super(EuclideanMFGP, self)), so poly / expdecay fidelity kernels
-               then raise TypeError.
+               dragonfly_amd.mf_gp.EuclideanMFGP.  SE / Matern fidelity and domain kernels give the
+               coordinate-product kernel on the device; any other factor (the reference's poly /
+               expdecay kernels) puts the GP into host-kernel mode -- kernel evaluated by its own
+               class on the host, factorisation and posterior on the device.  The MF fitter
+               constructs its GP through this module global (dragonfly/gp/euclidean_gp.py:707).
+               Opt-in because the reference class cannot be reached once the name is rebound (its
+               __init__ calls super(EuclideanMFGP, self)).
   S4 acquisitions  the fused callables are written into the namespaces
                dragonfly.opt.gpb_acquisitions.asy / syn / seq (looked up with getattr at
                dragonfly/opt/gp_bandit.py:490,510,651,681)

@@ -71,12 +71,20 @@ class Kernel(object):
 class _EuclideanDeviceKernel(Kernel):
   """ Shared device evaluation of SE / Matern / Additive kernels. """
 
+  def has_device_spec(self):
+    """ False for a grouped kernel with a factor the device does not evaluate (e.g. the reference's
+        PolyKernel inside a product): it is then composed on the host from its factors' own
+        evaluations, and GPs using it run in host-kernel mode (gp_core.GP._generic). """
+    return True
+
   def _child_evaluate(self, X1, X2):
     X1a = _as_2d_array(X1)
     same = X2 is X1
     X2a = X1a if same else _as_2d_array(X2)
     if X1a.shape[1] != X2a.shape[1]:
       raise ValueError('Second dimension of X1 and X2 should be equal.')   # general_utils.py:64
+    if not self.has_device_spec():
+      return self._host_compose(X1a, X2a)
     return get_engine().kernel_matrix(self.to_spec(in_dim=X1a.shape[1]), X1a,
                                       None if same else X2a)
 
@@ -223,6 +231,16 @@ class AdditiveKernel(_EuclideanDeviceKernel):
   def get_scaled_repr(self, X):
     raise NotImplementedError('Not defined for additive kernels.')
 
+  def has_device_spec(self):
+    return all(isinstance(k, (SEKernel, MaternKernel)) for k in self.kernel_list)
+
+  def _host_compose(self, X1, X2):
+    """ kernel.py:484-494 with each factor evaluated by its own class """
+    result = np.zeros((X1.shape[0], X2.shape[0]))
+    for kern, group in zip(self.kernel_list, self.groupings):
+      result += kern(X1[:, group], X2[:, group])
+    return self.hyperparams['scale'] * result
+
   def to_spec(self, in_dim=None):
     return _grouped_spec('additive', self, self.groupings, in_dim)
 
@@ -259,6 +277,16 @@ class CoordinateProductKernel(_EuclideanDeviceKernel):
 
   def get_scaled_repr(self, X):
     raise NotImplementedError('Not defined for product kernels.')
+
+  def has_device_spec(self):
+    return all(isinstance(k, (SEKernel, MaternKernel)) for k in self.kernel_list)
+
+  def _host_compose(self, X1, X2):
+    """ kernel.py:578-589 with each factor evaluated by its own class """
+    K = self.hyperparams['scale'] * np.ones((X1.shape[0], X2.shape[0]))
+    for kern, coords in zip(self.kernel_list, self.coordinate_list):
+      K *= kern(X1[:, coords], X2[:, coords])
+    return K
 
   def to_spec(self, in_dim=None):
     if len(self.kernel_list) != len(self.coordinate_list):

@@ -117,3 +117,32 @@ def test_acquisitions_take_the_closure_route_for_host_kernels(engine):
   mu, sd = og.eval(cands, 'std')
   beta = O.ucb_beta_th(3, len(Y))
   assert np.array_equal(x, cands[int(np.argmax(mu + beta * sd))])
+
+
+def test_product_kernel_with_a_host_factor_runs_in_host_kernel_mode(engine):
+  """ multi-fidelity GP whose fidelity kernel the device does not evaluate (poly): the product is
+      composed on the host from its factors, the posterior still runs on the device """
+  from dragonfly_amd.mf_gp import EuclideanMFGP
+  from dragonfly_amd import kernel as K
+  rs = np.random.RandomState(12)
+  n, fd, dd = 90, 1, 2
+  ZZ, XX = rs.rand(n, fd), rs.rand(n, dd)
+  YY = np.sin(3 * XX.sum(axis=1)) * (0.5 + ZZ[:, 0]) + 0.05 * rs.randn(n)
+  fidel = HostPolyKernel(fd, 2, 1.0, [0.9])
+  domain = K.SEKernel(dd, 1.0, [0.4, 0.6])
+  gp = EuclideanMFGP(list(ZZ), list(XX), list(YY), None, 1.5, fidel, domain, lambda x: np.zeros(len(x)), 0.02)
+  assert gp._generic and not gp.kernel.has_device_spec()
+  ZX = np.concatenate([ZZ, XX], axis=1)
+  ok = lambda A, B=None: 1.5 * fidel(A[:, :fd], (A if B is None else B)[:, :fd]) * \
+      O.se_kernel(A[:, fd:], (A if B is None else B)[:, fd:], 1.0, np.array([0.4, 0.6]))
+
+  class _Spec(object):
+    def __call__(self, A, B=None):
+      A = np.asarray(A, dtype=float)
+      return ok(A, None if B is None else np.asarray(B, dtype=float))
+  og = O.GPOracle(ZX, YY, _Spec(), 0.0, 0.02)
+  assert relerr(gp.alpha, og.alpha) < TOL
+  Zs, Xs = rs.rand(40, fd), rs.rand(40, dd)
+  mu, sd = gp.eval_at_fidel(list(Zs), list(Xs), 'std')
+  mur, sdr = og.eval(np.concatenate([Zs, Xs], axis=1), 'std')
+  assert relerr(mu, mur) < TOL and relerr(sd, sdr) < 1e-8
