@@ -191,6 +191,22 @@ def main():
   step()
   sync_all()
   sections = eng.timings(False)
+  cond_est = None
+  if rank == 0:
+    # conditioning of the matrix that was factored (quoted next to the parity numbers):
+    # lambda_max(K) by power iteration on the host, lambda_min(K + noise I) >= noise
+    gp = eng.gp_fit(spec, Xd, yd, noise)
+    Kh = gp.get_K()
+    gp.free()
+    v = np.ones(N_TRAIN) / np.sqrt(N_TRAIN)
+    lam = 0.0
+    for _ in range(12):
+      w = Kh.dot(v)
+      lam = float(np.linalg.norm(w))
+      v = w / lam
+    cond_est = {'lambda_max_K': round(lam, 3), 'noise_var': noise,
+                'cond_upper_bound': round((lam + noise) / noise, 1)}
+    del Kh
   if dist is not None:
     tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -220,6 +236,7 @@ def main():
       'candidates_per_s': round(CANDS_PER_GPU * world / (ms_per_step * 1e-3), 1),
       'sections_ms_extra_untimed_step_rank0': {k: round(v, 3) for k, v in sections.items() if v > 0},
       'result': {'lml': results['lml'], 'ts_best': results['best'], 'ts_argmax': int(results['idx'])},
+      'conditioning': cond_est,
       'roofline': {
         'bound': 'mfma', 'kernel': 'gemm_f64_kernel<NT,128x128> (v_mfma_f64_16x16x4_f64)',
         'achieved': round(achieved, 2), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
