@@ -111,3 +111,26 @@ def test_fitter_rand_exp_sampling_probabilities(engine):
   assert np.array_equal(np.asarray(res[0][1]), np.asarray(res[1][1])) and res[0][2] == res[1][2]
   assert np.allclose(res[0][4], res[1][4], rtol=1e-9, atol=1e-300)
   assert abs(res[0][4].sum() - 1.0) < 1e-12
+
+
+def test_additive_model_tuning_batched_and_per_candidate_agree(engine):
+  """ use_additive_gp: random groupings x random continuous hyper-parameters (euclidean_gp.py:718-746);
+      the additive kernels go through the non-uniform batch path """
+  from dragonfly_amd.euclidean_gp import EuclideanGPFitter
+  rs = np.random.RandomState(5)
+  n, d = 60, 6
+  X = rs.rand(n, d)
+  Y = (X[:, :2] ** 2).sum(axis=1) + np.sin(3 * X[:, 2]) + 0.05 * rs.randn(n)
+  out = []
+  for batch in (True, False):
+    opts = Namespace(kernel_type='se', ml_hp_tune_opt='rand', hp_tune_max_evals=600, hp_tune_criterion='ml',
+                     use_additive_gp=True, add_max_group_size=2, num_groups_per_group_size=3)
+    np.random.seed(77)
+    fitter = EuclideanGPFitter(list(X), list(Y), options=opts)
+    fitter.batch_lml = batch
+    kind, gp, hps = fitter.fit_gp()
+    assert kind == 'fitted_gp' and type(gp.kernel).__name__ == 'AdditiveKernel'
+    out.append((np.array(hps[0], dtype=float), list(hps[1]), gp.compute_log_marginal_likelihood(),
+                [list(g) for g in gp.kernel.groupings]))
+  assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][3] == out[1][3]
+  assert abs(out[0][2] - out[1][2]) <= 1e-12 * abs(out[1][2])
