@@ -1112,6 +1112,82 @@ extern "C" int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, cons
                         nullptr, true, nullptr, nullptr, vals_out, best_val, best_idx);
 }
 
+// All additive groups at once: the per-group cross matrices are stacked into one (sum m_g) x n
+// matrix so that the posterior solve is ONE triangular solve with sum(m_g) right-hand sides instead
+// of G small ones (the reference issues G solve_lower_triangular calls, gpb_acquisitions.py:161-176).
+// Xg_all: group g's candidates [m_g x |group g|], back to back.  Falls back to the per-group
+// route when the stack does not fit one posterior chunk.
+extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double* Xg_all, const int64_t* m_per_group,
+                                  double* vals_out, double* best_vals, int64_t* best_idx) {
+  DFH_ARG(gp && betas && Xg_all && m_per_group && best_vals && best_idx);
+  DFH_ARG(!gp->gram);
+  DFH_ARG(gp->kd.multi && !gp->kd.product);
+  dfh_ctx* ctx = gp->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const KernDev& kd = gp->kd;
+  const int G = kd.n_parts;
+  const int64_t n = gp->n;
+  std::vector<int64_t> off(G + 1, 0), xoff(G + 1, 0);
+  std::vector<int> gdim(G, 0);
+  for (int g = 0; g < G; ++g) {
+    DFH_ARG(m_per_group[g] >= 1);
+    for (int c = 0; c < kd.parts[g].kc; ++c) gdim[g] += kd.cols[kd.parts[g].poff + c] >= 0;
+    off[g + 1] = off[g] + m_per_group[g];
+    xoff[g + 1] = xoff[g] + m_per_group[g] * gdim[g];
+  }
+  const int64_t M = off[G];
+  if (M > pick_chunk(n, M)) {
+    for (int g = 0; g < G; ++g)
+      DFH_TRY(dfh_gp_add_ucb_group(gp, g, betas[g], Xg_all + xoff[g], m_per_group[g],
+                                   vals_out ? vals_out + off[g] : nullptr, &best_vals[g], &best_idx[g]));
+    return DFH_OK;
+  }
+  const double* dXg = nullptr;
+  DFH_TRY(to_device(ctx, Xg_all, (size_t)xoff[G] * 8, SCR_STAGE_A, &dXg));
+  char* xs = nullptr;
+  const size_t b_xsp = ((size_t)M * kd.P * 8 + 255) / 256 * 256;
+  DFH_TRY(scratch_get(ctx, SCR_XS, b_xsp + (size_t)M * kd.n_parts * 8, (void**)&xs));
+  double* Xsp = reinterpret_cast<double*>(xs);
+  double* Nsp = reinterpret_cast<double*>(xs + b_xsp);
+  double *Kct = nullptr, *vec = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)M * n * 8, (void**)&Kct));
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)M * 8 * 3, (void**)&vec));
+  double* mu_raw = vec; double* ss = vec + M; double* val = vec + 2 * M;
+  {
+    SectionTimer t(ctx, DFH_T_CROSS);
+    for (int g = 0; g < G; ++g) {
+      double* Xsp_g = Xsp + off[g] * kd.P; double* Nsp_g = Nsp + off[g] * kd.n_parts;
+      DFH_TRY(pack_scaled(ctx, kd, g, g + 1, true, dXg + xoff[g], m_per_group[g], gdim[g], Xsp_g, Nsp_g));
+      // K_j(X*_j, X[:, group j]) with the outer scale        (gpb_acquisitions.py:166-168)
+      DFH_TRY(kernmat_packed(ctx, kd, g, g + 1, true, Xsp_g, Nsp_g, m_per_group[g], gp->Xp, gp->Np, n, false,
+                             0.0, Kct + off[g] * n, n));
+    }
+    DFH_TRY(gemv_rows(ctx, Kct, M, n, n, gp->alpha, 1.0, nullptr, 0.0, mu_raw));
+  }
+  {
+    SectionTimer t(ctx, DFH_T_TRSM);
+    DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, M, n));
+  }
+  SectionTimer t(ctx, DFH_T_ACQ);
+  DFH_TRY(row_sumsq(ctx, Kct, M, n, n, ss));
+  for (int g = 0; g < G; ++g) {
+    const double kxx = kd.outer_scale * kerndev_part_kxx(kd, g);        // kern_scale * kernel_j(x, x)
+    const int64_t mg = m_per_group[g];
+    hipLaunchKernelGGL(k_posterior_acq, dim3((unsigned)((mg + 255) / 256)), dim3(256), 0, ctx->stream, (int)DFH_ACQ_UCB,
+                       betas[g], 0.0, kxx, 0.0, (const double*)nullptr, mu_raw + off[g], ss + off[g],
+                       (const double*)nullptr, (long)mg, (double*)nullptr, (double*)nullptr, val + off[g]);
+    DFH_LAUNCH_CHECK();
+  }
+  for (int g = 0; g < G; ++g) {
+    bool have = false; double bv = 0.0; int64_t bi = -1;
+    DFH_TRY(argmax_update(ctx, val + off[g], m_per_group[g], 0, &have, &bv, &bi));
+    best_vals[g] = bv; best_idx[g] = bi;
+  }
+  if (vals_out) DFH_TRY(from_device(ctx, vals_out, val, (size_t)M * 8));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
 extern "C" int dfh_gp_predict_covar(dfh_gp* gp, const double* Xs, int64_t m, const double* Xh, int64_t q,
                                     double* mu_out, double* cov_out) {
   DFH_ARG(gp && m >= 0 && q >= 0);

@@ -523,6 +523,25 @@ class FittedGP(object):
       return bv.value, bi.value, vals
     return bv.value, bi.value
 
+  def add_ucb_all(self, betas, cands_per_group, return_vals=False):
+    """ add-UCB for every group of the additive kernel in one device call (one posterior solve for
+        all groups).  cands_per_group[g]: [m_g x |group g|].  Returns (best_vals, best_idx[, vals]). """
+    G = len(cands_per_group)
+    blocks = [_f64(c) for c in cands_per_group]
+    ms = np.ascontiguousarray([b.shape[0] for b in blocks], dtype=np.int64)
+    flat = np.ascontiguousarray(np.concatenate([b.ravel() for b in blocks]), dtype=np.float64)
+    be = _f64(np.asarray(betas, dtype=float).reshape(-1))
+    if len(be) != G:
+      raise ValueError('add_ucb_all: need one beta per group.')
+    bv = np.empty(G, dtype=np.float64)
+    bi = np.empty(G, dtype=np.int64)
+    vals = np.empty(int(ms.sum()), dtype=np.float64) if return_vals else None
+    check(self.engine.lib.dfh_gp_add_ucb_all(self.handle, _ptr(be), _ptr(flat), _ptr(ms), _ptr(vals),
+                                             _ptr(bv), _ptr(bi)))
+    if return_vals:
+      return bv, bi, np.split(vals, np.cumsum(ms)[:-1])
+    return bv, bi
+
 
 _default_engine = None
 

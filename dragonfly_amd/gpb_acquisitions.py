@@ -170,12 +170,16 @@ def _add_ucb(gp, add_kernel, mean_funcs, anc_data):
   group_points = []
   num_coordinates = 0
   anc_data.max_evals = total_max_evals//num_groups
+  # The candidate sets are drawn group by group exactly as the reference's loop does (the
+  # acquisition itself consumes no random numbers), then all groups go to the device in one call.
+  betas, cands = [], []
   for j, group_j in enumerate(groupings):
-    betath_j = _get_add_ucb_beta_th(len(group_j), anc_data.t)
+    betas.append(_get_add_ucb_beta_th(len(group_j), anc_data.t))
     bounds_j = domain_bounds[group_j]
-    cands_j = map_to_bounds(np.random.random((int(anc_data.max_evals), len(bounds_j))), bounds_j)
-    _, idx = gp.device_gp.add_ucb_group(j, betath_j, cands_j)
-    point_j = cands_j[idx]
+    cands.append(map_to_bounds(np.random.random((int(anc_data.max_evals), len(bounds_j))), bounds_j))
+  _, idxs = gp.device_gp.add_ucb_all(betas, cands)
+  for cands_j, idx in zip(cands, idxs):
+    point_j = cands_j[int(idx)]
     group_points.append(point_j)
     num_coordinates += len(point_j)
   anc_data.max_evals = total_max_evals

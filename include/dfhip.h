@@ -241,6 +241,12 @@ int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block, const doub
  *   mu_g = scale*k_g(Xg, X[:,g]) alpha ; sd_g from the shared L ; val = mu_g + beta*sd_g.   */
 int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, const double* Xg, int64_t m,
                          double* vals_out, double* best_val, int64_t* best_idx);
+/* All groups of the additive model in one call: group g's candidates Xg_all + sum_{h<g} m_h*|group h|
+ * ([m_g x |group g|]), betas[g], results best_vals[g] / best_idx[g] (index within the group's
+ * candidates), vals_out [sum m_g] or NULL.  The G triangular solves of the reference
+ * (opt/gpb_acquisitions.py:161-176) become one solve with sum(m_g) right-hand sides.            */
+int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double* Xg_all, const int64_t* m_per_group,
+                       double* vals_out, double* best_vals, int64_t* best_idx);
 
 /* ---- timing of the last call's dominant kernels (HIP events, ms) ------------------------- */
 #define DFH_T_KERNMAT  0   /* training kernel-matrix build                                   */

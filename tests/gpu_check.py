@@ -404,7 +404,75 @@ def stage_append():
   print('STAGE append PASS')
 
 
-STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append']
+def stage_configs():
+  """ wall-clock of BASELINE configs 2, 3 and 5 (fit + candidate stage), inputs resident in HBM """
+  from dragonfly_amd.engine import Engine, KernelSpec
+  from oracle import ref_numpy as O
+  eng = Engine()
+  def timed(fn, reps=3):
+    fn(); eng.sync()
+    t0 = time.time()
+    for _ in range(reps):
+      fn()
+    eng.sync()
+    return (time.time() - t0) / reps * 1e3
+  # C2: Hartmann6-like, n=4096, d=6, Matern-2.5, EI over 65536 candidates
+  rs = np.random.RandomState(102)
+  n, d, m = 4096, 6, 65536
+  X = rs.random_sample((n, d)); Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+  spec = KernelSpec('matern', d, float(Y.var()), 0.5 * np.ones(d), nu=2.5)
+  Xd, yd, cd = eng.to_device(X), eng.to_device(Y - np.median(Y)), eng.to_device(np.random.RandomState(202).random_sample((m, d)))
+  noise = float(Y.var() / 20)
+  box = {}
+  def c2():
+    gp = eng.gp_fit(spec, Xd, yd, noise); box['r'] = gp.acq_argmax('ei', cd, params=(float(Y.max()), 0.0)); gp.free()
+  t_fit = timed(lambda: eng.gp_fit(spec, Xd, yd, noise).free())
+  t_all = timed(c2)
+  print('C2 n=4096 d=6 matern2.5 EI m=65536: fit %.2f ms, fit+acq %.2f ms (TRSM 1.1e12 flop -> %.1f TF/s over the acq stage)'
+        % (t_fit, t_all, 4096.0 ** 2 * 65536 / ((t_all - t_fit) * 1e-3) / 1e12))
+  # C3: n=16384, d=32, SE-ARD, posterior (mu, sigma) at 65536 candidates
+  rs = np.random.RandomState(103)
+  n, d, m = 16384, 32, 65536
+  X = rs.random_sample((n, d)); Y = (X ** 2).dot((np.arange(d) + 1.0) / d) + 0.01 * rs.randn(n)
+  spec = KernelSpec('se', d, float(Y.var()), 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0))
+  Xd, yd, cd = eng.to_device(X), eng.to_device(Y - np.median(Y)), eng.to_device(np.random.RandomState(203).random_sample((m, d)))
+  noise = float(Y.var() / 20)
+  def c3():
+    gp = eng.gp_fit(spec, Xd, yd, noise); box['r'] = gp.acq_argmax('ucb', cd, params=(2.0, 0.0)); gp.free()
+  t_fit = timed(lambda: eng.gp_fit(spec, Xd, yd, noise).free(), reps=2)
+  t_all = timed(c3, reps=2)
+  print('C3 n=16384 d=32 SE-ARD posterior m=65536: fit %.2f ms, fit+posterior+argmax %.2f ms (TRSM 1.76e13 flop -> %.1f TF/s)'
+        % (t_fit, t_all, 16384.0 ** 2 * 65536 / ((t_all - t_fit) * 1e-3) / 1e12))
+  # C5: additive d=100, 20 groups of 5, n=4096, add-UCB with 3276 candidates per group
+  rs = np.random.RandomState(105)
+  n, d, G = 4096, 100, 20
+  X = rs.random_sample((n, d)); Y = (X ** 2).sum(axis=1) / 10 + 0.05 * rs.randn(n)
+  perm = list(np.random.RandomState(405).permutation(d))
+  groups = [perm[i:i + 5] for i in range(0, d, 5)]
+  spec = KernelSpec('additive', d, float(Y.var()), groups=groups, sub_kinds=['se'] * G, sub_scales=[1.0] * G,
+                    sub_nus=[0.0] * G, sub_bandwidths=[0.2 * np.sqrt(5) * np.ones(5)] * G)
+  Xd, yd = eng.to_device(X), eng.to_device(Y - np.median(Y))
+  noise = float(Y.var() / 20)
+  ch = [np.random.RandomState(205 + g).random_sample((65536 // G, 5)) for g in range(G)]
+  cg = [eng.to_device(c) for c in ch]
+  def c5_groups():
+    gp = eng.gp_fit(spec, Xd, yd, noise)
+    for g in range(G):
+      box['r'] = gp.add_ucb_group(g, 2.0, cg[g])
+    gp.free()
+  def c5_all():
+    gp = eng.gp_fit(spec, Xd, yd, noise)
+    box['r'] = gp.add_ucb_all([2.0] * G, ch)
+    gp.free()
+  t_fit = timed(lambda: eng.gp_fit(spec, Xd, yd, noise).free())
+  t_grp = timed(c5_groups)
+  t_all = timed(c5_all)
+  print('C5 additive d=100 (20x5) n=4096 add-UCB 20 x 3276 candidates: fit %.2f ms, fit+acq %.2f ms in one call '
+        '(%.2f ms with one call per group)' % (t_fit, t_all, t_grp))
+  print('STAGE configs DONE')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs']
 
 if __name__ == '__main__':
   if len(sys.argv) == 3 and sys.argv[1] == '--run':

@@ -79,6 +79,13 @@ def test_config5_additive_d100_add_ucb_full_size(engine):
   assert relerr(gp.get_alpha(), og.alpha) < TOL
   assert abs(gp.lml - og.lml()) <= TOL * abs(og.lml())
   m_j = 65536 // G
+  # all 20 groups in one device call (one posterior solve) == the per-group calls
+  cands = [np.random.RandomState(205 + j).random_sample((m_j, 5)) for j in range(G)]
+  betas = [O.add_ucb_beta_th(5, n)] * G
+  bvs, bis, vals_all = gp.add_ucb_all(betas, cands, return_vals=True)
+  for j in (0, 7, 19):
+    bv, bi, vals = gp.add_ucb_group(j, betas[j], cands[j], return_vals=True)
+    assert bi == bis[j] and bv == bvs[j] and relerr(vals_all[j], vals) < 1e-12
   for j in (0, 7, 19):
     Xj = np.random.RandomState(205 + j).random_sample((m_j, 5))
     beta = O.add_ucb_beta_th(5, n)
