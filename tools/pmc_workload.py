@@ -29,6 +29,10 @@ for _ in range(2):
   eng.gemm(A2, B2, shape=(M, M, M), out=C2)
 eng.sync()
 print('pmc workload done')
+# one n=4096 factorisation: the pivot-step kernel (diag_step64_kernel) for the LDS counters
+Kc = eng.empty((4096, 4096))
+eng.kernel_matrix(spec, eng.to_device(rs.rand(4096, d)), None, diag_add=0.05, out=Kc)
+eng.cholesky(Kc)
 # FETCH_SIZE calibration in the GEMM's own load pattern (16 B per lane): A [32768 x 16384] is read
 # exactly once from HBM (4.295 GB, well past the 256 MB Infinity Cache), B [128 x 16384] (16.8 MB)
 # stays cache-resident, C is 33.5 MB.

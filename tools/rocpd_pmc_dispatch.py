@@ -24,6 +24,8 @@ def main(path, filts):
       util = cs['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024.0)    # 1024 SIMDs
       tf = cs.get('SQ_INSTS_VALU_MFMA_MOPS_F64', 0.0) * 512.0 / (d['us'] * 1e-6) / 1e12
       extra = ' | clock %.2f GHz MfmaUtil %.1f%% executed %.1f TF/s' % (cyc / (d['us'] * 1e3), 100 * util, tf)
+    if 'SQ_LDS_BANK_CONFLICT' in cs and cs.get('SQ_LDS_IDX_ACTIVE', 0) > 0:
+      extra = ' | LDS bank-conflict cycles / active cycles = %.3f' % (cs['SQ_LDS_BANK_CONFLICT'] / cs['SQ_LDS_IDX_ACTIVE'])
     if 'FETCH_SIZE' in cs:
       b = cs['FETCH_SIZE'] * 1024 * 2
       extra = ' | 2*FETCH_SIZE*1024 = %.3f GB -> %.2f TB/s' % (b / 1e9, b / (d['us'] * 1e-6) / 1e12)
