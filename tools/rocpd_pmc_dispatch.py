@@ -14,8 +14,15 @@ def main(path, filts):
   for did, name, grid, cname, val, us in rows:
     d = disp.setdefault(did, dict(name=name, grid=grid, us=us, c={}))
     d['c'][cname] = d['c'].get(cname, 0.0) + val
+  shown = {}
   for did, d in disp.items():
     if filts and not any(f in d['name'] for f in filts):
+      continue
+    key = (d['name'], d['grid'] // 65536 if 'diag_step' in d['name'] else d['grid'])
+    shown[key] = shown.get(key, 0) + 1
+    if shown[key] > 3:          # at most three dispatches per kernel and launch shape
+      continue
+    if 'gemm_f64' in d['name'] and d['us'] < 500.0:     # the factorisation's many small GEMMs
       continue
     cs = d['c']
     extra = ''
