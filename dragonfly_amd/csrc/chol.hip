@@ -25,11 +25,11 @@ constexpr int PB = 64;       // pivot block
 constexpr int PBP = 65;      // LDS row stride
 
 // ---------------------------------------------------------------------------------------------
-// 64 x 64 pivot-block kernels.  The block is factored by ONE wave (factor64_wave below: a row per
-// lane, columns published through LDS, deferred rank-1 updates); history of the alternatives
-// measured on gfx950: a 256-thread column-per-thread version with one barrier per column (100 us),
-// its rank-4 blocked form with 16 barriers (58k cycles), a single-wave all-v_readlane form
-// (~29 cycles per readlane pair + FMA: slower), the present one (36k cycles).
+// 64 x 64 pivot-block kernels.  The block is factored by the four waves of a workgroup without
+// barriers (factor64_waves below); history of the alternatives measured on gfx950: a 256-thread
+// column-per-thread version with one barrier per column (100 us), its rank-4 blocked form with 16
+// barriers (58k cycles), a single-wave all-v_readlane form (~29 cycles per readlane pair + FMA:
+// slower), a single wave with LDS-broadcast columns and deferred updates (36k cycles, issue-bound).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_block64(const double* __restrict__ A, long lda, int nb, int w,
                                               int k, double (&a)[16]) {
@@ -80,106 +80,192 @@ __device__ __forceinline__ void fast_rsqrt_sqrt(double d, double* rs, double* sq
   *sq = s;
 }
 
+// Factorisation of the 64 x 64 pivot block by the four waves of the workgroup.  Lane i of every
+// wave holds row i; wave w owns the 16 columns 16w .. 16w+15 (16 doubles per lane).
+//
+// The elimination runs on UNSCALED columns (LDL^T style): with u[:,k] the column as it stands when
+// it becomes the pivot column and d_k = u[k][k],
+//     a[i][j] -= (u[i][k] / d_k) * u[j][k]          for j > k,
+// and only at the very end L[:,k] = u[:,k] / sqrt(d_k).  The dependent chain from one pivot to the
+// next is then  v_readlane d_k -> v_rcp_f64 + two Newton steps -> multiply -> one FMA  (7 dependent
+// VALU operations; a dependent fp64 operation costs ~25 cycles here) -- the reciprocal square root
+// with its ~20 dependent operations is off the chain: sixteen independent ones per wave at the end.
+//   * The OWNER of the current 16 columns runs that chain inside the wave (the element u[k+1][k]
+//     comes from lane k+1 by v_readlane), updates its next column eagerly and its other columns
+//     one step late, and publishes every finished column u[:,k] and 1/d_k to an LDS ring, then
+//     raises the column's flag.  A wave's LDS operations execute in order, so data -> flag needs
+//     only a compiler barrier, no s_waitcnt.
+//   * The waves owning LATER columns consume published columns as their flags come up: one
+//     per-lane read (their row's element) + 8 broadcast ds_read_b128 + 16 FMAs per column.
+//   * Waves owning earlier columns are finished (wave 0 then stages the panel rows).
+// No workgroup barrier inside the 64 steps.  History of this kernel on gfx950: 256 threads with a
+// barrier per column (100 us), rank-4 blocked with 16 barriers (58k cycles), one wave with
+// LDS-broadcast columns (36k cycles, issue-bound: 7300 instructions x 4 cycles), four waves with
+// the rsqrt on the chain (38k: latency-bound), this one.
+// Branch-free: a non-positive / NaN pivot only raises a flag (columns and flags are still
+// published, so nobody waits forever).
+#define COMPILER_BARRIER() asm volatile("" ::: "memory")
+
+// Owner step for column k = 16 w + KL.  The published ring slot of column k holds u[i][k] for the
+// rows i >= 1 and, in row 0's place, 1/d_k (row 0 of a column k >= 1 lies above the diagonal and
+// is never read as data; for k = 0 only row 0's own -- unused -- updates see it).  A non-zero
+// row-0 entry doubles as the "published" flag: the ring's row-0 entries are zeroed beforehand, and
+// a wave's ds_write_b64 lands as one LDS operation.
+template <int KL>
+__device__ __forceinline__ void f64_owner_step(double (&a)[16], int lane, int w, double* ring, int& bad,
+                                               double& mprev) {
 #define SB() __builtin_amdgcn_sched_barrier(0)
-// one column step of factor64_wave (K is a template parameter so that every register index is a
-// compile-time constant: a partially unrolled loop would put the 64-double row into scratch)
-template <int K>
-__device__ __forceinline__ void f64w_step(double (&a)[PB], int lane, double* colbuf, double& my_diag,
-                                          int& bad, double& lprev) {
-  constexpr int k = K;
-    const double* cbp = colbuf + ((k + 1) & 1) * PB;       // column published by step k-1
-    constexpr int jb = k + 1;                                  // first deferred column
-    constexpr int ngroups = (k >= 1) ? (PB - jb + 7) / 8 : 0;  // groups of 8 columns jb + 8g ...
-    double c0[8], c1[8];
-#define LOAD_GROUP(g, arr)                                                                      \
-    if ((g) < ngroups) {                                                                          \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
-        const int j = jb + 8 * (g) + t;                                                           \
-        arr[t] = (j < PB) ? cbp[j] : 0.0;                                                         \
-      }                                                                                           \
-    }
-#define FMA_GROUP(g, arr)                                                                       \
-    if ((g) < ngroups) {                                                                          \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
-        const int j = jb + 8 * (g) + t;                                                           \
-        if (j < PB) a[j] = fma(-lprev, arr[t], a[j]);                                             \
-      }                                                                                           \
-    }
-    // group 0 holds column k+1, which the eager update below needs: it is consumed first
-    LOAD_GROUP(0, c0);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(a[k]), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(a[k]), k);
-    const double d = __hiloint2double(hi, lo);
-    bad = (bad < 0 && !(d > 0.0)) ? k : bad;               // uniform: d is the same in every lane
-    SB();
-    LOAD_GROUP(1, c1);
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    SB();
-    FMA_GROUP(0, c0); LOAD_GROUP(2, c0);
-    double t1 = h * y;
-    SB();
-    FMA_GROUP(1, c1); LOAD_GROUP(3, c1);
-    double e = fma(-t1, y, 0.5);
-    SB();
-    FMA_GROUP(2, c0); LOAD_GROUP(4, c0);
-    y = fma(y, e, y);
-    SB();
-    FMA_GROUP(3, c1); LOAD_GROUP(5, c1);
-    t1 = h * y;
-    SB();
-    FMA_GROUP(4, c0); LOAD_GROUP(6, c0);
-    e = fma(-t1, y, 0.5);
-    SB();
-    FMA_GROUP(5, c1); LOAD_GROUP(7, c1);
-    y = fma(y, e, y);
-    SB();
-    FMA_GROUP(6, c0);
-    double sq = d * y;
-    SB();
-    FMA_GROUP(7, c1);
-    const double res = fma(-sq, sq, d);
-    const double hy = 0.5 * y;
-    SB();
-    sq = fma(res, hy, sq);                                  // sqrt(d)
-    const double e2 = fma(-sq, y, 1.0);
-    const double r = fma(e2, y, y);                         // 1/sqrt(d), consistent with sq
-    const double l = (lane == k) ? sq : a[k] * r;
-    my_diag = (lane == k) ? sq : my_diag;
-    a[k] = (lane >= k) ? l : 0.0;                           // column k is final (zero above the diagonal)
-    if (k + 1 < PB) {
-      colbuf[(k & 1) * PB + lane] = l;                      // published for the deferred update in step k+1
-      const int slo = __builtin_amdgcn_readlane(__double2loint(l), k + 1);
-      const int shi = __builtin_amdgcn_readlane(__double2hiint(l), k + 1);
-      a[k + 1] = fma(-l, __hiloint2double(shi, slo), a[k + 1]);      // eager: next pivot column
-    }
-    lprev = l;
-    SB();
-}
+  const int k = 16 * w + KL;
+  // Column k updates the next TWO own columns eagerly, through v_readlane (no LDS on the way to the
+  // next pivot); the previous own column's update of columns KL+2 .. 15 comes one step late through
+  // the LDS ring: those reads are issued first and are consumed inside the chain's stalls.
+  double c[16];
+  if (KL >= 1) {
+    const double* cbp = ring + (k - 1) * PB + 16 * w;
+#pragma unroll
+    for (int j = KL + 2; j < 16; ++j) c[j] = cbp[j];
+  }
+  const int lo = __builtin_amdgcn_readlane(__double2loint(a[KL]), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(a[KL]), k);
+  const double d = __hiloint2double(hi, lo);
+  bad = (bad < 0 && !(d > 0.0)) ? k : bad;                  // uniform: d is the same in every lane
+  // dependent chain readlane -> rcp -> 4 FMA -> mul -> FMA, with the deferred FMAs pinned into its
+  // stalls (in-order issue: left to itself the compiler puts them behind the chain, or -- worse --
+  // sinks them to where each column is needed)
+  double rc = __builtin_amdgcn_rcp(d);
+  double t1 = 0.0, t2 = 0.0;
+  if (KL + 1 < 16) {
+    t1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[KL]), k + 1),
+                          __builtin_amdgcn_readlane(__double2loint(a[KL]), k + 1));      // u[k+1][k]
+  }
+  if (KL + 2 < 16) {
+    t2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[KL]), k + 2),
+                          __builtin_amdgcn_readlane(__double2loint(a[KL]), k + 2));      // u[k+2][k]
+  }
+  SB();
+  if (KL >= 1) {
+#pragma unroll
+    for (int j = KL + 2; j < 16 && j < KL + 6; ++j) a[j] = fma(-mprev, c[j], a[j]);
+  }
+  double er = fma(-d, rc, 1.0);
+  SB();
+  if (KL >= 1) {
+#pragma unroll
+    for (int j = KL + 6; j < 16 && j < KL + 10; ++j) a[j] = fma(-mprev, c[j], a[j]);
+  }
+  rc = fma(rc, er, rc);
+  SB();
+  if (KL >= 1) {
+#pragma unroll
+    for (int j = KL + 10; j < 16; ++j) a[j] = fma(-mprev, c[j], a[j]);
+  }
+  er = fma(-d, rc, 1.0);
+  SB();
+  rc = fma(rc, er, rc);
+  SB();
+  const double m = a[KL] * rc;                                // u[i][k] / d_k
+  if (KL + 1 < 16) a[KL + 1] = fma(-m, t1, a[KL + 1]);        // eager: the next pivot column
+  SB();
+  if (KL + 2 < 16) a[KL + 2] = fma(-m, t2, a[KL + 2]);        // and the one after it
+  // publish: the column, with 1/d_k (never exactly zero here: it is the flag) in row 0's place
+  const double rcpub = (rc == 0.0) ? 1.0 : rc;
+  ring[k * PB + lane] = (lane == 0) ? rcpub : a[KL];
+  mprev = m;
+  SB();
 #undef SB
-#undef LOAD_GROUP
-#undef FMA_GROUP
-
-template <int... Ks>
-__device__ __forceinline__ void f64w_run(double (&a)[PB], int lane, double* colbuf, double& my_diag, int& bad,
-                                         double& lprev, std::integer_sequence<int, Ks...>) {
-  (f64w_step<Ks>(a, lane, colbuf, my_diag, bad, lprev), ...);
 }
 
-__device__ __forceinline__ int factor64_wave(double (&a)[PB], int lane, double* colbuf, double* diag_out) {
-  // Software pipeline: the rank-1 update of step k-1 for the columns beyond k is deferred into
-  // step k, where it is independent of pivot k's dependent chain
-  //   readlane a[k] -> rsqrt (Newton) -> scale -> readlane L[k+1][k] -> FMA into column k+1.
-  // The deferred columns are processed in groups of 8 (four broadcast ds_read_b128 each); group g
-  // is loaded before chain operation g and consumed after chain operation g+1, so LDS latency
-  // and the chain's issue stalls hide each other.  sched_barriers pin that interleaving -- left
-  // alone the compiler serialises every LDS read behind an s_waitcnt (measured: 86k cycles for
-  // the 64 steps instead of ~30k).  Branch-free: a bad pivot only raises a flag.
-  double my_diag = 1.0;
+template <int... KLs>
+__device__ __forceinline__ void f64_owner_block(double (&a)[16], int lane, int w, double* ring, int& bad,
+                                                std::integer_sequence<int, KLs...>) {
+  double mprev = 0.0;
+  (f64_owner_step<KLs>(a, lane, w, ring, bad, mprev), ...);
+}
+
+// Apply NC published columns k0 .. k0+NC-1 of an earlier block to this wave's columns.  Columns
+// are published in order, so the flag of the last one covers them all.  SPEC: flag and data are
+// read in ONE LDS round trip (the flag first: LDS serves a wave's reads in order, so if the flag
+// was up the data behind it is valid; otherwise everything is re-read) -- for the wave that is
+// about to become the owner; the others poll the flag alone: the 16 broadcast values per column
+// cost 8 LDS clocks per ds_read_b128, and with up to three waves consuming every column the LDS
+// is the shared bottleneck (measured alternatives: speculative prefetch for everybody 27.9k
+// cycles for the block, v_readlane instead of LDS broadcasts 52k, this 26.5k).
+// The polls are bounded (about 0.2 s) so that a logic error could never hang the GPU: the owner of
+// an earlier block never waits on anything, in practice a flag is up within a few hundred cycles.
+template <int NC, bool SPEC>
+__device__ __forceinline__ void f64_consume_cols(double (&a)[16], int lane, int w, int k0, const double* ring) {
+  double rcv[NC], u[NC], cb[NC][16];
+  auto read_cols = [&]() {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      rcv[c] = ring[(k0 + c) * PB];
+      u[c] = ring[(k0 + c) * PB + lane];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cb[c][j] = ring[(k0 + c) * PB + 16 * w + j];
+    }
+  };
+  if (SPEC) {
+    for (int spins = 0; spins < (1 << 22); ++spins) {
+      COMPILER_BARRIER();                              // re-read LDS in every iteration
+      const double flag = ring[(k0 + NC - 1) * PB];
+      COMPILER_BARRIER();                              // the flag read is issued before the data reads
+      read_cols();
+      if (flag != 0.0) break;
+    }
+  } else {
+    for (int spins = 0; spins < (1 << 22); ++spins) {
+      COMPILER_BARRIER();
+      if (ring[(k0 + NC - 1) * PB] != 0.0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    COMPILER_BARRIER();
+    read_cols();
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double m = u[c] * rcv[c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = fma(-m, cb[c][j], a[j]);
+  }
+}
+
+__device__ __forceinline__ void f64_consume_block(double (&a)[16], int lane, int w, int kb, const double* ring) {
+  const int kb0 = 16 * kb;
+  f64_consume_cols<4, false>(a, lane, w, kb0, ring);
+  f64_consume_cols<4, false>(a, lane, w, kb0 + 4, ring);
+  f64_consume_cols<4, false>(a, lane, w, kb0 + 8, ring);
+  if (w == kb + 1) {
+    // the next owner is waiting for exactly these: take them as they come
+    f64_consume_cols<2, false>(a, lane, w, kb0 + 12, ring);
+    f64_consume_cols<1, true>(a, lane, w, kb0 + 14, ring);
+    f64_consume_cols<1, true>(a, lane, w, kb0 + 15, ring);
+  } else {
+    f64_consume_cols<4, false>(a, lane, w, kb0 + 12, ring);
+  }
+}
+
+// On return a[] holds this wave's 16 columns of L (zero above the diagonal); returns the first bad
+// column of the wave's own block or -1.  rdiag_out: 1 / L[lane][lane] for the lanes whose column
+// this wave owns.
+__device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, double* ring, double* rdiag_out,
+                                              long long* dbg_stamp = nullptr) {
   int bad = -1;
-  double lprev = 0.0;
-  f64w_run(a, lane, colbuf, my_diag, bad, lprev, std::make_integer_sequence<int, PB>{});
-  *diag_out = my_diag;
+  for (int kb = 0; kb < w; ++kb) f64_consume_block(a, lane, w, kb, ring);
+  if (dbg_stamp) dbg_stamp[0] = (long long)__builtin_amdgcn_s_memtime();
+  f64_owner_block(a, lane, w, ring, bad, std::make_integer_sequence<int, 16>{});
+  if (dbg_stamp) dbg_stamp[1] = (long long)__builtin_amdgcn_s_memtime();
+  // scale the columns, L[:,k] = u[:,k] * sqrt(1/d_k): sixteen independent square-root chains
+  double my_r = 1.0;
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) {
+    const int k = 16 * w + kl;
+    const double rck = ring[k * PB];                 // 1/d_k as published
+    double rs, sq;
+    fast_rsqrt_sqrt(rck, &rs, &sq);                  // sq = sqrt(1/d_k) = 1/L[k][k], rs = sqrt(d_k) = L[k][k]
+    a[kl] = (lane == k) ? rs : ((lane > k) ? a[kl] * sq : 0.0);
+    my_r = (lane == k) ? sq : my_r;
+  }
+  *rdiag_out = my_r;
   return bad;
 }
 
@@ -214,7 +300,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* Sp = dsm;                       // [64][SPP] factor, columns permuted by perm16
   double* R = dsm + PB * SPP;             // [64][65] panel rows
-  double* colbuf = dsm + PB * SPP + PB * PBP;      // [2][4][64] published panel columns
+  double* colbuf = dsm + PB * SPP + PB * PBP;      // [64] reciprocal diagonal, then the column ring and its flags
   const int tid = threadIdx.x;
   const int k = tid & 63, w = tid >> 6;
 
@@ -228,35 +314,54 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     if (i < nb && k < nb) v = (k <= i) ? D[i * lda + k] : 0.0;
     Sp[i * SPP + k] = v;
   }
-  __shared__ int s_bad;
+  __shared__ int s_badv[4];
+  double* rdiag = colbuf;                          // [64] 1 / L[c][c]
+  double* ring = colbuf + PB;                      // [64][64] published (unscaled) columns
+  if (tid < PB) ring[tid * PB] = 0.0;              // row-0 entries double as the "published" flags
   __syncthreads();
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  double* rdiag = colbuf + 2 * PB;                 // 1 / L[c][c]
   const int r0 = ((int)blockIdx.x - 1) * PB;
   double* Pn = D + (long)(nb + r0) * lda;
-  if (w == 0) {
-    double a[PB];
+  {
+    double a[16];
 #pragma unroll
-    for (int j = 0; j < PB; ++j) a[j] = Sp[k * SPP + j];      // lane k <- row k
-    double my_diag = 1.0;
-    const int bad = factor64_wave(a, k, colbuf, &my_diag);
-    if (k == 0) s_bad = bad;
-    if (bad < 0) {
-      // factor image for the row solves: Sp[row][perm16(col)], and the reciprocal diagonal
-#pragma unroll
-      for (int j = 0; j < PB; ++j) Sp[k * SPP + perm16(j)] = a[j];
-      rdiag[k] = fast_div(1.0, my_diag, fast_rcp(my_diag));
+    for (int j = 0; j < 16; ++j) a[j] = Sp[k * SPP + 16 * w + j];      // lane k <- row k, this wave's columns
+    __syncthreads();                               // the staged block is read: Sp may take the factor image
+    double my_rdiag = 1.0;
+    long long stamp[2] = {0, 0};
+    const bool dbg = info_dbg[7] != 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0;
+    const int bad = factor64_waves(a, k, w, ring, &my_rdiag, dbg ? stamp : nullptr);
+    if (k == 0) s_badv[w] = bad;
+    if (dbg && k == 0) {
+      // waves 0 / 1: start and end of the own 16 columns, relative to t1 (debug hook only)
+      if (w == 0) { info_dbg[0] = stamp[0] - (long long)t1; info_dbg[1] = stamp[1] - (long long)t1; }
+      if (w == 1) { info_dbg[5] = stamp[0] - (long long)t1; info_dbg[6] = stamp[1] - (long long)t1; }
     }
-  } else if (blockIdx.x > 0) {
-    // meanwhile waves 1-3 stage this workgroup's 64 panel rows (coalesced along the row)
-    for (int idx = tid - 64; idx < PB * PB; idx += 192) {
-      const int i = idx >> 6, kk = idx & 63;
-      R[i * PBP + kk] = (r0 + i < rows_below && kk < nb) ? Pn[i * lda + kk] : 0.0;
+    // factor image for the row solves: Sp[row][perm16(col)], and the reciprocal diagonal
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Sp[k * SPP + perm16(16 * w + j)] = a[j];
+    if ((k >> 4) == w) rdiag[k] = my_rdiag;
+    if (w == 0 && blockIdx.x > 0) {
+      // wave 0 is done after the first 16 columns: it stages this workgroup's 64 panel rows
+      // (coalesced along the row) while the other waves finish the factorisation
+      // (16 loads in flight at a time: one load per iteration would cost a full memory latency each)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double tmp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 16 * c + r;
+          tmp[r] = (r0 + i < rows_below && k < nb) ? Pn[i * lda + k] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R[(16 * c + r) * PBP + k] = tmp[r];
+      }
     }
   }
   __syncthreads();
   const unsigned long long t2 = __builtin_amdgcn_s_memtime();
   if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) { info_dbg[2] = (long long)(t1 - t0); info_dbg[3] = (long long)(t2 - t1); }
+  const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
   if (s_bad >= 0) {
     if (blockIdx.x == 0 && tid == 0 && info[0] == 0) info[0] = pivot_base + s_bad + 1;
     return;
@@ -326,7 +431,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   }
   if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) info_dbg[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
 }
-constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + 8 * PB) * 8;
+constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB) * 8;   // image, panel rows, rdiag, ring
 
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
@@ -671,7 +776,7 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
 // Diagnostics hook (not part of the product path): times `reps` back-to-back launches of the
 // 64-wide diagonal step on a synthetic SPD block and returns in-kernel cycle stamps.
 extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, double* ms_per_launch,
-                                   long long* cycles_out /* [3]: load, factor, trsm */) {
+                                   long long* cycles_out /* [7]: load, factor, trsm, waves 0-3 */) {
   DFH_ARG(ctx && reps > 0 && rows_below >= 0 && rows_below <= 448);
   DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(diag_step64_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));
@@ -702,7 +807,8 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   long long out[8];
   DFH_HIP(hipMemcpy(out, d_info + CHOL_MAX_BATCH, sizeof(out), hipMemcpyDeviceToHost));
   if (ms_per_launch) *ms_per_launch = ms / reps;
-  if (cycles_out) { cycles_out[0] = out[2]; cycles_out[1] = out[3]; cycles_out[2] = out[4]; }
+  if (cycles_out) { cycles_out[0] = out[2]; cycles_out[1] = out[3]; cycles_out[2] = out[4];
+                    cycles_out[3] = out[0]; cycles_out[4] = out[1]; cycles_out[5] = out[5]; cycles_out[6] = out[6]; }
   long long zero[8] = {0};
   DFH_HIP(hipMemcpy(d_info + CHOL_MAX_BATCH, zero, sizeof(zero), hipMemcpyHostToDevice));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
