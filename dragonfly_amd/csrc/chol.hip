@@ -105,6 +105,7 @@ __device__ __forceinline__ void fast_rsqrt_sqrt(double d, double* rs, double* sq
 // Branch-free: a non-positive / NaN pivot only raises a flag (columns and flags are still
 // published, so nobody waits forever).
 #define COMPILER_BARRIER() asm volatile("" ::: "memory")
+constexpr int SPP_STAGE = 66;   // row stride of the staged pivot block (= SPP of the factor image, below)
 
 // Owner step for column k = 16 w + KL.  The published ring slot of column k holds u[i][k] for the
 // rows i >= 1 and, in row 0's place, 1/d_k (row 0 of a column k >= 1 lies above the diagonal and
@@ -182,75 +183,84 @@ __device__ __forceinline__ void f64_owner_block(double (&a)[16], int lane, int w
   (f64_owner_step<KLs>(a, lane, w, ring, bad, mprev), ...);
 }
 
-// Apply NC published columns k0 .. k0+NC-1 of an earlier block to this wave's columns.  Columns
-// are published in order, so the flag of the last one covers them all.  SPEC: flag and data are
-// read in ONE LDS round trip (the flag first: LDS serves a wave's reads in order, so if the flag
-// was up the data behind it is valid; otherwise everything is re-read) -- for the wave that is
-// about to become the owner; the others poll the flag alone: the 16 broadcast values per column
-// cost 8 LDS clocks per ds_read_b128, and with up to three waves consuming every column the LDS
-// is the shared bottleneck (measured alternatives: speculative prefetch for everybody 27.9k
-// cycles for the block, v_readlane instead of LDS broadcasts 52k, this 26.5k).
-// The polls are bounded (about 0.2 s) so that a logic error could never hang the GPU: the owner of
+// Consumption of published columns by a wave that owns later columns: a rank-NV update of the
+// wave's 64 x 16 block on the matrix cores,
+//     acc[t] -= U[rows of tile t][k0 .. k0+3] * diag(1/d) * U[this wave's 16 rows][k0 .. k0+3]^T,
+// one v_mfma_f64_16x16x4 per 16-row tile.  Every lane fetches ONE element per operand from the
+// ring (per-lane addresses, 4 LDS clocks per read): 6 reads per four columns.  The earlier
+// FMA formulation needed the sixteen u[j][k] in every lane -- 8 broadcast ds_read_b128 of 8 LDS
+// clocks each per column; with up to three waves consuming every column that saturated the LDS
+// (and slowed the owner's chain with it).  While it is a consumer, the wave keeps its block in the
+// MFMA accumulator layout: acc[t][r] = element (row 16t + (lane>>4) + 4r, column 16w + (lane&15)).
+// NV < 4: only the first NV of the four columns are published yet; the others are masked to zero.
+// Flag and data come in ONE LDS round trip (the flag first: LDS serves a wave's reads in order, so
+// if the flag was up the data behind it is valid; otherwise everything is re-read -- cheap now).
+// The poll is bounded (about 0.2 s) so that a logic error could never hang the GPU: the owner of
 // an earlier block never waits on anything, in practice a flag is up within a few hundred cycles.
-template <int NC, bool SPEC>
-__device__ __forceinline__ void f64_consume_cols(double (&a)[16], int lane, int w, int k0, const double* ring) {
-  double rcv[NC], u[NC], cb[NC][16];
-  auto read_cols = [&]() {
+template <int NV>
+__device__ __forceinline__ void f64_consume_mfma(double4_t (&acc)[4], int lane, int w, int k0, int kvalid0,
+                                                 const double* ring) {
+  // columns k0 + kvalid0 .. k0 + kvalid0 + NV - 1 are applied (the ones before were applied earlier)
+  const int kq = lane >> 4, l15 = lane & 15;
+  const double* col = ring + (k0 + kq) * PB;
+  double rcv = 0.0, bu = 0.0, au[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int spins = 0; spins < (1 << 22); ++spins) {
+    COMPILER_BARRIER();                                // LDS is re-read in every iteration
+    const double flag = ring[(k0 + kvalid0 + NV - 1) * PB];
+    COMPILER_BARRIER();                                // the flag read is issued before the data reads
+    rcv = col[0];
+    bu = col[16 * w + l15];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      rcv[c] = ring[(k0 + c) * PB];
-      u[c] = ring[(k0 + c) * PB + lane];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) cb[c][j] = ring[(k0 + c) * PB + 16 * w + j];
-    }
-  };
-  if (SPEC) {
-    for (int spins = 0; spins < (1 << 22); ++spins) {
-      COMPILER_BARRIER();                              // re-read LDS in every iteration
-      const double flag = ring[(k0 + NC - 1) * PB];
-      COMPILER_BARRIER();                              // the flag read is issued before the data reads
-      read_cols();
-      if (flag != 0.0) break;
-    }
-  } else {
-    for (int spins = 0; spins < (1 << 22); ++spins) {
-      COMPILER_BARRIER();
-      if (ring[(k0 + NC - 1) * PB] != 0.0) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    COMPILER_BARRIER();
-    read_cols();
+    for (int t = 0; t < 4; ++t) au[t] = col[16 * t + l15];
+    if (flag != 0.0) break;
+    __builtin_amdgcn_s_sleep(1);
   }
+  const bool valid = (kq >= kvalid0) && (kq < kvalid0 + NV);
+  const double bneg = valid ? -(bu * rcv) : 0.0;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const double m = u[c] * rcv[c];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = fma(-m, cb[c][j], a[j]);
-  }
+  for (int t = 0; t < 4; ++t)
+    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(valid ? au[t] : 0.0, bneg, acc[t], 0, 0, 0);
 }
 
-__device__ __forceinline__ void f64_consume_block(double (&a)[16], int lane, int w, int kb, const double* ring) {
+__device__ __forceinline__ void f64_consume_block(double4_t (&acc)[4], int lane, int w, int kb, const double* ring) {
   const int kb0 = 16 * kb;
-  f64_consume_cols<4, false>(a, lane, w, kb0, ring);
-  f64_consume_cols<4, false>(a, lane, w, kb0 + 4, ring);
-  f64_consume_cols<4, false>(a, lane, w, kb0 + 8, ring);
-  if (w == kb + 1) {
-    // the next owner is waiting for exactly these: take them as they come
-    f64_consume_cols<2, false>(a, lane, w, kb0 + 12, ring);
-    f64_consume_cols<1, true>(a, lane, w, kb0 + 14, ring);
-    f64_consume_cols<1, true>(a, lane, w, kb0 + 15, ring);
-  } else {
-    f64_consume_cols<4, false>(a, lane, w, kb0 + 12, ring);
-  }
+  f64_consume_mfma<4>(acc, lane, w, kb0, 0, ring);
+  f64_consume_mfma<4>(acc, lane, w, kb0 + 4, 0, ring);
+  f64_consume_mfma<4>(acc, lane, w, kb0 + 8, 0, ring);
+  // (taking the last four columns one at a time for the wave that owns the next block does not
+  //  pay: every batch costs a full LDS round trip plus the MFMA latency, ~450 cycles)
+  f64_consume_mfma<4>(acc, lane, w, kb0 + 12, 0, ring);
 }
 
-// On return a[] holds this wave's 16 columns of L (zero above the diagonal); returns the first bad
-// column of the wave's own block or -1.  rdiag_out: 1 / L[lane][lane] for the lanes whose column
-// this wave owns.
-__device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, double* ring, double* rdiag_out,
-                                              long long* dbg_stamp = nullptr) {
+// On return a[] holds this wave's 16 columns of L in the row-per-lane layout (zero above the
+// diagonal); returns the first bad column of the wave's own block or -1.  rdiag_out: 1 / L[lane][lane]
+// for the lanes whose column this wave owns.  stage: the pivot block as staged in LDS (row stride
+// SPP); tbuf: 64 x 17 doubles of LDS private to this wave (layout change consumer -> owner).
+__device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
+                                              double* ring, double* rdiag_out, long long* dbg_stamp = nullptr) {
   int bad = -1;
-  for (int kb = 0; kb < w; ++kb) f64_consume_block(a, lane, w, kb, ring);
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = stage[lane * SPP_STAGE + j];       // lane <- row, columns 0..15
+    __syncthreads();                                   // the staged block is read: its LDS may be reused
+  } else {
+    double4_t acc[4];
+    const int kq = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = stage[(16 * t + kq + 4 * r) * SPP_STAGE + 16 * w + l15];
+    __syncthreads();
+    for (int kb = 0; kb < w; ++kb) f64_consume_block(acc, lane, w, kb, ring);
+    // accumulator layout -> row per lane, through this wave's private LDS block
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tbuf[(16 * t + kq + 4 * r) * 17 + l15] = acc[t][r];
+    COMPILER_BARRIER();                                // same wave: LDS executes its operations in order
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = tbuf[lane * 17 + j];
+  }
   if (dbg_stamp) dbg_stamp[0] = (long long)__builtin_amdgcn_s_memtime();
   f64_owner_block(a, lane, w, ring, bad, std::make_integer_sequence<int, 16>{});
   if (dbg_stamp) dbg_stamp[1] = (long long)__builtin_amdgcn_s_memtime();
@@ -324,13 +334,11 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   double* Pn = D + (long)(nb + r0) * lda;
   {
     double a[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = Sp[k * SPP + 16 * w + j];      // lane k <- row k, this wave's columns
-    __syncthreads();                               // the staged block is read: Sp may take the factor image
     double my_rdiag = 1.0;
     long long stamp[2] = {0, 0};
     const bool dbg = info_dbg[7] != 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0;
-    const int bad = factor64_waves(a, k, w, ring, &my_rdiag, dbg ? stamp : nullptr);
+    double* tbuf = ring + PB * PB + (w > 0 ? (w - 1) : 0) * PB * 17;
+    const int bad = factor64_waves(a, k, w, Sp, tbuf, ring, &my_rdiag, dbg ? stamp : nullptr);
     if (k == 0) s_badv[w] = bad;
     if (dbg && k == 0) {
       // waves 0 / 1: start and end of the own 16 columns, relative to t1 (debug hook only)
@@ -431,7 +439,8 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   }
   if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) info_dbg[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
 }
-constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB) * 8;   // image, panel rows, rdiag, ring
+static_assert(SPP == SPP_STAGE, "staging stride");
+constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17) * 8;   // image, panel rows, rdiag, ring, 3 layout buffers
 
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
