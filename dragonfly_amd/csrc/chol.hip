@@ -233,11 +233,11 @@ __device__ __forceinline__ void f64_consume_block(double4_t (&acc)[4], int lane,
 }
 
 // On return a[] holds this wave's 16 columns of L in the row-per-lane layout (zero above the
-// diagonal); returns the first bad column of the wave's own block or -1.  rdiag_out: 1 / L[lane][lane]
-// for the lanes whose column this wave owns.  stage: the pivot block as staged in LDS (row stride
+// diagonal); returns the first bad column of the wave's own block or -1.  stage: the pivot block as staged in LDS (row stride
 // SPP); tbuf: 64 x 17 doubles of LDS private to this wave (layout change consumer -> owner).
 __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
-                                              double* ring, double* rdiag_out, long long* dbg_stamp = nullptr) {
+                                              double* ring, double* lbb, double* linv, double* rdiag,
+                                              long long* dbg_stamp = nullptr) {
   int bad = -1;
   if (w == 0) {
 #pragma unroll
@@ -264,18 +264,70 @@ __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, 
   if (dbg_stamp) dbg_stamp[0] = (long long)__builtin_amdgcn_s_memtime();
   f64_owner_block(a, lane, w, ring, bad, std::make_integer_sequence<int, 16>{});
   if (dbg_stamp) dbg_stamp[1] = (long long)__builtin_amdgcn_s_memtime();
-  // scale the columns, L[:,k] = u[:,k] * sqrt(1/d_k): sixteen independent square-root chains
+  // scale the columns, L[:,k] = u[:,k] * sqrt(1/d_k): sixteen independent square-root chains,
+  // written stage by stage across the sixteen so that no operation waits for its predecessor
+  // (one chain after the other costs 16 x 15 dependent operations of ~25 cycles)
   double my_r = 1.0;
+  {
+    double x[16], y[16], h[16], e[16], sq[16];
 #pragma unroll
-  for (int kl = 0; kl < 16; ++kl) {
-    const int k = 16 * w + kl;
-    const double rck = ring[k * PB];                 // 1/d_k as published
-    double rs, sq;
-    fast_rsqrt_sqrt(rck, &rs, &sq);                  // sq = sqrt(1/d_k) = 1/L[k][k], rs = sqrt(d_k) = L[k][k]
-    a[kl] = (lane == k) ? rs : ((lane > k) ? a[kl] * sq : 0.0);
-    my_r = (lane == k) ? sq : my_r;
+    for (int kl = 0; kl < 16; ++kl) x[kl] = ring[(16 * w + kl) * PB];      // 1/d_k as published
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) { y[kl] = __builtin_amdgcn_rsq(x[kl]); h[kl] = 0.5 * x[kl]; }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-(h[kl] * y[kl]), y[kl], 0.5);
+#pragma unroll
+      for (int kl = 0; kl < 16; ++kl) y[kl] = fma(y[kl], e[kl], y[kl]);     // y = 1/sqrt(x) = sqrt(d_k) = L[k][k]
+    }
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) sq[kl] = x[kl] * y[kl];
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) sq[kl] = fma(fma(-sq[kl], sq[kl], x[kl]), 0.5 * y[kl], sq[kl]);   // sqrt(x) = 1/L[k][k]
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-sq[kl], y[kl], 1.0);
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) y[kl] = fma(e[kl], y[kl], y[kl]);       // L[k][k], consistent with sq
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) {
+      const int k = 16 * w + kl;
+      a[kl] = (lane == k) ? y[kl] : ((lane > k) ? a[kl] * sq[kl] : 0.0);
+      my_r = (lane == k) ? sq[kl] : my_r;              // 1 / L[k][k]
+    }
   }
-  *rdiag_out = my_r;
+  if (dbg_stamp) dbg_stamp[2] = (long long)__builtin_amdgcn_s_memtime();
+  // Inverse of the wave's 16 x 16 diagonal block (for the MFMA row solve): its sixteen rows sit in
+  // lanes 16w .. 16w+15; lane 16w + j computes column j of the inverse by right-looking forward
+  // substitution (two dependent operations per step), the block's entries coming as LDS broadcasts
+  // among those sixteen lanes.  Waves 0-2 do this while later waves still factor; only wave 3's is
+  // exposed.  (A helper wave following the owner's published, unscaled columns -- the inverse needs
+  // only u and 1/d -- was tried to hide that one too; the follower ran at ~440 cycles per column
+  // against the owner's 225 and ended later.)
+  if ((lane >> 4) == w) {
+    const int il = lane & 15;
+    double* lb = lbb + w * (16 * 17);
+    double* li = linv + w * (16 * 17);
+    rdiag[lane] = my_r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) lb[il * 17 + kk] = a[kk];
+    COMPILER_BARRIER();                              // same wave: LDS executes its operations in order
+    double sv[16], rd[16], yv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sv[i] = (i == il) ? 1.0 : 0.0; rd[i] = rdiag[16 * w + i]; }
+    // (results are stored after the loop: a store inside it may alias the block's loads for all the
+    //  compiler knows, which puts an LDS round trip into every step)
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double y = sv[kk] * rd[kk];
+      yv[kk] = y;
+#pragma unroll
+      for (int i = kk + 1; i < 16; ++i) sv[i] = fma(-lb[i * 17 + kk], y, sv[i]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) li[kk * 17 + il] = yv[kk];
+  }
+  if (dbg_stamp) dbg_stamp[3] = (long long)__builtin_amdgcn_s_memtime();
   return bad;
 }
 
@@ -325,8 +377,11 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     Sp[i * SPP + k] = v;
   }
   __shared__ int s_badv[4];
-  double* rdiag = colbuf;                          // [64] 1 / L[c][c]
   double* ring = colbuf + PB;                      // [64][64] published (unscaled) columns
+  double* tbuf0 = ring + PB * PB;                  // 3 x [64][17] layout buffers (later 4 x [16][17] solve tiles)
+  double* lbb = tbuf0 + 3 * PB * 17;               // 4 x [16][17] diagonal 16-blocks of the factor
+  double* linv = lbb + 4 * 16 * 17;                // 4 x [16][17] their inverses
+  double* rdiag = colbuf;                          // [64] 1 / L[c][c]
   if (tid < PB) ring[tid * PB] = 0.0;              // row-0 entries double as the "published" flags
   __syncthreads();
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -334,24 +389,22 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   double* Pn = D + (long)(nb + r0) * lda;
   {
     double a[16];
-    double my_rdiag = 1.0;
-    long long stamp[2] = {0, 0};
+    long long stamp[4] = {0, 0, 0, 0};
     const bool dbg = info_dbg[7] != 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0;
-    double* tbuf = ring + PB * PB + (w > 0 ? (w - 1) : 0) * PB * 17;
-    const int bad = factor64_waves(a, k, w, Sp, tbuf, ring, &my_rdiag, dbg ? stamp : nullptr);
+    double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
+    const int bad = factor64_waves(a, k, w, Sp, tbuf, ring, lbb, linv, rdiag, dbg ? stamp : nullptr);
     if (k == 0) s_badv[w] = bad;
     if (dbg && k == 0) {
-      // waves 0 / 1: start and end of the own 16 columns, relative to t1 (debug hook only)
-      if (w == 0) { info_dbg[0] = stamp[0] - (long long)t1; info_dbg[1] = stamp[1] - (long long)t1; }
-      if (w == 1) { info_dbg[5] = stamp[0] - (long long)t1; info_dbg[6] = stamp[1] - (long long)t1; }
+      // wave 3: start / end of its own 16 columns, end of scaling, end of the 16 x 16 inverse (debug hook only)
+      if (w == 3) { info_dbg[0] = stamp[0] - (long long)t1; info_dbg[1] = stamp[1] - (long long)t1;
+                    info_dbg[5] = stamp[2] - (long long)t1; info_dbg[6] = stamp[3] - (long long)t1; }
     }
     // factor image for the row solves: Sp[row][perm16(col)], and the reciprocal diagonal
 #pragma unroll
     for (int j = 0; j < 16; ++j) Sp[k * SPP + perm16(16 * w + j)] = a[j];
-    if ((k >> 4) == w) rdiag[k] = my_rdiag;
     if (w == 0 && blockIdx.x > 0) {
       // wave 0 is done after the first 16 columns: it stages this workgroup's 64 panel rows
-      // (coalesced along the row) while the other waves finish the factorisation
+      // (coalesced along the row) while the other waves go on with the factorisation
       // (16 loads in flight at a time: one load per iteration would cost a full memory latency each)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -384,52 +437,47 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     return;
   }
   {
-    // forward substitution x L^T = p, four lanes per row: lane q of a quad accumulates the terms
-    // kk = q (mod 4) (its 16 values of row c of L are contiguous in Sp), two quad shuffles combine
-    // them, x[c] = s * (1 / L[c][c]).  Terms with kk >= c vanish on their own: L is lower
-    // triangular and x[kk] is still zero when row c is processed.
-    const int row = tid >> 2, q = tid & 3;
-    double xq[16], rq[16];                         // x[4t + q], p[4t + q]
+    // Row solve X L^T = P on the matrix cores, 16-column blocks: for b = 0..3
+    //     X_b = (P_b - sum_{b' < b} X_b' L[b][b']^T) Linv_bb^T
+    // with the inverses of the four 16 x 16 diagonal blocks (computed by the waves that own them,
+    // see factor64_waves).  Wave w takes rows 16w .. 16w+15 of the workgroup's 64: no dependence
+    // between waves.  X_b goes back into R, from where the later blocks read it as an A operand;
+    // the only layout change is accumulator -> A operand for the multiplication by Linv_bb^T, through
+    // a 16 x 16 LDS tile private to the wave.  40 MFMAs per wave; the substitution this replaces was
+    // a 64-step dependent chain (16k cycles).
+    double* Tt = tbuf0 + w * (16 * 17);
+    const int kq = k >> 4, l15 = k & 15;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { xq[t] = 0.0; rq[t] = R[row * PBP + 4 * t + q]; }
-    double sv[16];
+    for (int b = 0; b < 4; ++b) {
+      // two accumulators per product: a dependent MFMA waits ~64 cycles for its predecessor
+      double4_t acc, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) sv[t] = 0.0;
-    sv[0] = Sp[0 * SPP + q * 16];
-    double rd = rdiag[0];
-    LDS_FENCE();
+      for (int r = 0; r < 4; ++r) acc[r] = R[(16 * w + kq + 4 * r) * PBP + 16 * b + l15];
 #pragma unroll
-    for (int c = 0; c < PB; ++c) {
-      // prefetch row c+1 of L (this lane's residue class) while row c is being reduced
-      double sn[16];
-      double rdn = 0.0;
+      for (int bp = 0; bp < b; ++bp)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) sn[t] = 0.0;
-      if (c + 1 < PB) {
+        for (int st = 0; st < 4; ++st) {
+          const double av = R[(16 * w + l15) * PBP + 16 * bp + 4 * st + kq];                 // X_b'[i][k]
+          const double bv = -Sp[(16 * b + l15) * SPP + perm16(16 * bp + 4 * st + kq)];       // -L[16b+j][16b'+k]
+          if (st & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
 #pragma unroll
-        for (int t = 0; t <= (c + 1) / 4; ++t) sn[t] = Sp[(c + 1) * SPP + q * 16 + t];
-        rdn = rdiag[c + 1];
+      for (int r = 0; r < 4; ++r) Tt[(kq + 4 * r) * 17 + l15] = acc[r] + acc2[r];
+      COMPILER_BARRIER();                            // same wave: LDS executes its operations in order
+      double4_t x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const double av = Tt[l15 * 17 + 4 * st + kq];                                        // T[i][k]
+        const double bv = linv[b * (16 * 17) + l15 * 17 + 4 * st + kq];                      // Linv_bb[j][k]
+        if (st & 1) x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x2, 0, 0, 0);
+        else x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
       }
-      LDS_FENCE();
-      // four independent partial sums: the dependent FMA chain is c/16 + 1 long instead of c/4 + 1
-      double s0 = ((c & 3) == q) ? rq[c / 4] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      COMPILER_BARRIER();
 #pragma unroll
-      for (int t = 0; t <= c / 4; ++t) {
-        if ((t & 3) == 0) s0 = fma(-xq[t], sv[t], s0);
-        else if ((t & 3) == 1) s1 = fma(-xq[t], sv[t], s1);
-        else if ((t & 3) == 2) s2 = fma(-xq[t], sv[t], s2);
-        else s3 = fma(-xq[t], sv[t], s3);
-      }
-      double s = quad_sum((s0 + s1) + (s2 + s3));
-      const double xc = s * rd;
-      if ((c & 3) == q) xq[c / 4] = xc;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) sv[t] = sn[t];
-      rd = rdn;
+      for (int r = 0; r < 4; ++r) R[(16 * w + kq + 4 * r) * PBP + 16 * b + l15] = x[r] + x2[r];
+      COMPILER_BARRIER();
     }
-    __syncthreads();                               // all reads of R done before it is overwritten
-#pragma unroll
-    for (int t = 0; t < 16; ++t) R[row * PBP + 4 * t + q] = xq[t];
   }
   __syncthreads();
 #pragma unroll
@@ -440,7 +488,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) info_dbg[4] = (long long)(__builtin_amdgcn_s_memtime() - t2);
 }
 static_assert(SPP == SPP_STAGE, "staging stride");
-constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17) * 8;   // image, panel rows, rdiag, ring, 3 layout buffers
+constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17 + 8 * 16 * 17) * 8;   // image, panel rows, rdiag, ring, layout buffers, 16-blocks + inverses
 
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.

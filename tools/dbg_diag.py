@@ -9,4 +9,4 @@ for rows in (0, 64, 448):
   for reps in (1, 10, 200):
     ms = C.c_double(0); cyc = (C.c_longlong * 7)()
     rc = lib.dfh_debug_diag_step(eng.ctx, reps, rows, C.byref(ms), cyc)
-    print('rows_below=%d reps=%d rc=%d  %.1f us/launch  cycles load=%d factor=%d trsm=%d | wave0 own block %d..%d wave1 own block %d..%d' % (rows, reps, rc, ms.value * 1e3, cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5], cyc[6]))
+    print('rows_below=%d reps=%d rc=%d  %.1f us/launch  cycles load=%d factor=%d trsm=%d | wave3: own block %d..%d scaled %d inverse %d' % (rows, reps, rc, ms.value * 1e3, cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5], cyc[6]))
