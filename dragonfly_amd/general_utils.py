@@ -20,13 +20,11 @@ def map_to_bounds(pts, bounds):
 
 def dist_squared(X1, X2):
   """ n1 x n2 matrix of squared distances, clipped at zero (general_utils.py:58-70). """
-  X1 = np.asarray(X1, dtype=np.float64)
-  X2 = np.asarray(X2, dtype=np.float64)
-  _, dim1 = X1.shape
-  _, dim2 = X2.shape
-  if dim1 != dim2:
+  A = np.asarray(X1, dtype=np.float64)
+  B = np.asarray(X2, dtype=np.float64)
+  if A.shape[1] != B.shape[1]:
     raise ValueError('Second dimension of X1 and X2 should be equal.')
-  return get_engine().dist_squared(X1, X2)
+  return get_engine().dist_squared(A, B)
 
 
 def stable_cholesky(M, add_to_diag_till_psd=True):
@@ -54,8 +52,8 @@ def _solve_triangular_common(A, b, lower):
   """ general_utils.py:208-213 """
   A = np.asarray(A, dtype=np.float64)
   b = np.asarray(b, dtype=np.float64)
-  if A.size == 0 and b.shape[0] == 0:
-    return np.zeros((b.shape))
+  if b.shape[0] == 0 and A.size == 0:
+    return np.zeros(b.shape)          # nothing to solve
   eng = get_engine()
   if lower:
     return eng.solve_triangular(A, b, upper=False)
@@ -77,8 +75,6 @@ def draw_gaussian_samples(num_samples, mu, K):
   """ num_samples draws from N(mu, K) (general_utils.py:224-232); the normals come from the
       global np.random state with the reference's call, the factor and the product from the
       device. """
-  num_pts = len(mu)
-  L = stable_cholesky(K)
-  U = np.random.normal(size=(num_pts, num_samples))
-  V = get_engine().gemm(L, U, transb=True).T + mu
-  return V
+  factor = stable_cholesky(K)
+  normals = np.random.normal(size=(len(mu), num_samples))
+  return get_engine().gemm(factor, normals, transb=True).T + mu

@@ -102,50 +102,67 @@ def _fused_argmax(gp, acq, params, anc_data, max_evals=None):
 
 
 def _get_syn_recommendations_from_asy(asy_acq, num_workers, list_of_gps, anc_datas):
-  """ gpb_acquisitions.py:90-115: earlier recommendations become hallucinated points. """
-  def _get_next_and_append(_list_of_objects):
-    ret = _list_of_objects.pop(0)
-    _list_of_objects = _list_of_objects + [ret]
-    return ret, _list_of_objects
-  if not hasattr(list_of_gps, '__iter__'):
-    list_of_gps = [list_of_gps] * num_workers
-  if not hasattr(anc_datas, '__iter__'):
-    anc_datas = [anc_datas] * num_workers
-  list_of_gps = [copy(gp) for gp in list_of_gps]
-  anc_datas = [copy(ad) for ad in anc_datas]
-  next_gp, list_of_gps = _get_next_and_append(list_of_gps)
-  next_anc_data, anc_datas = _get_next_and_append(anc_datas)
-  recommendations = [asy_acq(next_gp, next_anc_data)]
-  for _ in range(1, num_workers):
-    next_gp, list_of_gps = _get_next_and_append(list_of_gps)
-    next_anc_data, anc_datas = _get_next_and_append(anc_datas)
-    next_anc_data.eval_points_in_progress = recommendations
-    recommendations.append(asy_acq(next_gp, next_anc_data))
+  """ A synchronous batch is the asynchronous rule applied num_workers times in a row, every
+      earlier recommendation counting as an evaluation in progress for the later ones
+      (gpb_acquisitions.py:90-115); a single gp / anc_data serves all workers, lists are used
+      round-robin.  The objects are shallow-copied so that the caller's anc_data keeps its own
+      eval_points_in_progress. """
+  def _per_worker(obj):
+    seq = list(obj) if hasattr(obj, '__iter__') else [obj]
+    return [copy(seq[i % len(seq)]) for i in range(num_workers)]
+  recommendations = []
+  for worker, (worker_gp, worker_anc) in enumerate(zip(_per_worker(list_of_gps), _per_worker(anc_datas))):
+    if worker > 0:
+      worker_anc.eval_points_in_progress = recommendations
+    recommendations.append(asy_acq(worker_gp, worker_anc))
   return recommendations
+
+
+def _host_acquisition(gp, anc_data, formula):
+  """ The reference's closure route: `formula(mu, sigma)` on the posterior of whatever points the
+      maximiser asks for (hallucinated observations included), maximised by maximise_acquisition. """
+  gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
+  return maximise_acquisition(lambda x: formula(*gp_eval(x)), anc_data)
+
+
+def _acquire(gp, anc_data, acq, params, formula):
+  """ One acquisition step: fused on the device when possible, the closure route otherwise. """
+  if _can_fuse(gp, anc_data):
+    return _fused_argmax(gp, acq, params, anc_data)
+  return _host_acquisition(gp, anc_data, formula)
+
+
+def _ndtr(x):
+  from scipy.stats import norm as normal_distro
+  return normal_distro.cdf(x)
+
+
+def _expected_improvement_for_norm_diff(norm_diff):
+  """ z Phi(z) + phi(z)  (gpb_acquisitions.py:247-249; host form, closure route only) """
+  from scipy.stats import norm as normal_distro
+  return norm_diff * normal_distro.cdf(norm_diff) + normal_distro.pdf(norm_diff)
 
 
 # Thompson sampling ---------------------------------------------------------------------------
 def asy_ts(gp, anc_data):
-  """ gpb_acquisitions.py:119-127: always random candidates + a vectorised joint sample. """
+  """ gpb_acquisitions.py:119-127: TS always works on random candidates with one vectorised joint
+      sample; a different configured method only multiplies the number of candidates by four. """
   anc_data = copy(anc_data)
   if anc_data.acq_opt_method != 'rand':
+    anc_data.max_evals *= 4
     anc_data.acq_opt_method = 'rand'
-    anc_data.max_evals = 4 * anc_data.max_evals
   Xh = _halluc_points(anc_data)
-  if Xh is None and gp.num_tr_data > 0 and anc_data.domain.get_type() == 'euclidean' and \
-     not getattr(gp, '_generic', False):
-    # fused: covariance, stable_cholesky, L u and the arg-max stay on the device
-    cands = _candidates(anc_data)
-    test_mean = gp.mean_func(cands)
-    U = np.random.normal(size=(len(cands), 1))          # general_utils.py:230
-    _, idx = gp.device_gp.thompson(cands, U.ravel(), block=len(cands), mean_vals=test_mean)
-    return cands[idx]
-  gp_sample = get_gp_sampler_for_parallel_strategy(gp, anc_data)
-  return maximise_acquisition(gp_sample, anc_data, vectorised=True)
-
-
-def syn_ts(num_workers, list_of_gps, anc_datas):
-  return _get_syn_recommendations_from_asy(asy_ts, num_workers, list_of_gps, anc_datas)
+  fused = Xh is None and gp.num_tr_data > 0 and anc_data.domain.get_type() == 'euclidean' and \
+          not getattr(gp, '_generic', False)
+  if not fused:
+    return maximise_acquisition(get_gp_sampler_for_parallel_strategy(gp, anc_data), anc_data,
+                                vectorised=True)
+  # covariance, stable_cholesky, L u and the arg-max stay on the device; the standard normals are
+  # np.random.normal(size=(m, 1)) as in draw_gaussian_samples (general_utils.py:230)
+  cands = _candidates(anc_data)
+  normals = np.random.normal(size=(len(cands), 1)).ravel()
+  _, idx = gp.device_gp.thompson(cands, normals, block=len(cands), mean_vals=gp.mean_func(cands))
+  return cands[idx]
 
 
 # Add-UCB -------------------------------------------------------------------------------------
@@ -156,7 +173,10 @@ def _get_add_ucb_beta_th(dim, time_step):
 
 def _add_ucb(gp, add_kernel, mean_funcs, anc_data):
   """ gpb_acquisitions.py:139-189: one UCB maximisation per additive group, each over its own
-      candidate set; the per-group posterior uses the shared factor L and alpha in HBM. """
+      candidate set (max_evals // number of groups points, drawn group by group from the global
+      np.random state as the reference's loop draws them; the acquisition itself consumes no random
+      numbers), the winners assembled coordinate-wise.  All groups go to the device in ONE call:
+      the per-group posteriors share the factor L and alpha in HBM and one triangular solve. """
   if not isinstance(add_kernel, AdditiveKernel):
     raise TypeError('add_ucb needs a GP with an AdditiveKernel.')
   if mean_funcs is not None:
@@ -164,48 +184,30 @@ def _add_ucb(gp, add_kernel, mean_funcs, anc_data):
   if not str(anc_data.acq_opt_method).lower().startswith('rand'):
     raise NotImplementedError('add_ucb on the device engine uses acq_opt_method="rand".')
   groupings = add_kernel.groupings
-  total_max_evals = anc_data.max_evals
-  domain_bounds = np.asarray(anc_data.domain_bounds, dtype=np.float64)
-  num_groups = len(add_kernel.kernel_list)
-  group_points = []
-  num_coordinates = 0
-  anc_data.max_evals = total_max_evals//num_groups
-  # The candidate sets are drawn group by group exactly as the reference's loop does (the
-  # acquisition itself consumes no random numbers), then all groups go to the device in one call.
-  betas, cands = [], []
-  for j, group_j in enumerate(groupings):
-    betas.append(_get_add_ucb_beta_th(len(group_j), anc_data.t))
-    bounds_j = domain_bounds[group_j]
-    cands.append(map_to_bounds(np.random.random((int(anc_data.max_evals), len(bounds_j))), bounds_j))
-  _, idxs = gp.device_gp.add_ucb_all(betas, cands)
-  for cands_j, idx in zip(cands, idxs):
-    point_j = cands_j[int(idx)]
-    group_points.append(point_j)
-    num_coordinates += len(point_j)
-  anc_data.max_evals = total_max_evals
-  ret = np.zeros((num_coordinates,))
-  for point_j, group_j in zip(group_points, groupings):
-    ret[group_j] = point_j
-  return ret
+  all_bounds = np.asarray(anc_data.domain_bounds, dtype=np.float64)
+  per_group_evals = int(anc_data.max_evals // len(add_kernel.kernel_list))
+  betas = [_get_add_ucb_beta_th(len(grp), anc_data.t) for grp in groupings]
+  cands = [map_to_bounds(np.random.random((per_group_evals, len(grp))), all_bounds[grp])
+           for grp in groupings]
+  _, winners = gp.device_gp.add_ucb_all(betas, cands)
+  point = np.zeros((sum(len(grp) for grp in groupings),))
+  for grp, cands_g, idx in zip(groupings, cands, winners):
+    point[grp] = cands_g[int(idx)]
+  return point
 
 
 def asy_add_ucb(gp, anc_data):
   return _add_ucb(gp, gp.kernel, None, anc_data)
 
 
-def syn_add_ucb(num_workers, list_of_gps, anc_datas):
-  return _get_syn_recommendations_from_asy(asy_add_ucb, num_workers, list_of_gps, anc_datas)
-
-
 # UCB ------------------------------------------------------------------------------------------
 def _get_gp_ucb_dim(gp):
-  """ gpb_acquisitions.py:202-209 """
-  if hasattr(gp, 'ucb_dim') and gp.ucb_dim is not None:
-    return gp.ucb_dim
-  elif hasattr(gp.kernel, 'dim'):
-    return gp.kernel.dim
-  else:
-    return 3.0
+  """ The dimension that enters beta_t (gpb_acquisitions.py:202-209): an explicit gp.ucb_dim, the
+      kernel's dimension, or 3. """
+  explicit = getattr(gp, 'ucb_dim', None)
+  if explicit is not None:
+    return explicit
+  return getattr(gp.kernel, 'dim', 3.0)
 
 
 def _get_ucb_beta_th(dim, time_step):
@@ -214,115 +216,72 @@ def _get_ucb_beta_th(dim, time_step):
 
 
 def asy_ucb(gp, anc_data):
-  """ gpb_acquisitions.py:215-223 """
+  """ mu + beta_t sigma  (gpb_acquisitions.py:215-223) """
   beta_th = _get_ucb_beta_th(_get_gp_ucb_dim(gp), anc_data.t)
-  if _can_fuse(gp, anc_data):
-    return _fused_argmax(gp, 'ucb', (beta_th, 0.0), anc_data)
-  gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
-  def _ucb_acq(x):
-    mu, sigma = gp_eval(x)
-    return mu + beta_th * sigma
-  return maximise_acquisition(_ucb_acq, anc_data)
-
-
-def syn_ucb(num_workers, list_of_gps, anc_datas):
-  return _get_syn_recommendations_from_asy(asy_ucb, num_workers, list_of_gps, anc_datas)
+  return _acquire(gp, anc_data, 'ucb', (beta_th, 0.0), lambda mu, sigma: mu + beta_th * sigma)
 
 
 # PI -------------------------------------------------------------------------------------------
-def _ndtr(x):
-  from scipy.stats import norm as normal_distro
-  return normal_distro.cdf(x)
-
-
 def asy_pi(gp, anc_data):
-  """ gpb_acquisitions.py:230-239 """
-  curr_best = anc_data.curr_max_val
-  if _can_fuse(gp, anc_data):
-    return _fused_argmax(gp, 'pi', (curr_best, 0.0), anc_data)
-  gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
-  def _pi_acq(x):
-    mu, sigma = gp_eval(x)
-    return _ndtr((mu - curr_best) / sigma)
-  return maximise_acquisition(_pi_acq, anc_data)
-
-
-def syn_pi(num_workers, list_of_gps, anc_datas):
-  return _get_syn_recommendations_from_asy(asy_pi, num_workers, list_of_gps, anc_datas)
+  """ Phi((mu - best) / sigma)  (gpb_acquisitions.py:230-239) """
+  best = anc_data.curr_max_val
+  return _acquire(gp, anc_data, 'pi', (best, 0.0), lambda mu, sigma: _ndtr((mu - best) / sigma))
 
 
 # EI -------------------------------------------------------------------------------------------
-def _expected_improvement_for_norm_diff(norm_diff):
-  """ gpb_acquisitions.py:247-249 (host form, used on the per-point fallback route only) """
-  from scipy.stats import norm as normal_distro
-  return norm_diff * normal_distro.cdf(norm_diff) + normal_distro.pdf(norm_diff)
-
-
 def asy_ei(gp, anc_data):
-  """ gpb_acquisitions.py:251-261 """
-  curr_best = anc_data.curr_max_val
-  if _can_fuse(gp, anc_data):
-    return _fused_argmax(gp, 'ei', (curr_best, 0.0), anc_data)
-  gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
-  def _ei_acq(x):
-    mu, sigma = gp_eval(x)
-    norm_diff = (mu - curr_best) / sigma
-    return sigma * _expected_improvement_for_norm_diff(norm_diff)
-  return maximise_acquisition(_ei_acq, anc_data)
-
-
-def syn_ei(num_workers, list_of_gps, anc_datas):
-  return _get_syn_recommendations_from_asy(asy_ei, num_workers, list_of_gps, anc_datas)
+  """ sigma (z Phi(z) + phi(z)), z = (mu - best) / sigma  (gpb_acquisitions.py:251-261) """
+  best = anc_data.curr_max_val
+  return _acquire(gp, anc_data, 'ei', (best, 0.0),
+                  lambda mu, sigma: sigma * _expected_improvement_for_norm_diff((mu - best) / sigma))
 
 
 # TTEI -----------------------------------------------------------------------------------------
 def _ttei(gp_eval, anc_data, ref_point, gp=None):
-  """ gpb_acquisitions.py:269-280 """
-  ref_mean, ref_std = gp_eval([ref_point])
-  ref_mean = float(np.ravel(ref_mean)[0])
-  ref_std = float(np.ravel(ref_std)[0])
+  """ Expected improvement over a reference point, with the combined standard deviation
+      (gpb_acquisitions.py:269-280). """
+  ref_mean, ref_std = [float(np.ravel(v)[0]) for v in gp_eval([ref_point])]
   if gp is not None and _can_fuse(gp, anc_data):
     return _fused_argmax(gp, 'ttei', (ref_mean, ref_std), anc_data)
   def _tt_ei_acq(x):
     mu, sigma = gp_eval(x)
-    comb_std = np.sqrt(ref_std**2 + sigma**2)
-    norm_diff = (mu - ref_mean)/comb_std
-    return comb_std * _expected_improvement_for_norm_diff(norm_diff)
+    comb_std = np.sqrt(ref_std ** 2 + sigma ** 2)
+    return comb_std * _expected_improvement_for_norm_diff((mu - ref_mean) / comb_std)
   return maximise_acquisition(_tt_ei_acq, anc_data)
 
 
 def asy_ttei(gp, anc_data):
-  """ gpb_acquisitions.py:282-294 """
+  """ Top-two EI (gpb_acquisitions.py:282-294): with probability 1/2 plain EI; otherwise EI with
+      half the budget gives the reference point and the other half maximises the improvement over
+      it.  The coin is the first np.random.random() call, as in the reference. """
   if np.random.random() < 0.5:
     return asy_ei(gp, anc_data)
-  else:
-    max_acq_opt_evals = anc_data.max_evals
-    anc_data = copy(anc_data)
-    anc_data.max_evals = max_acq_opt_evals//2
-    ei_argmax = asy_ei(gp, anc_data)
-    gp_eval = _get_gp_eval_for_parallel_strategy(gp, anc_data, 'std')
-    return _ttei(gp_eval, anc_data, ei_argmax, gp)
-
-
-def syn_ttei(num_workers, list_of_gps, anc_data):
-  return _get_syn_recommendations_from_asy(asy_ttei, num_workers, list_of_gps, anc_data)
+  halved = copy(anc_data)
+  halved.max_evals = anc_data.max_evals // 2
+  ei_argmax = asy_ei(gp, halved)
+  return _ttei(_get_gp_eval_for_parallel_strategy(gp, halved, 'std'), halved, ei_argmax, gp)
 
 
 # Random ---------------------------------------------------------------------------------------
 def asy_rand(_, anc_data):
   """ gpb_acquisitions.py:301-306: maximise a random acquisition. """
-  def _rand_eval(_):
-    return np.random.random((1,))
-  return maximise_acquisition(_rand_eval, anc_data)
+  return maximise_acquisition(lambda _x: np.random.random((1,)), anc_data)
 
 
-def syn_rand(num_workers, list_of_gps, anc_datas):
-  return _get_syn_recommendations_from_asy(asy_rand, num_workers, list_of_gps, anc_datas)
+# Synchronous versions (gpb_acquisitions.py:129, 191, 225, 241, 263, 296, 308) -------------------
+def _synchronous(asy_acq):
+  def syn_acq(num_workers, list_of_gps, anc_datas):
+    return _get_syn_recommendations_from_asy(asy_acq, num_workers, list_of_gps, anc_datas)
+  syn_acq.__name__ = asy_acq.__name__.replace('asy_', 'syn_')
+  return syn_acq
 
 
+syn_ts, syn_add_ucb, syn_ucb = _synchronous(asy_ts), _synchronous(asy_add_ucb), _synchronous(asy_ucb)
+syn_pi, syn_ei, syn_ttei, syn_rand = _synchronous(asy_pi), _synchronous(asy_ei), _synchronous(asy_ttei), \
+                                     _synchronous(asy_rand)
+
+_ASY = dict(ucb=asy_ucb, add_ucb=asy_add_ucb, ei=asy_ei, pi=asy_pi, ttei=asy_ttei, ts=asy_ts, rand=asy_rand)
+asy = Namespace(**_ASY)
+seq = Namespace(**_ASY)
 syn = Namespace(ucb=syn_ucb, add_ucb=syn_add_ucb, ei=syn_ei, pi=syn_pi, ttei=syn_ttei, ts=syn_ts,
                 rand=syn_rand)
-asy = Namespace(ucb=asy_ucb, add_ucb=asy_add_ucb, ei=asy_ei, pi=asy_pi, ttei=asy_ttei, ts=asy_ts,
-                rand=asy_rand)
-seq = Namespace(ucb=asy_ucb, add_ucb=asy_add_ucb, ei=asy_ei, pi=asy_pi, ttei=asy_ttei, ts=asy_ts,
-                rand=asy_rand)

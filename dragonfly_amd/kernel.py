@@ -1,9 +1,11 @@
-"""Euclidean kernels evaluated on the MI355X: SE, Matern and Additive.
+"""Euclidean kernels evaluated on the MI355X: SE, Matern, Additive and coordinate-wise Product.
 
-Host-side mirror of dragonfly/gp/kernel.py (reference lines in the docstrings): same class
-names, constructor arguments, `hyperparams` dictionary and error behaviour, so code written
-against the reference's kernels runs unchanged.  The Gram / cross matrices themselves are
-produced by libdfhip.so (csrc/kernmat.hip) -- there is no NumPy evaluation path here.
+Host-side counterpart of dragonfly/gp/kernel.py: the class names, constructor arguments, the
+`hyperparams` dictionary, the printed form and the error behaviour are the reference's (its lines
+are quoted in the docstrings), so code written against the reference's kernels runs unchanged.
+The Gram / cross matrices themselves are produced by libdfhip.so (csrc/kernmat.hip) -- there is no
+NumPy evaluation path here, except for grouped kernels with a factor the device does not know,
+which are composed from their factors' own evaluations.
 """
 import numpy as np
 
@@ -18,50 +20,66 @@ def _as_2d_array(X):
   return np.ascontiguousarray(X)
 
 
-def _get_se_matern_scale_bw_strs(kern):
-  """ kernel.py:48-57 """
-  if kern.dim > 6:
-    bw_str = 'avg-bw: %0.4f'%(kern.hyperparams['dim_bandwidths'].mean())
+def _scale_and_bandwidth_text(kern):
+  """ The two fragments the reference prints for SE / Matern kernels (kernel.py:48-57): the mean
+      bandwidth above six dimensions, the individual ones otherwise. """
+  bws = kern.hyperparams['dim_bandwidths']
+  if kern.dim <= 6:
+    bw_text = 'bws:[%s]' % (' '.join('%0.2f' % (b) for b in bws))
   else:
-    bw_str = 'bws:[' + ' '.join(['%0.2f'%(dbw) for dbw in
-                                 kern.hyperparams['dim_bandwidths']]) + ']'
-  scale_str = 'sc:%0.4f'%(kern.hyperparams['scale'])
-  return scale_str, bw_str
+    bw_text = 'avg-bw: %0.4f' % (bws.mean())
+  return 'sc:%0.4f' % (kern.hyperparams['scale']), bw_text
+
+
+def _bandwidth_vector(dim, bandwidths, allow_scalar):
+  """ Per-dimension bandwidths as the reference stores them (kernel.py:151-160, 247-250): a
+      vector of length dim (checked), or one value repeated; None stays None. """
+  if bandwidths is None:
+    return None
+  if hasattr(bandwidths, '__len__'):
+    if len(bandwidths) != dim:
+      raise ValueError('Dimension of dim_bandwidths should be the same as dimension.')
+    return np.array(bandwidths).T
+  if not allow_scalar:
+    raise ValueError('Dimension of dim_bandwidths should be the same as dimension.')
+  return np.array([bandwidths] * dim).T
 
 
 class Kernel(object):
-  """ A kernel class (kernel.py:60-129). """
+  """ Base class (kernel.py:60-129): a callable returning the n1 x n2 kernel matrix, with its
+      parameters in the dictionary `hyperparams`. """
 
   def __init__(self):
-    super(Kernel, self).__init__()
-    self.hyperparams = {}
+    self.hyperparams = dict()
 
   def is_guaranteed_psd(self):
     raise NotImplementedError('Implement in a child class.')
 
-  def __call__(self, X1, X2=None):
-    return self.evaluate(X1, X2)
-
   def evaluate(self, X1, X2=None):
-    """ kernel.py:76-83: n1 x n2 kernel matrix; empty inputs give an empty matrix. """
-    X2 = X1 if X2 is None else X2
-    if len(X1) == 0 or len(X2) == 0:
-      return np.zeros((len(X1), len(X2)))
+    """ kernel.py:76-83; empty inputs give an empty matrix without touching the device. """
+    if X2 is None:
+      X2 = X1
+    n1, n2 = len(X1), len(X2)
+    if n1 == 0 or n2 == 0:
+      return np.zeros((n1, n2))
     return self._child_evaluate(X1, X2)
+
+  __call__ = evaluate
 
   def _child_evaluate(self, X1, X2):
     raise NotImplementedError('Implement in a child class.')
 
   def set_hyperparams(self, **kwargs):
-    self.hyperparams = kwargs
+    """ Replaces the whole dictionary (kernel.py:110-112). """
+    self.hyperparams = dict(kwargs)
 
   def add_hyperparams(self, **kwargs):
-    for key, value in kwargs.items():
-      self.hyperparams[key] = value
+    """ Adds / overwrites entries (kernel.py:114-117). """
+    self.hyperparams.update(kwargs)
 
   def to_spec(self, in_dim=None):
     """ Description handed to the C-ABI (struct dfh_kernel_desc). in_dim: number of columns of
-        the inputs (only an additive kernel cannot tell it from its own parameters). """
+        the inputs (only a grouped kernel cannot tell it from its own parameters). """
     raise NotImplementedError('Implement in a child class.')
 
   def __str__(self):
@@ -69,7 +87,7 @@ class Kernel(object):
 
 
 class _EuclideanDeviceKernel(Kernel):
-  """ Shared device evaluation of SE / Matern / Additive kernels. """
+  """ Shared device evaluation of the Euclidean kernels. """
 
   def has_device_spec(self):
     """ False for a grouped kernel with a factor the device does not evaluate (e.g. the reference's
@@ -78,40 +96,34 @@ class _EuclideanDeviceKernel(Kernel):
     return True
 
   def _child_evaluate(self, X1, X2):
-    X1a = _as_2d_array(X1)
-    same = X2 is X1
-    X2a = X1a if same else _as_2d_array(X2)
-    if X1a.shape[1] != X2a.shape[1]:
+    A = _as_2d_array(X1)
+    B = None if X2 is X1 else _as_2d_array(X2)
+    if B is not None and A.shape[1] != B.shape[1]:
       raise ValueError('Second dimension of X1 and X2 should be equal.')   # general_utils.py:64
     if not self.has_device_spec():
-      return self._host_compose(X1a, X2a)
-    return get_engine().kernel_matrix(self.to_spec(in_dim=X1a.shape[1]), X1a,
-                                      None if same else X2a)
+      return self._host_compose(A, A if B is None else B)
+    return get_engine().kernel_matrix(self.to_spec(in_dim=A.shape[1]), A, B)
 
+  # helpers of the reference's SE kernel that other parts of Dragonfly call (kernel.py:179-200)
   def get_scaled_repr(self, X):
-    """ kernel.py:179-181 / 255-257 """
     return X/self.hyperparams['dim_bandwidths']
 
-  def change_smoothness(self, factor):
-    """ kernel.py:198-200 """
-    self.hyperparams['dim_bandwidths'] *= factor
-
   def get_effective_norm(self, X, order=None, is_single=True):
-    """ kernel.py:183-190 """
-    scaled_X = self.get_scaled_repr(X)
+    scaled = self.get_scaled_repr(X)
     if is_single:
-      return np.linalg.norm(scaled_X, ord=order)
-    return np.array([np.linalg.norm(sx, ord=order) for sx in scaled_X])
+      return np.linalg.norm(scaled, ord=order)
+    return np.array([np.linalg.norm(row, ord=order) for row in scaled])
 
   def compute_std_slack(self, X1, X2):
-    """ kernel.py:192-196 """
-    k_12 = np.array([float(self.evaluate(X1[i].reshape(1, -1), X2[i].reshape(1, -1)))
-                     for i in range(len(X1))])
-    return np.sqrt(self.hyperparams['scale'] - k_12)
+    pairwise = [float(self.evaluate(x1.reshape(1, -1), x2.reshape(1, -1))) for x1, x2 in zip(X1, X2)]
+    return np.sqrt(self.hyperparams['scale'] - np.array(pairwise))
+
+  def change_smoothness(self, factor):
+    self.hyperparams['dim_bandwidths'] *= factor
 
 
 class SEKernel(_EuclideanDeviceKernel):
-  """ Squared exponential kernel (kernel.py:132-222). """
+  """ Squared exponential kernel scale * exp(-|x/bw - y/bw|^2 / 2) (kernel.py:132-222). """
 
   def __init__(self, dim, scale=None, dim_bandwidths=None):
     super(SEKernel, self).__init__()
@@ -121,34 +133,26 @@ class SEKernel(_EuclideanDeviceKernel):
   def is_guaranteed_psd(self):
     return True
 
+  def set_scale(self, scale):
+    self.hyperparams['scale'] = scale
+
   def set_dim_bandwidths(self, dim_bandwidths):
-    if dim_bandwidths is not None:
-      if len(dim_bandwidths) != self.dim:
-        raise ValueError('Dimension of dim_bandwidths should be the same as dimension.')
-      dim_bandwidths = np.array(dim_bandwidths).T
-    self.add_hyperparams(dim_bandwidths=dim_bandwidths)
+    self.hyperparams['dim_bandwidths'] = _bandwidth_vector(self.dim, dim_bandwidths, allow_scalar=False)
 
   def set_single_bandwidth(self, bandwidth):
-    dim_bandwidths = None if bandwidth is None else [bandwidth] * self.dim
-    self.set_dim_bandwidths(dim_bandwidths)
-
-  def set_scale(self, scale):
-    self.add_hyperparams(scale=scale)
+    self.hyperparams['dim_bandwidths'] = _bandwidth_vector(self.dim, bandwidth, allow_scalar=True)
 
   def set_se_hyperparams(self, scale, dim_bandwidths):
+    """ kernel.py:167-173: a vector is taken per dimension, anything else as one common value. """
     self.set_scale(scale)
-    if hasattr(dim_bandwidths, '__len__'):
-      self.set_dim_bandwidths(dim_bandwidths)
-    else:
-      self.set_single_bandwidth(dim_bandwidths)
+    self.hyperparams['dim_bandwidths'] = _bandwidth_vector(self.dim, dim_bandwidths, allow_scalar=True)
 
   def to_spec(self, in_dim=None):
     return KernelSpec('se', self.dim, self.hyperparams['scale'],
                       np.ravel(np.asarray(self.hyperparams['dim_bandwidths'], dtype=float)))
 
   def __str__(self):
-    scale_str, bw_str = _get_se_matern_scale_bw_strs(self)
-    return 'SE: ' + scale_str + ' ' + bw_str
+    return 'SE: %s %s' % _scale_and_bandwidth_text(self)
 
 
 class MaternKernel(_EuclideanDeviceKernel):
@@ -165,15 +169,14 @@ class MaternKernel(_EuclideanDeviceKernel):
     return True
 
   def set_matern_hyperparams(self, nu, scale, dim_bandwidths):
-    """ kernel.py:242-253 """
+    """ kernel.py:242-253; the half-integer check and its message are the reference's. """
     if nu%1 != 0.5:
       raise ValueError('Matern kernel: nu has to be p + 0.5 where p is an integer.')
-    self.add_hyperparams(nu=nu)
-    self.add_hyperparams(scale=scale)
-    dim_bandwidths = dim_bandwidths if hasattr(dim_bandwidths, '__len__') else \
-                     [dim_bandwidths] * self.dim
-    dim_bandwidths = np.array(dim_bandwidths).T
-    self.add_hyperparams(dim_bandwidths=dim_bandwidths)
+    if hasattr(dim_bandwidths, '__len__'):
+      bws = np.array(dim_bandwidths).T            # length is checked when the kernel is evaluated
+    else:
+      bws = np.array([dim_bandwidths] * self.dim).T
+    self.hyperparams.update(nu=nu, scale=scale, dim_bandwidths=bws)
     self.p = int(nu)
     self.norm_constant = 1.0     # 1/value(0); the library evaluates it with the reference's formula
 
@@ -185,89 +188,96 @@ class MaternKernel(_EuclideanDeviceKernel):
                       nu=self.hyperparams['nu'])
 
   def __str__(self):
-    scale_str, bw_str = _get_se_matern_scale_bw_strs(self)
-    nu_str = 'nu=%0.1f'%(self.hyperparams['nu'])
-    return 'Matern: ' + nu_str + ' ' + scale_str + ' ' + bw_str
+    return 'Matern: nu=%0.1f %s %s' % ((self.hyperparams['nu'],) + _scale_and_bandwidth_text(self))
 
 
-def _grouped_spec(kind, kernel, groupings, in_dim):
-  """ KernelSpec of a kernel made of SE / Matern sub-kernels on coordinate groups. """
-  kinds, scales, nus, bws = [], [], [], []
-  for kern in kernel.kernel_list:
-    if isinstance(kern, SEKernel):
-      kinds.append('se')
-      nus.append(0.0)
-    elif isinstance(kern, MaternKernel):
-      kinds.append('matern')
-      nus.append(kern.hyperparams['nu'])
-    else:
-      raise TypeError('%s on the device supports SE/Matern sub-kernels only, got %s.'
-                      % (type(kernel).__name__, type(kern)))
-    scales.append(kern.hyperparams['scale'])
-    bws.append(np.ravel(np.asarray(kern.hyperparams['dim_bandwidths'], dtype=float)))
-  groups = [[int(i) for i in grp] for grp in groupings]
-  if in_dim is None:
-    in_dim = max(max(max(g) for g in groups) + 1, kernel.dim)
-  return KernelSpec(kind, in_dim, kernel.hyperparams['scale'], groups=groups,
-                    sub_kinds=kinds, sub_scales=scales, sub_nus=nus, sub_bandwidths=bws)
+class _GroupedKernel(_EuclideanDeviceKernel):
+  """ A kernel assembled from SE / Matern factors on groups of coordinates: the additive kernel
+      (sum) and the coordinate-wise product kernel.  `_groups()` gives the coordinate lists. """
+  _kind = None
+  _label = None
+
+  def _groups(self):
+    raise NotImplementedError
+
+  def is_guaranteed_psd(self):
+    return all(kern.is_guaranteed_psd() for kern in self.kernel_list)
+
+  def get_scaled_repr(self, X):
+    raise NotImplementedError('Not defined for grouped kernels.')
+
+  def has_device_spec(self):
+    return all(isinstance(kern, (SEKernel, MaternKernel)) for kern in self.kernel_list)
+
+  def to_spec(self, in_dim=None):
+    groups = [[int(c) for c in grp] for grp in self._groups()]
+    if len(groups) != len(self.kernel_list):
+      raise ValueError("number of kernels do not correspond to number of groups.")
+    kinds, scales, nus, bws = [], [], [], []
+    for kern in self.kernel_list:
+      if isinstance(kern, SEKernel):
+        kinds.append('se')
+        nus.append(0.0)
+      elif isinstance(kern, MaternKernel):
+        kinds.append('matern')
+        nus.append(kern.hyperparams['nu'])
+      else:
+        raise TypeError('%s on the device supports SE/Matern sub-kernels only, got %s.'
+                        % (type(self).__name__, type(kern)))
+      scales.append(kern.hyperparams['scale'])
+      bws.append(np.ravel(np.asarray(kern.hyperparams['dim_bandwidths'], dtype=float)))
+    if in_dim is None:
+      in_dim = max(1 + max(max(grp) for grp in groups), self.dim)
+    return KernelSpec(self._kind, in_dim, self.hyperparams['scale'], groups=groups, sub_kinds=kinds,
+                      sub_scales=scales, sub_nus=nus, sub_bandwidths=bws)
+
+  def __str__(self):
+    parts = ', '.join('%s(%s)' % (grp, kern) for grp, kern in zip(self._groups(), self.kernel_list))
+    return '%s scale=%0.2f, %s' % (self._label, self.hyperparams['scale'], parts)
 
 
-class AdditiveKernel(_EuclideanDeviceKernel):
-  """ Additive kernel on Euclidean spaces with non-overlapping groups (kernel.py:461-501). The
-      sub-kernels must be SEKernel / MaternKernel objects. """
+class AdditiveKernel(_GroupedKernel):
+  """ Additive kernel scale * sum_g k_g(X[:, group g]) with non-overlapping groups
+      (kernel.py:461-501). """
+  _kind = 'additive'
+  _label = 'ADD'
 
   def __init__(self, scale, kernel_list, groupings):
     if len(kernel_list) != len(groupings):
       raise ValueError("number of kernels do not correspond to number of groups.")
     super(AdditiveKernel, self).__init__()
-    self.kernel_list = kernel_list
-    self.groupings = groupings
-    self.add_hyperparams(scale=scale)
-    self.dim = sum([kern.dim for kern in self.kernel_list])
+    self.hyperparams['scale'] = scale
+    self.kernel_list, self.groupings = kernel_list, groupings
+    self.dim = sum(kern.dim for kern in kernel_list)
 
-  def is_guaranteed_psd(self):
-    return all([kern.is_guaranteed_psd() for kern in self.kernel_list])
-
-  def get_scaled_repr(self, X):
-    raise NotImplementedError('Not defined for additive kernels.')
-
-  def has_device_spec(self):
-    return all(isinstance(k, (SEKernel, MaternKernel)) for k in self.kernel_list)
+  def _groups(self):
+    return self.groupings
 
   def _host_compose(self, X1, X2):
     """ kernel.py:484-494 with each factor evaluated by its own class """
-    result = np.zeros((X1.shape[0], X2.shape[0]))
-    for kern, group in zip(self.kernel_list, self.groupings):
-      result += kern(X1[:, group], X2[:, group])
-    return self.hyperparams['scale'] * result
-
-  def to_spec(self, in_dim=None):
-    return _grouped_spec('additive', self, self.groupings, in_dim)
-
-  def __str__(self):
-    kernels_str_list = ['%s(%s)'%(grp, kern) for (grp, kern) in
-                        zip(self.groupings, self.kernel_list)]
-    kernels_str = ', '.join(kernels_str_list)
-    return 'ADD scale=%0.2f, '%(self.hyperparams['scale']) + kernels_str
+    total = np.zeros((X1.shape[0], X2.shape[0]))
+    for kern, grp in zip(self.kernel_list, self.groupings):
+      total += kern(X1[:, grp], X2[:, grp])
+    return self.hyperparams['scale'] * total
 
 
-class CoordinateProductKernel(_EuclideanDeviceKernel):
+class CoordinateProductKernel(_GroupedKernel):
   """ Coordinate-wise product kernel scale * prod_i k_i(X[:, coordinate_list[i]])
-      (kernel.py:541-591); the kernel of a Euclidean multi-fidelity GP (fidelity x domain).
-      The sub-kernels must be SEKernel / MaternKernel objects. """
+      (kernel.py:541-591); the kernel of a Euclidean multi-fidelity GP (fidelity x domain). """
+  _kind = 'product'
+  _label = 'CoordProd'
 
   def __init__(self, dim, scale, kernel_list=None, coordinate_list=None):
     super(CoordinateProductKernel, self).__init__()
     self.dim = dim
-    self.add_hyperparams(scale=scale)
-    self.kernel_list = kernel_list
-    self.coordinate_list = coordinate_list
+    self.hyperparams['scale'] = scale
+    self.kernel_list, self.coordinate_list = kernel_list, coordinate_list
+
+  def _groups(self):
+    return self.coordinate_list
 
   def set_kernel_list(self, kernel_list):
     self.kernel_list = kernel_list
-
-  def is_guaranteed_psd(self):
-    return all([kern.is_guaranteed_psd() for kern in self.kernel_list])
 
   def set_new_kernel(self, kernel_idx, new_kernel):
     self.kernel_list[kernel_idx] = new_kernel
@@ -275,11 +285,8 @@ class CoordinateProductKernel(_EuclideanDeviceKernel):
   def set_kernel_hyperparams(self, kernel_idx, **kwargs):
     self.kernel_list[kernel_idx].set_hyperparams(**kwargs)
 
-  def get_scaled_repr(self, X):
-    raise NotImplementedError('Not defined for product kernels.')
-
-  def has_device_spec(self):
-    return all(isinstance(k, (SEKernel, MaternKernel)) for k in self.kernel_list)
+  def to_spec(self, in_dim=None):
+    return super(CoordinateProductKernel, self).to_spec(self.dim if in_dim is None else in_dim)
 
   def _host_compose(self, X1, X2):
     """ kernel.py:578-589 with each factor evaluated by its own class """
@@ -287,14 +294,3 @@ class CoordinateProductKernel(_EuclideanDeviceKernel):
     for kern, coords in zip(self.kernel_list, self.coordinate_list):
       K *= kern(X1[:, coords], X2[:, coords])
     return K
-
-  def to_spec(self, in_dim=None):
-    if len(self.kernel_list) != len(self.coordinate_list):
-      raise ValueError("number of kernels do not correspond to number of coordinate groups.")
-    return _grouped_spec('product', self, self.coordinate_list, in_dim if in_dim is not None else self.dim)
-
-  def __str__(self):
-    kernels_str_list = ['%s(%s)'%(grp, kern) for (grp, kern) in
-                        zip(self.coordinate_list, self.kernel_list)]
-    kernels_str = ', '.join(kernels_str_list)
-    return 'CoordProd scale=%0.2f, '%(self.hyperparams['scale']) + kernels_str

@@ -9,63 +9,60 @@ from .gp_core import GP
 
 
 def get_ZX_from_ZZ_XX(ZZ, XX):
-  """ mf_gp.py:18-23 """
-  if hasattr(ZZ, '__iter__') and len(ZZ) == len(XX):
-    return [(z, x) for (z, x) in zip(ZZ, XX)]
-  return (ZZ, XX)
+  """ Joint representation of fidelity and domain data (mf_gp.py:18-23): paired point by point
+      when the two are sequences of equal length, otherwise one (fidelity, domain) pair. """
+  paired = hasattr(ZZ, '__iter__') and len(ZZ) == len(XX)
+  return list(zip(ZZ, XX)) if paired else (ZZ, XX)
 
 
 class MFGP(GP):
-  """ A GP to be used in multi-fidelity settings (mf_gp.py:26-107).  mf_kernel must be a combined
-      kernel on the joint points (the Namespace form of the reference builds a CartesianProductKernel
-      over arbitrary spaces, which is outside the Euclidean device path). """
+  """ A GP to be used in multi-fidelity settings (mf_gp.py:26-107): a GP on the joint points with
+      the fidelity / domain split kept alongside.  mf_kernel must be a combined kernel on the joint
+      points (the Namespace form of the reference builds a CartesianProductKernel over arbitrary
+      spaces, which is outside the Euclidean device path). """
 
   def __init__(self, ZZ, XX, YY, mf_kernel, mean_func, noise_var, *args, **kwargs):
-    self.ZZ = list(ZZ)
-    self.XX = list(XX)
-    self.YY = list(YY)
-    if not isinstance(mf_kernel, gp_kernel.Kernel):
+    if not isinstance(mf_kernel, gp_kernel.Kernel) and not hasattr(mf_kernel, 'is_guaranteed_psd'):
       raise NotImplementedError('dragonfly_amd.MFGP needs a combined kernel object '
                                 '(e.g. CoordinateProductKernel); there is no CPU fallback.')
-    ZX = self.get_ZX_from_ZZ_XX(ZZ, XX)
-    super(MFGP, self).__init__(ZX, YY, mf_kernel, mean_func, noise_var, *args, **kwargs)
+    self._keep_mf_data(ZZ, XX, YY)
+    super(MFGP, self).__init__(self.get_ZX_from_ZZ_XX(ZZ, XX), YY, mf_kernel, mean_func, noise_var,
+                               *args, **kwargs)
+
+  def _keep_mf_data(self, ZZ, XX, YY):
+    self.ZZ, self.XX, self.YY = list(ZZ), list(XX), list(YY)
 
   def get_ZX_from_ZZ_XX(self, ZZ, XX):
+    """ Overridden by subclasses with a more compact joint representation. """
     return get_ZX_from_ZZ_XX(ZZ, XX)
 
+  # evaluation / sampling at (fidelity, domain) points: mf_gp.py:57-68, 89-92
   def eval_at_fidel(self, ZZ_test, XX_test, *args, **kwargs):
-    """ mf_gp.py:57-61 """
     return self.eval(self.get_ZX_from_ZZ_XX(ZZ_test, XX_test), *args, **kwargs)
 
   def eval_at_fidel_with_hallucinated_observations(self, ZZ_test, XX_test, ZZ_halluc, XX_halluc,
                                                    *args, **kwargs):
-    """ mf_gp.py:63-68 """
-    ZX_test = self.get_ZX_from_ZZ_XX(ZZ_test, XX_test)
-    ZX_halluc = self.get_ZX_from_ZZ_XX(ZZ_halluc, XX_halluc)
-    return self.eval_with_hallucinated_observations(ZX_test, ZX_halluc, *args, **kwargs)
+    joint_test = self.get_ZX_from_ZZ_XX(ZZ_test, XX_test)
+    joint_halluc = self.get_ZX_from_ZZ_XX(ZZ_halluc, XX_halluc)
+    return self.eval_with_hallucinated_observations(joint_test, joint_halluc, *args, **kwargs)
 
+  def draw_mf_samples(self, num_samples, ZZ_test=None, XX_test=None, *args, **kwargs):
+    joint = None if ZZ_test is None else self.get_ZX_from_ZZ_XX(ZZ_test, XX_test)
+    return self.draw_samples(num_samples, joint, *args, **kwargs)
+
+  # data: mf_gp.py:70-87
   def set_mf_data(self, ZZ, XX, YY, build_posterior=True):
-    """ mf_gp.py:70-76 """
-    self.ZZ = list(ZZ)
-    self.XX = list(XX)
-    self.YY = list(YY)
+    self._keep_mf_data(ZZ, XX, YY)
     super(MFGP, self).set_data(self.get_ZX_from_ZZ_XX(ZZ, XX), YY, build_posterior)
 
   def add_mf_data_multiple(self, ZZ_new, XX_new, YY_new, *args, **kwargs):
-    """ mf_gp.py:78-83 """
-    ZX_new = self.get_ZX_from_ZZ_XX(ZZ_new, XX_new)
-    self.ZZ.extend(ZZ_new)
-    self.XX.extend(XX_new)
-    self.add_data_multiple(ZX_new, YY_new, *args, **kwargs)
+    joint_new = self.get_ZX_from_ZZ_XX(ZZ_new, XX_new)
+    self.ZZ += list(ZZ_new)
+    self.XX += list(XX_new)
+    self.add_data_multiple(joint_new, YY_new, *args, **kwargs)
 
   def add_mf_data_single(self, zz_new, xx_new, yy_new, *args, **kwargs):
-    """ mf_gp.py:85-87 """
     self.add_mf_data_multiple([zz_new], [xx_new], [yy_new], *args, **kwargs)
-
-  def draw_mf_samples(self, num_samples, ZZ_test=None, XX_test=None, *args, **kwargs):
-    """ mf_gp.py:89-92 """
-    ZX_test = None if ZZ_test is None else self.get_ZX_from_ZZ_XX(ZZ_test, XX_test)
-    return self.draw_samples(num_samples, ZX_test, *args, **kwargs)
 
   def get_fidel_kernel(self):
     return self.fidel_kernel

@@ -8,42 +8,45 @@ import numpy as np
 from .general_utils import map_to_bounds
 
 
-def random_sample(obj, bounds, max_evals, vectorised=True):
-  """ oper_utils.py:59-67 """
-  dim = len(bounds)
-  rand_pts = map_to_bounds(np.random.random((int(max_evals), dim)), bounds)
+def _evaluate(obj, pts, vectorised):
+  """ Objective values at the rows of pts: one call, or one call per point. """
   if vectorised:
-    obj_vals = obj(rand_pts)
-  else:
-    obj_vals = np.array([obj(x) for x in rand_pts])
-  return rand_pts, obj_vals
+    return obj(pts)
+  return np.array([obj(pt) for pt in pts])
+
+
+def random_sample(obj, bounds, max_evals, vectorised=True):
+  """ max_evals uniform points in the box `bounds` and the objective there (oper_utils.py:59-67).
+      The draw is np.random.random((max_evals, dim)) mapped to the bounds -- the reference's call,
+      so a seeded run sees the same points. """
+  pts = map_to_bounds(np.random.random((int(max_evals), len(bounds))), bounds)
+  return pts, _evaluate(obj, pts, vectorised)
 
 
 def random_maximise(obj, bounds, max_evals, return_history=False, vectorised=True):
-  """ oper_utils.py:70-80 """
-  rand_pts, obj_vals = random_sample(obj, bounds, max_evals, vectorised)
-  max_idx = obj_vals.argmax()
-  max_val = obj_vals[max_idx]
-  max_pt = rand_pts[max_idx]
-  if return_history:
-    history = Namespace(query_vals=obj_vals, query_points=rand_pts)
-  else:
-    history = None
-  return max_val, max_pt, history
+  """ Best of a random sample (oper_utils.py:70-80): np.argmax's rule -- the first maximum, a NaN
+      beats everything -- picks the winner.  Returns (value, point, history or None). """
+  pts, vals = random_sample(obj, bounds, max_evals, vectorised)
+  best = vals.argmax()
+  history = Namespace(query_vals=vals, query_points=pts) if return_history else None
+  return vals[best], pts[best], history
 
 
 def random_sample_cts_dscr(obj, cts_bounds, dscr_vals, max_evals, vectorised=True):
-  """ oper_utils.py:random_sample_cts_dscr -- continuous + discrete random sampling used by
-      the rand_exp_sampling hyper-parameter tuner. """
-  dim = len(cts_bounds)
-  cts_rand_pts = map_to_bounds(np.random.random((int(max_evals), dim)), cts_bounds) \
-                 if dim > 0 else np.zeros((int(max_evals), 0))
-  dscr_rand_pts = [[np.random.choice(vals) for vals in dscr_vals] for _ in range(int(max_evals))]
-  if vectorised:
-    obj_vals = obj(cts_rand_pts, dscr_rand_pts)
+  """ Random continuous x discrete samples for the rand_exp_sampling hyper-parameter tuner
+      (oper_utils.py:100-112): the continuous block is drawn first, then one np.random.choice per
+      discrete parameter and sample. """
+  num = int(max_evals)
+  if len(cts_bounds) > 0:
+    cts_pts = map_to_bounds(np.random.random((num, len(cts_bounds))), cts_bounds)
   else:
-    obj_vals = np.array([obj(c, d) for c, d in zip(cts_rand_pts, dscr_rand_pts)])
-  return cts_rand_pts, dscr_rand_pts, obj_vals
+    cts_pts = np.zeros((num, 0))
+  dscr_pts = [[np.random.choice(vals) for vals in dscr_vals] for _ in range(num)]
+  if vectorised:
+    obj_vals = obj(cts_pts, dscr_pts)
+  else:
+    obj_vals = np.array([obj(c, d) for c, d in zip(cts_pts, dscr_pts)])
+  return cts_pts, dscr_pts, obj_vals
 
 
 class EuclideanDomain(object):
