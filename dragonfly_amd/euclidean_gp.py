@@ -71,24 +71,21 @@ class EuclideanGP(GP):
 
   @classmethod
   def _get_kernel_from_type(cls, kernel_type, kernel_hyperparams):
-    """ euclidean_gp.py:154-175 (se and matern run on the device) """
-    if kernel_type in ['se']:
-      return gp_kernel.SEKernel(kernel_hyperparams['dim'], kernel_hyperparams['scale'],
-                                kernel_hyperparams['dim_bandwidths'])
-    elif kernel_type in ['matern']:
-      return gp_kernel.MaternKernel(kernel_hyperparams['dim'],
-                                    kernel_hyperparams['nu'], kernel_hyperparams['scale'],
-                                    kernel_hyperparams['dim_bandwidths'])
-    else:
-      raise ValueError('Cannot construct kernel from kernel_type %s.' % (kernel_type))
+    """ A kernel given by name and a dictionary of its parameters (euclidean_gp.py:154-175); the
+        two Euclidean kernels that run on the device. """
+    hp = kernel_hyperparams
+    if kernel_type == 'se':
+      return gp_kernel.SEKernel(hp['dim'], hp['scale'], hp['dim_bandwidths'])
+    if kernel_type == 'matern':
+      return gp_kernel.MaternKernel(hp['dim'], hp['nu'], hp['scale'], hp['dim_bandwidths'])
+    raise ValueError('Cannot construct kernel from kernel_type %s.' % (kernel_type))
 
   def _child_str(self):
-    """ euclidean_gp.py:177-183 """
-    ke_str = self._get_kernel_str(self.kernel)
-    dim = 0 if len(self.X) == 0 else len(self.X[0])
-    mean_str = 'mu(0)=%0.3f'%(self.mean_func([np.zeros(dim,)])[0])
-    ret = 'scale: %0.3f, %s, %s' % (self.kernel.hyperparams['scale'], ke_str, mean_str)
-    return ret
+    """ 'scale: .., <kernel>, mu(0)=..' as the reference prints it (euclidean_gp.py:177-183) """
+    origin = [np.zeros(len(self.X[0]) if len(self.X) > 0 else 0)]
+    return 'scale: %0.3f, %s, mu(0)=%0.3f' % (self.kernel.hyperparams['scale'],
+                                             self._get_kernel_str(self.kernel),
+                                             self.mean_func(origin)[0])
 
   @classmethod
   def _get_kernel_str(cls, kern):
@@ -177,33 +174,30 @@ def get_euclidean_integral_gp_kernel_with_scale(kernel_type, scale, kernel_hyper
 
 
 # Additive-model helpers (euclidean_gp.py:718-774) -------------------------------------------------
-def optimise_cts_hps_for_given_dscr_hps_in_add_model(given_dscr_hps, \
-    num_groups_per_group_size, dim, hp_tune_max_evals, cts_hp_optimise, \
-    tuning_objective):
-  """ euclidean_gp.py:718-746 """
+def optimise_cts_hps_for_given_dscr_hps_in_add_model(given_dscr_hps, num_groups_per_group_size, dim,
+                                                     hp_tune_max_evals, cts_hp_optimise,
+                                                     tuning_objective):
+  """ Additive-model search (euclidean_gp.py:718-746): the last discrete hyper-parameter is the
+      group size; several random partitions of the coordinates into groups of that size are tried,
+      the continuous hyper-parameters are optimised for each (with the evaluation budget split
+      between them, at least 500 each) and the best (value, hps, groupings) wins.  A negative
+      number of partitions means the reference's default: one for singleton groups (all
+      partitions are the same), else between 5 and 25 growing with the dimension.  The random
+      permutations come from the global np.random state, one np.random.permutation(dim) each. """
   group_size = given_dscr_hps[-1]
-  if num_groups_per_group_size < 0:
-    if group_size == 1:
-      num_groups_per_group_size = 1
-    else:
-      num_groups_per_group_size = max(5, min(2 * dim, 25))
-  grp_best_hps = None
-  grp_best_val = -np.inf
-  grp_best_other_params = None
-  for _ in range(num_groups_per_group_size):
-    rand_perm = list(np.random.permutation(dim))
-    groupings = [rand_perm[i:i+group_size]
-                 for i in range(0, dim, group_size)]
-    other_gp_params = Namespace(add_gp_groupings=groupings)
-    cts_tuning_objective = lambda arg: tuning_objective(arg, given_dscr_hps[:],
-                                                        other_gp_params=other_gp_params)
-    max_evals = int(max(500, hp_tune_max_evals/num_groups_per_group_size))
-    opt_cts_val, opt_cts_hps, _ = cts_hp_optimise(cts_tuning_objective, max_evals)
-    if opt_cts_val > grp_best_val:
-      grp_best_val = opt_cts_val
-      grp_best_hps = opt_cts_hps
-      grp_best_other_params = other_gp_params
-  return grp_best_val, grp_best_hps, grp_best_other_params
+  num_partitions = num_groups_per_group_size
+  if num_partitions < 0:
+    num_partitions = 1 if group_size == 1 else max(5, min(2 * dim, 25))
+  evals_each = int(max(500, hp_tune_max_evals / num_partitions))
+  best = (-np.inf, None, None)
+  for _ in range(num_partitions):
+    order = list(np.random.permutation(dim))
+    partition = Namespace(add_gp_groupings=[order[lo:lo + group_size] for lo in range(0, dim, group_size)])
+    objective = lambda cts_hps, _p=partition: tuning_objective(cts_hps, given_dscr_hps[:], other_gp_params=_p)
+    value, cts_hps, _ = cts_hp_optimise(objective, evals_each)
+    if value > best[0]:
+      best = (value, cts_hps, partition)
+  return best
 
 
 class EuclideanGPFitter(object):
