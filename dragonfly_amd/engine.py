@@ -27,6 +27,8 @@ def _ptr(a):
     return None
   if isinstance(a, DeviceArray):
     return a.ptr
+  if isinstance(a, C.c_void_p):
+    return a
   return a.ctypes.data_as(C.c_void_p)
 
 
@@ -51,6 +53,16 @@ class DeviceArray(object):
     out = np.empty(self.shape, dtype=np.float64)
     check(self.engine.lib.dfh_memcpy_d2h(self.engine.ctx, _ptr(out), self.ptr, self.size * 8))
     return out
+
+  def slice(self, start, count):
+    """ `count` doubles from element `start`, as a host array. """
+    out = np.empty(int(count), dtype=np.float64)
+    check(self.engine.lib.dfh_memcpy_d2h(self.engine.ctx, _ptr(out), self.offset(start), int(count) * 8))
+    return out
+
+  def row(self, i):
+    """ Row i of a 2-D buffer as a host array (the winning candidate of a device-side search). """
+    return self.slice(int(i) * self.shape[-1], self.shape[-1])
 
   def offset(self, n_elems):
     """ A raw pointer n_elems doubles into the buffer (no ownership). """
@@ -184,6 +196,54 @@ class Engine(object):
 
   def empty(self, shape):
     return DeviceArray(self, shape)
+
+  def random_candidates(self, num, dim, bounds=None, rng=None, out=None):
+    """ `num` uniform points of the box `bounds` ([dim][2]; None = unit cube) generated in HBM:
+        the draw np.random.random((num, dim)) mapped to the bounds (oper_utils.py:62,
+        general_utils.py:25-27), bit for bit, from the state of `rng` -- None / the np.random module
+        (the global legacy state the reference uses), a np.random.RandomState, or a
+        np.random.Generator over a Philox bit generator.  The generator is advanced exactly as
+        the host draw would have advanced it.  Returns a DeviceArray [num x dim] (or fills `out`,
+        a DeviceArray or a host array). """
+    num, dim = int(num), int(dim)
+    if num < 0 or dim < 1:
+      raise ValueError('random_candidates needs num >= 0 and dim >= 1.')
+    if bounds is not None:
+      bounds = _f64(bounds)
+      if bounds.shape != (dim, 2):
+        raise ValueError('bounds must have shape (dim, 2).')
+    if out is None:
+      out = DeviceArray(self, (max(num, 1), dim))
+      out.shape, out.size = (num, dim), num * dim
+    if rng is None or rng is np.random or isinstance(rng, np.random.RandomState):
+      legacy = np.random if (rng is None or rng is np.random) else rng
+      state = legacy.get_state()
+      if state[0] != 'MT19937':
+        raise ValueError('The legacy NumPy state is not MT19937.')
+      key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+      pos = C.c_int32(int(state[2]))
+      check(self.lib.dfh_rand_mt19937_uniform(self.ctx, _ptr(key), C.byref(pos), num, dim, _ptr(bounds),
+                                              _ptr(out)))
+      legacy.set_state((state[0], key, int(pos.value)) + tuple(state[3:]))
+      return out
+    bit_gen = getattr(rng, 'bit_generator', rng)
+    if not isinstance(bit_gen, np.random.Philox):
+      raise ValueError('Device candidate generation follows MT19937 (np.random / RandomState) or '
+                       'Philox (Generator(Philox(...))) streams; got %s.' % (type(bit_gen).__name__))
+    state = bit_gen.state
+    if state['has_uint32']:
+      raise ValueError('The Philox generator holds half a word from a 32-bit draw.')
+    key = np.ascontiguousarray(state['state']['key'], dtype=np.uint64).copy()
+    counter = np.ascontiguousarray(state['state']['counter'], dtype=np.uint64).copy()
+    held = np.ascontiguousarray(state['buffer'], dtype=np.uint64).copy()
+    held_pos = C.c_int32(int(state['buffer_pos']))
+    check(self.lib.dfh_rand_philox_uniform(self.ctx, _ptr(key), _ptr(counter), _ptr(held),
+                                           C.byref(held_pos), num, dim, _ptr(bounds), _ptr(out)))
+    state['state']['counter'] = counter
+    state['buffer'] = held
+    state['buffer_pos'] = int(held_pos.value)
+    bit_gen.state = state
+    return out
 
   def mem_info(self):
     """ (free, total) HBM bytes of this engine's device. """
@@ -523,13 +583,18 @@ class FittedGP(object):
       return bv.value, bi.value, vals
     return bv.value, bi.value
 
-  def add_ucb_all(self, betas, cands_per_group, return_vals=False):
+  def add_ucb_all(self, betas, cands_per_group, return_vals=False, sizes=None):
     """ add-UCB for every group of the additive kernel in one device call (one posterior solve for
-        all groups).  cands_per_group[g]: [m_g x |group g|].  Returns (best_vals, best_idx[, vals]). """
-    G = len(cands_per_group)
-    blocks = [_f64(c) for c in cands_per_group]
-    ms = np.ascontiguousarray([b.shape[0] for b in blocks], dtype=np.int64)
-    flat = np.ascontiguousarray(np.concatenate([b.ravel() for b in blocks]), dtype=np.float64)
+        all groups).  cands_per_group[g]: [m_g x |group g|] -- or ONE DeviceArray holding the groups'
+        candidate blocks back to back, with sizes[g] = m_g.  Returns (best_vals, best_idx[, vals]). """
+    if isinstance(cands_per_group, DeviceArray):
+      flat = cands_per_group
+      ms = np.ascontiguousarray(sizes, dtype=np.int64)
+    else:
+      blocks = [_f64(c) for c in cands_per_group]
+      ms = np.ascontiguousarray([b.shape[0] for b in blocks], dtype=np.int64)
+      flat = np.ascontiguousarray(np.concatenate([b.ravel() for b in blocks]), dtype=np.float64)
+    G = len(ms)
     be = _f64(np.asarray(betas, dtype=float).reshape(-1))
     if len(be) != G:
       raise ValueError('add_ucb_all: need one beta per group.')

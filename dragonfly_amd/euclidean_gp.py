@@ -18,7 +18,7 @@ import numpy as np
 from . import kernel as gp_kernel
 from .engine import get_engine
 from .general_utils import map_to_bounds
-from .gp_core import GP
+from .gp_core import GP, ConstantMean
 from .kernel import _as_2d_array
 from .oper_utils import random_maximise, random_sample_cts_dscr
 from .option_handler import get_option_specs, load_options
@@ -351,9 +351,7 @@ class EuclideanGPFitter(object):
         gp_cts_hps = gp_cts_hps[1:]
       else:
         mean_func_const_value = 0
-      def _get_mean_func(_mean_func_const_value):
-        return lambda x: np.array([_mean_func_const_value] * len(x))
-      mean_func = _get_mean_func(mean_func_const_value)
+      mean_func = ConstantMean(mean_func_const_value)
     if self.options.noise_var_type == 'tune':
       noise_var = np.exp(gp_cts_hps[0])
       gp_cts_hps = gp_cts_hps[1:]

@@ -16,6 +16,18 @@ from .general_utils import draw_gaussian_samples
 from .kernel import _as_2d_array
 
 
+class ConstantMean(object):
+  """ The constant prior mean the fitter gives a GP (gp_core.py:527-530: one value per point).  The
+      value is exposed so that device-resident candidates need not come back to the host just to
+      have a constant evaluated on them. """
+
+  def __init__(self, value):
+    self.constant_value = value
+
+  def __call__(self, x):
+    return np.array([self.constant_value] * len(x))
+
+
 def _check_feature_label_lengths_and_format(X, Y):
   """ gp_core.py:72-76 """
   if len(X) != len(Y):

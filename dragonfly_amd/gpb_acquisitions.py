@@ -14,6 +14,7 @@ comes back.  Other acq_opt_method values are per-point serial tree searches in t
 package is installed under Dragonfly (dragonfly_amd.install), each callback hitting GP.eval on
 the device.
 """
+import os
 from argparse import Namespace
 from copy import copy
 
@@ -22,6 +23,10 @@ import numpy as np
 from .general_utils import map_to_bounds
 from .kernel import AdditiveKernel, _as_2d_array
 from .oper_utils import random_maximise
+
+# Candidates of the fused 'rand' path are generated in HBM (bit-identical to the host draw, same
+# generator state afterwards); DFH_HOST_CANDIDATES=1 keeps the draw on the host.
+DEVICE_CANDIDATES = os.environ.get('DFH_HOST_CANDIDATES', '0') != '1'
 
 # A maximiser for non-'rand' methods; dragonfly_amd.install points this at
 # dragonfly.exd.exd_utils.maximise_with_method.
@@ -33,6 +38,20 @@ def _candidates(anc_data, max_evals=None):
   bounds = np.asarray(anc_data.domain.bounds, dtype=np.float64)
   m = int(anc_data.max_evals if max_evals is None else max_evals)
   return map_to_bounds(np.random.random((m, len(bounds))), bounds)
+
+
+def _device_candidates(gp, anc_data):
+  """ The same draw generated in HBM (Engine.random_candidates): the global np.random state is
+      continued bit for bit and left where the host draw would have left it, so the candidates
+      are the reference's -- without the host generation and the m x d copy.  Returns the
+      DeviceArray and what acq_argmax / thompson need to add the prior mean: a constant when the
+      mean function is the fitter's constant, else its values on a host copy of the candidates. """
+  bounds = np.asarray(anc_data.domain.bounds, dtype=np.float64)
+  cands = gp.device_gp.engine.random_candidates(int(anc_data.max_evals), len(bounds), bounds=bounds)
+  const = getattr(gp.mean_func, 'constant_value', None)
+  if const is not None:
+    return cands, dict(mean_const=float(const))
+  return cands, dict(mean_vals=gp.mean_func(cands.download()))
 
 
 def _is_rand_euclidean(anc_data):
@@ -92,12 +111,15 @@ def get_gp_sampler_for_parallel_strategy(gp, anc_data):
   return lambda x: gp.draw_samples(1, x).ravel()
 
 
-def _fused_argmax(gp, acq, params, anc_data, max_evals=None):
-  """ Candidates -> posterior -> acquisition -> arg-max in one device call; returns the point. """
-  cands = _candidates(anc_data, max_evals)
-  test_mean = gp.mean_func(cands)
+def _fused_argmax(gp, acq, params, anc_data):
+  """ Candidates -> posterior -> acquisition -> arg-max on the device; returns the point. """
   Xh = _halluc_points(anc_data)
-  _, idx = gp.device_gp.acq_argmax(acq, cands, params=params, mean_vals=test_mean, X_halluc=Xh)
+  if DEVICE_CANDIDATES:
+    cands, mean = _device_candidates(gp, anc_data)
+    _, idx = gp.device_gp.acq_argmax(acq, cands, params=params, X_halluc=Xh, **mean)
+    return cands.row(idx)
+  cands = _candidates(anc_data)
+  _, idx = gp.device_gp.acq_argmax(acq, cands, params=params, mean_vals=gp.mean_func(cands), X_halluc=Xh)
   return cands[idx]
 
 
@@ -159,6 +181,11 @@ def asy_ts(gp, anc_data):
                                 vectorised=True)
   # covariance, stable_cholesky, L u and the arg-max stay on the device; the standard normals are
   # np.random.normal(size=(m, 1)) as in draw_gaussian_samples (general_utils.py:230)
+  if DEVICE_CANDIDATES:
+    cands, mean = _device_candidates(gp, anc_data)
+    normals = np.random.normal(size=(cands.shape[0], 1)).ravel()
+    _, idx = gp.device_gp.thompson(cands, normals, block=cands.shape[0], **mean)
+    return cands.row(idx)
   cands = _candidates(anc_data)
   normals = np.random.normal(size=(len(cands), 1)).ravel()
   _, idx = gp.device_gp.thompson(cands, normals, block=len(cands), mean_vals=gp.mean_func(cands))
@@ -187,10 +214,21 @@ def _add_ucb(gp, add_kernel, mean_funcs, anc_data):
   all_bounds = np.asarray(anc_data.domain_bounds, dtype=np.float64)
   per_group_evals = int(anc_data.max_evals // len(add_kernel.kernel_list))
   betas = [_get_add_ucb_beta_th(len(grp), anc_data.t) for grp in groupings]
+  point = np.zeros((sum(len(grp) for grp in groupings),))
+  if DEVICE_CANDIDATES:
+    engine = gp.device_gp.engine
+    widths = [len(grp) for grp in groupings]
+    starts = np.concatenate([[0], np.cumsum([per_group_evals * w for w in widths])])
+    flat = engine.empty((int(starts[-1]),))
+    for grp, start in zip(groupings, starts):
+      engine.random_candidates(per_group_evals, len(grp), bounds=all_bounds[grp], out=flat.offset(start))
+    _, winners = gp.device_gp.add_ucb_all(betas, flat, sizes=[per_group_evals] * len(groupings))
+    for grp, start, idx in zip(groupings, starts, winners):
+      point[grp] = flat.slice(int(start) + int(idx) * len(grp), len(grp))
+    return point
   cands = [map_to_bounds(np.random.random((per_group_evals, len(grp))), all_bounds[grp])
            for grp in groupings]
   _, winners = gp.device_gp.add_ucb_all(betas, cands)
-  point = np.zeros((sum(len(grp) for grp in groupings),))
   for grp, cands_g, idx in zip(groupings, cands, winners):
     point[grp] = cands_g[int(idx)]
   return point

@@ -248,6 +248,25 @@ int dfh_gp_add_ucb_group(dfh_gp* gp, int32_t group, double beta, const double* X
 int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double* Xg_all, const int64_t* m_per_group,
                        double* vals_out, double* best_vals, int64_t* best_idx);
 
+/* ---- candidate generation on the device ---------------------------------------------------
+ * The m x d block of uniform candidates every random-search acquisition draws,
+ *   np.random.random((max_evals, dim))                   (dragonfly/utils/oper_utils.py:62)
+ *   pts * (bounds[:,1] - bounds[:,0]) + bounds[:,0]      (dragonfly/utils/general_utils.py:25-27)
+ * produced in HBM, bit for bit what NumPy produces from the same generator state, so neither the
+ * host generation nor the m x d host-to-device copy remains.  `bounds` is a HOST array [d][2]
+ * (lo, hi) or NULL for the unit cube; `out` [m x d] may be a dfh_malloc() pointer (the candidates
+ * then stay on the device for dfh_gp_acq_argmax / dfh_gp_ts / dfh_gp_predict) or a host pointer.
+ *
+ * dfh_rand_mt19937_uniform continues a legacy NumPy state -- `key`[624] and `pos` of
+ * np.random.get_state() -- and updates both in place to the state NumPy would be left in, so the
+ * caller hands them back with np.random.set_state() and later host draws continue the stream.
+ * dfh_rand_philox_uniform does the same for numpy.random.Philox (Philox4x64-10): key[2], and in/out
+ * counter[4], buffer[4], buffer_pos of the bit generator's state.                                */
+int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int64_t m, int64_t d,
+                             const double* bounds, double* out);
+int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64_t* counter, uint64_t* buffer,
+                            int32_t* buffer_pos, int64_t m, int64_t d, const double* bounds, double* out);
+
 /* ---- timing of the last call's dominant kernels (HIP events, ms) ------------------------- */
 #define DFH_T_KERNMAT  0   /* training kernel-matrix build                                   */
 #define DFH_T_CHOL     1   /* blocked Cholesky (all launches)                                */

@@ -472,7 +472,34 @@ def stage_configs():
   print('STAGE configs DONE')
 
 
-STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs']
+def stage_rng():
+  """ candidate generation: device MT19937 / Philox streams vs the host draw + upload """
+  from dragonfly_amd.engine import Engine
+  eng = Engine()
+  for m, d in ((65536, 6), (262144, 32), (2097152, 32)):
+    out = eng.empty((m, d))
+    bounds = np.stack([np.zeros(d), np.ones(d) * 2.0], axis=1)
+    rs = np.random.RandomState(1)
+    t0 = time.time(); host = rs.random_sample((m, d)) * 2.0 + 0.0; t_gen = time.time() - t0
+    t0 = time.time(); out.upload(host); eng.sync(); t_up = time.time() - t0
+    rs = np.random.RandomState(1)
+    eng.random_candidates(16, d, bounds=bounds, rng=np.random.RandomState(2), out=out)   # warm-up
+    t0 = time.time(); eng.random_candidates(m, d, bounds=bounds, rng=rs, out=out); eng.sync(); t_mt = time.time() - t0
+    same = np.array_equal(out.download(), host)
+    gen = np.random.Generator(np.random.Philox(key=5))
+    ref = np.random.Generator(np.random.Philox(key=5)).random((m, d)) * 2.0 + 0.0
+    eng.random_candidates(16, d, bounds=bounds, rng=np.random.Generator(np.random.Philox(key=6)), out=out)
+    t0 = time.time(); eng.random_candidates(m, d, bounds=bounds, rng=gen, out=out); eng.sync(); t_ph = time.time() - t0
+    same_ph = np.array_equal(out.download(), ref)
+    print('m=%d d=%d (%.0f MB): host draw %.1f ms + upload %.1f ms | device MT19937 %.2f ms (identical: %s) | '
+          'device Philox %.2f ms = %.0f GB/s (identical: %s)'
+          % (m, d, m * d * 8 / 1e6, t_gen * 1e3, t_up * 1e3, t_mt * 1e3, same, t_ph * 1e3,
+             m * d * 8 / t_ph / 1e9, same_ph), flush=True)
+    out.free()
+  print('STAGE rng DONE')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs', 'rng']
 
 if __name__ == '__main__':
   if len(sys.argv) == 3 and sys.argv[1] == '--run':

@@ -1,0 +1,115 @@
+"""MI355X: device candidate generation is bit-identical to the draw the reference
+makes on the host -- np.random.random((m, d)) from the global MT19937 state mapped to the bounds
+(dragonfly/utils/oper_utils.py:62, general_utils.py:25-27) -- and leaves the generator in the state
+NumPy would have left it in.  NumPy itself is the reference's arithmetic here, so it is the
+checker; oracle/ref_rng.py is checked against it on the CPU side."""
+import numpy as np
+import pytest
+
+from oracle import ref_rng as R
+
+pytestmark = pytest.mark.gpu
+
+BOX = np.array([[-5.0, 10.0], [0.0, 15.0], [0.1, 0.3], [2.0, 2.5], [-1.0, 1.0]])
+
+
+@pytest.mark.parametrize('seed,burn,m,d', [(1, 0, 1000, 2), (2, 5, 313, 5), (3, 623, 1, 1), (4, 1248, 4096, 3),
+                                           (5, 11, 0, 4), (6, 1, 65536, 32)])
+def test_mt19937_candidates_match_numpy_and_continue_the_stream(engine, seed, burn, m, d):
+  ref = np.random.RandomState(seed)
+  dev = np.random.RandomState(seed)
+  if burn:
+    ref.random_sample(burn)
+    dev.random_sample(burn)
+  bounds = None if d > len(BOX) else BOX[:d]
+  want = ref.random_sample((m, d))
+  if bounds is not None:
+    want = R.map_to_bounds(want, bounds)
+  got = engine.random_candidates(m, d, bounds=bounds, rng=dev)
+  assert got.shape == (m, d)
+  if m:
+    assert np.array_equal(got.download(), want)
+  a, b = ref.get_state(), dev.get_state()
+  assert np.array_equal(a[1], b[1]) and a[2] == b[2]
+  # ... and later host draws (the TS normals, the next hyper-parameter samples) continue identically
+  assert np.array_equal(ref.normal(size=7), dev.normal(size=7))
+
+
+def test_mt19937_global_state_and_host_output(engine):
+  np.random.seed(4242)
+  want = R.map_to_bounds(np.random.random((777, 3)), BOX[:3])
+  tail = np.random.random(5)
+  np.random.seed(4242)
+  out = np.empty((777, 3))
+  engine.random_candidates(777, 3, bounds=BOX[:3], out=out)      # rng=None: the global state
+  assert np.array_equal(out, want)
+  assert np.array_equal(np.random.random(5), tail)
+
+
+def test_mt19937_against_the_restatement_across_many_blocks(engine):
+  rs = np.random.RandomState(99)
+  rs.random_sample(100)
+  st = rs.get_state()
+  want, key, pos = R.mt19937_random_sample(st[1], st[2], (3000, 7))
+  got = engine.random_candidates(3000, 7, rng=rs).download()
+  after = rs.get_state()
+  assert np.array_equal(got, want) and np.array_equal(after[1], key) and after[2] == pos
+
+
+@pytest.mark.parametrize('burn,m,d', [(0, 1000, 2), (3, 101, 4), (1, 1, 1), (2, 1, 2), (4, 50000, 5), (0, 0, 3)])
+def test_philox_candidates_match_numpy_generator(engine, burn, m, d):
+  ones = (1 << 64) - 1
+  mk = lambda: np.random.Generator(np.random.Philox(key=np.array([7, ones], dtype=np.uint64),
+                                                    counter=np.array([ones - 2, ones, 3, 0], dtype=np.uint64)))
+  ref, dev = mk(), mk()
+  if burn:
+    ref.random(burn)
+    dev.random(burn)
+  want = R.map_to_bounds(ref.random((m, d)), BOX[:d])
+  got = engine.random_candidates(m, d, bounds=BOX[:d], rng=dev)
+  if m:
+    assert np.array_equal(got.download(), want)
+  sa, sb = ref.bit_generator.state, dev.bit_generator.state
+  assert np.array_equal(sa['state']['counter'], sb['state']['counter'])
+  assert sa['buffer_pos'] == sb['buffer_pos']
+  assert np.array_equal(ref.random(9), dev.random(9))
+
+
+def test_unsupported_generator_is_rejected(engine):
+  with pytest.raises(ValueError):
+    engine.random_candidates(10, 2, rng=np.random.Generator(np.random.PCG64(1)))
+
+
+@pytest.mark.parametrize('mean_kind', ['constant', 'callable'])
+def test_acquisitions_pick_the_same_point_with_device_and_host_candidates(engine, mean_kind, monkeypatch):
+  from argparse import Namespace
+  from dragonfly_amd import gpb_acquisitions as A
+  from dragonfly_amd.euclidean_gp import EuclideanGP
+  from dragonfly_amd.gp_core import ConstantMean
+  from dragonfly_amd.kernel import SEKernel, AdditiveKernel
+  from dragonfly_amd.oper_utils import EuclideanDomain
+  rs = np.random.RandomState(8)
+  d = 4
+  X = rs.random_sample((60, d))
+  Y = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 - X[:, 2] * X[:, 3]
+  mean = ConstantMean(float(np.median(Y))) if mean_kind == 'constant' else (lambda x: 0.1 * np.asarray(x)[:, 0])
+  gp = EuclideanGP(X, Y, SEKernel(d, float(Y.var()), 0.4 * np.ones(d)), mean, float(Y.var()) / 20)
+  add_kernel = AdditiveKernel(float(Y.var()), [SEKernel(2, 1.0, 0.4 * np.ones(2)) for _ in range(2)],
+                              [[0, 2], [3, 1]])
+  add_gp = EuclideanGP(X, Y, add_kernel, ConstantMean(float(np.median(Y))), float(Y.var()) / 20)
+  domain = EuclideanDomain([[-1, 2], [0, 1], [0.5, 0.75], [0, 3]])
+  mk_anc = lambda: Namespace(max_evals=3000, t=60, domain=domain, domain_bounds=domain.bounds,
+                             acq_opt_method='rand', curr_max_val=float(Y.max()), handle_parallel='halluc',
+                             eval_points_in_progress=[np.array([0.3, 0.3, 0.6, 1.0])], is_mf=False)
+  for acq, model in (('ucb', gp), ('ei', gp), ('pi', gp), ('ttei', gp), ('ts', gp), ('add_ucb', add_gp)):
+    picks, tails = [], []
+    for on_device in (True, False):
+      monkeypatch.setattr(A, 'DEVICE_CANDIDATES', on_device)
+      np.random.seed(31)
+      anc = mk_anc()
+      if acq == 'ts':
+        anc.eval_points_in_progress = []
+      picks.append(np.asarray(getattr(A.asy, acq)(model, anc), dtype=float))
+      tails.append(np.random.random(4))
+    assert np.array_equal(picks[0], picks[1]), acq
+    assert np.array_equal(tails[0], tails[1]), acq
