@@ -775,12 +775,33 @@ int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const d
   return DFH_OK;
 }
 
+// at most this many right-hand rows take the right-looking (wide, shallow) form of trsm_rows
+constexpr int64_t TRSM_FEW_ROWS = 256;
+
 int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
               double* Kct, int64_t m, int64_t ldk) {
   if (m <= 0 || n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
   double* T = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TMP, (size_t)m * NB * 8, (void**)&T));
+  if (m <= TRSM_FEW_ROWS) {
+    // A handful of rows (single-point GP.eval calls, tree-search frontiers, hallucinated batches):
+    // the left-looking form below would run each block as ONE tile row with a K loop over every
+    // earlier column -- a few workgroups walking all of L serially.  Right-looking instead: solve
+    // the block, then subtract its contribution from ALL later columns at once, a GEMM that is
+    // (n - c0) / 128 tiles wide with K = 512, so L streams from HBM across the whole chip.
+    for (int64_t c0 = 0; c0 < n; c0 += NB) {
+      const int64_t w = (n - c0 < NB) ? n - c0 : NB;
+      const int64_t rest = n - c0 - w;
+      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, inv + (c0 / NB) * NB * NB, NB, 0.0,
+                       nullptr, 0, T, NB));
+      DFH_TRY(copy_matrix(ctx, T, NB, Kct + c0, ldk, m, w));
+      if (rest > 0)
+        DFH_TRY(gemm_f64(ctx, 0, m, rest, w, -1.0, T, NB, L + (c0 + w) * ldl + c0, ldl, 1.0,
+                         Kct + c0 + w, ldk, Kct + c0 + w, ldk));
+    }
+    return DFH_OK;
+  }
   for (int64_t c0 = 0; c0 < n; c0 += NB) {
     const int64_t w = (n - c0 < NB) ? n - c0 : NB;
     // T = Kct[:, c0:c0+w] - Vt[:, 0:c0] * L[c0:c0+w, 0:c0]^T      (K = 0 degenerates to a copy)

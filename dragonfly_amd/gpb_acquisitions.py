@@ -22,11 +22,16 @@ import numpy as np
 
 from .general_utils import map_to_bounds
 from .kernel import AdditiveKernel, _as_2d_array
+from .doo import pdoo_maximise_batched
 from .oper_utils import random_maximise
 
 # Candidates of the fused 'rand' path are generated in HBM (bit-identical to the host draw, same
 # generator state afterwards); DFH_HOST_CANDIDATES=1 keeps the draw on the host.
 DEVICE_CANDIDATES = os.environ.get('DFH_HOST_CANDIDATES', '0') != '1'
+
+# Open leaves whose halves are prefetched with every cache miss of the batched PDOO (0: one point
+# per device call, the reference's access pattern).
+PDOO_FRONTIER = int(os.environ.get('DFH_PDOO_FRONTIER', '32'))
 
 # A maximiser for non-'rand' methods; dragonfly_amd.install points this at
 # dragonfly.exd.exd_utils.maximise_with_method.
@@ -65,22 +70,41 @@ def _can_fuse(gp, anc_data):
   return _is_rand_euclidean(anc_data) and gp.num_tr_data > 0 and not getattr(gp, '_generic', False)
 
 
+def _fortran_direct_available():
+  """ True when a Dragonfly with its compiled DIRECT is importable (oper_utils.py:21-25). """
+  try:
+    from dragonfly.utils import oper_utils as ref_oper_utils
+    return ref_oper_utils.direct_ft_wrap is not None
+  except ImportError:
+    return False
+
+
 def maximise_acquisition(acq_fn, anc_data, *args, **kwargs):
-  """ gpb_acquisitions.py:23-40 for host-evaluated acquisition callables. """
-  acq_opt_method = anc_data.acq_opt_method
+  """ gpb_acquisitions.py:23-40 for acquisition callables over rows of points ([m x d] -> [m]).
+      'rand': one vectorised call on the random candidates.  'pdoo', and 'direct' where the
+      reference itself falls back to PDOO because its Fortran DIRECT is not built
+      (oper_utils.py:130-133): the tree search of dragonfly_amd.doo, which visits the boxes the
+      reference visits but fetches the values a frontier per device call.  Anything else goes to
+      Dragonfly's own maximiser when installed under it. """
+  acq_opt_method = str(anc_data.acq_opt_method).lower()
   if anc_data.domain.get_type() != 'euclidean':
     raise NotImplementedError('dragonfly_amd acquisitions handle Euclidean domains.')
-  if str(acq_opt_method).lower().startswith('rand'):
+  if acq_opt_method.startswith('rand'):
     kwargs.pop('vectorised', None)
     _, opt_pt, _ = random_maximise(acq_fn, anc_data.domain.bounds, anc_data.max_evals)
     return opt_pt
+  if acq_opt_method.startswith('pdoo') or \
+     (acq_opt_method.startswith('direct') and not _fortran_direct_available()):
+    frontier = int(getattr(anc_data, 'pdoo_frontier', PDOO_FRONTIER))
+    _, opt_pt, _ = pdoo_maximise_batched(acq_fn, anc_data.domain.bounds, anc_data.max_evals,
+                                         frontier=frontier, depth=2 if frontier > 0 else 0)
+    return opt_pt
   if external_maximise_with_method is None:
     raise NotImplementedError(
-        'acq_opt_method=%s is a per-point serial search in the reference (DIRECT/PDOO); only '
-        '"rand" is fused on the device. Install under Dragonfly (dragonfly_amd.install) to use '
-        'its maximisers.' % (acq_opt_method))
+        'acq_opt_method=%s is served by Dragonfly\'s own maximiser; install under Dragonfly '
+        '(dragonfly_amd.install) to use it.' % (anc_data.acq_opt_method))
   acquisition = lambda x: acq_fn(x.reshape((1, -1)))
-  _, opt_pt = external_maximise_with_method(acq_opt_method, acquisition, anc_data.domain,
+  _, opt_pt = external_maximise_with_method(anc_data.acq_opt_method, acquisition, anc_data.domain,
                                             anc_data.max_evals, *args, **kwargs)
   return opt_pt
 

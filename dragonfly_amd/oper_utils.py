@@ -5,6 +5,7 @@ from argparse import Namespace
 
 import numpy as np
 
+from .doo import pdoo_maximise, pdoo_maximise_batched, pdoo_minimise    # pylint: disable=unused-import
 from .general_utils import map_to_bounds
 
 

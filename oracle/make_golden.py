@@ -259,13 +259,60 @@ def gen_mfgp_case():
   print('wrote mfgp_f1_d3_n70')
 
 
+def gen_pdoo_cases():
+  """ The reference's PDOO (utils/doo.py, oper_utils.py:257-271) on closed-form objectives -- value,
+      point and the full query sequence -- and its acquisitions maximised with acq_opt_method
+      'pdoo' / 'direct' (the latter falls back to PDOO: no Fortran DIRECT here, oper_utils.py:130)
+      on two of the GP cases above. """
+  from dragonfly.utils.doo import DOOFunction, pdoo_wrap
+  from dragonfly.utils import oper_utils as ref_ou
+  from dragonfly.gp.gp_core import GP
+  from dragonfly.gp import kernel as K
+  from dragonfly.opt import gpb_acquisitions as A
+  from dragonfly.exd.domains import EuclideanDomain
+  from oracle.test_objectives import PDOO_CASES
+  out = {}
+  for name, fn, bounds, budget in PDOO_CASES:
+    val, pt, _ = ref_ou.pdoo_maximise(fn, bounds, budget)
+    _, _, hist = pdoo_wrap(DOOFunction(fn, bounds), budget, 1.0, 0.9, 2, 0.8, 1e-3, 0.5, return_history=True)
+    out[name + '_val'], out[name + '_pt'] = val, pt
+    out[name + '_queries'] = np.array(hist.query_points)
+    print('pdoo %s: %d queries, value %.6f' % (name, len(hist.query_points), val))
+  assert ref_ou.direct_ft_wrap is None, 'the fixture records the PDOO fall-back of "direct"'
+  for case_name in ('se_d2_n40', 'matern25_d6_n60'):
+    g = np.load(os.path.join(OUT, 'gp_' + case_name + '.npz'))
+    d = g['X'].shape[1]
+    if case_name.startswith('se'):
+      kern = K.SEKernel(d, float(g['kern_scale']), g['kern_bw'])
+    else:
+      kern = K.MaternKernel(d, float(g['kern_nu']), float(g['kern_scale']), g['kern_bw'])
+    mean_c = float(g['mean_c'])
+    gp = GP(list(g['X']), list(g['Y']), kern, lambda x, _c=mean_c: np.array([_c] * len(x)), float(g['noise']))
+    bounds = np.array([[0.0, 1.0]] * d)
+    for method, acq, in_progress in (('pdoo', 'ucb', ()), ('pdoo', 'ei', ()), ('direct', 'ucb', ()),
+                                     ('pdoo', 'pi', (g['Xh'][0],))):
+      anc = Namespace(max_evals=300, t=len(g['Y']), domain=EuclideanDomain(bounds),
+                      curr_max_val=float(g['Y'].max()), eval_points_in_progress=list(in_progress),
+                      acq_opt_method=method, handle_parallel='halluc', is_mf=False, domain_bounds=bounds)
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out['%s_%s_%s' % (case_name, method, acq)] = np.asarray(getattr(A.asy, acq)(gp, anc))
+      print('gp %s %s %s ->' % (case_name, method, acq), out['%s_%s_%s' % (case_name, method, acq)])
+  np.savez_compressed(os.path.join(OUT, 'pdoo_cases.npz'), **out)
+  print('wrote pdoo_cases')
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   import_reference()
   if len(sys.argv) > 1 and sys.argv[1] == 'mfgp':
     gen_mfgp_case()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'pdoo':
+    gen_pdoo_cases()
+    sys.exit(0)
   gen_gp_cases()
   gen_fitter_case()
   gen_c1_case()
   gen_mfgp_case()
+  gen_pdoo_cases()

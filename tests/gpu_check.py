@@ -499,7 +499,35 @@ def stage_rng():
   print('STAGE rng DONE')
 
 
-STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs', 'rng']
+def stage_pdoo():
+  """ PDOO acquisition maximisation: one point per device call (the reference's pattern) vs a frontier per call """
+  from dragonfly_amd.engine import Engine, KernelSpec
+  from dragonfly_amd.doo import pdoo_maximise_batched
+  eng = Engine()
+  for n, d, budget in ((4096, 6, 2000), (16384, 32, 2000)):
+    rs = np.random.RandomState(7)
+    X = rs.random_sample((n, d)); Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+    spec = KernelSpec('se', d, float(Y.var()), 0.3 * np.sqrt(d) * np.ones(d))
+    gp = eng.gp_fit(spec, X, Y - np.median(Y), float(Y.var() / 20))
+    def ucb(pts):
+      mu, sd = gp.predict(pts)
+      return mu + 2.0 * sd
+    bounds = [[0.0, 1.0]] * d
+    res = {}
+    for frontier, depth in ((0, 0), (32, 2), (128, 3)):
+      t0 = time.time()
+      v, p, h = pdoo_maximise_batched(ucb, bounds, budget, frontier=frontier, depth=depth, return_history=True)
+      res[frontier] = (time.time() - t0, v, p, h)
+    same = all(res[f][1] == res[0][1] and np.array_equal(res[f][2], res[0][2]) for f in res)
+    print('n=%d d=%d budget=%d (%d callbacks in the reference): ' % (n, d, budget, res[0][3].points_requested)
+          + ' | '.join('frontier %d: %.1f ms, %d calls, %d points' % (f, res[f][0] * 1e3, res[f][3].device_calls,
+                                                                     res[f][3].points_evaluated) for f in res)
+          + ' | identical: %s' % same, flush=True)
+    gp.free()
+  print('STAGE pdoo DONE')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs', 'rng', 'pdoo']
 
 if __name__ == '__main__':
   if len(sys.argv) == 3 and sys.argv[1] == '--run':
