@@ -20,6 +20,7 @@ from .engine import get_engine
 from .general_utils import map_to_bounds
 from .gp_core import GP, ConstantMean
 from .kernel import _as_2d_array
+from .doo import pdoo_maximise_batched
 from .oper_utils import random_maximise, random_sample_cts_dscr
 from .option_handler import get_option_specs, load_options
 
@@ -217,6 +218,7 @@ class EuclideanGPFitter(object):
     self.num_data = len(X)
     self._X_dev = None
     self.batch_lml = True      # False: one dfh_gp_fit per candidate (the reference's loop shape)
+    self.pdoo_frontier = 32    # open boxes prefetched per batch by the direct / pdoo tuners (0: one at a time)
     self._set_up()
 
   # -- set up (gp_core.py:323-356, 393-416; euclidean_gp.py:215-276) -------------------------------
@@ -293,27 +295,37 @@ class EuclideanGPFitter(object):
       self.param_order.append(["additive_grp", "dscr"])
 
   def _set_up_ml_hp_tune(self):
-    """ gp_core.py:423-474, restricted to the batchable optimisers. """
+    """ gp_core.py:423-474.  Every optimiser sees the tuning objective as a *batch* objective
+        (candidates in, log marginal likelihoods out, one dfh_gp_lml_batch call):
+          rand / rand_exp_sampling  the whole random sample is one batch (the reference evaluates
+                 it one candidate at a time, vectorised=False, gp_core.py:437,441; the random draws
+                 are the same calls in the same order, so a seeded run picks the same candidates);
+          pdoo   the tree search of dragonfly_amd.doo, a frontier of boxes per batch;
+          direct the reference's own fall-back when its Fortran DIRECT is not built -- PDOO
+                 (oper_utils.py:130-133); stand-alone there is no Fortran DIRECT, so always.
+        'default' resolves as in the reference (gp_core.py:77-82): direct up to 60
+        hyper-parameters, pdoo beyond. """
     method = self.options.ml_hp_tune_opt
     if method == 'default':
-      method = 'rand'
-    if method not in ['rand', 'rand_exp_sampling']:
-      raise NotImplementedError(
-          'ml_hp_tune_opt=%s (a serial tree search in the reference) is not part of the device '
-          'engine; use "rand" / "rand_exp_sampling", or dragonfly_amd.install under Dragonfly.'
-          % (method))
+      method = 'pdoo' if self.num_hps > 60 else 'direct'
+    if method not in ['rand', 'rand_exp_sampling', 'direct', 'pdoo']:
+      raise ValueError('Unknown ml_hp_tune_opt %s.' % (method))
     self.ml_hp_tune_opt_method = method
     if self.options.hp_tune_max_evals is not None and self.options.hp_tune_max_evals > 0:
       self.hp_tune_max_evals = self.options.hp_tune_max_evals
+    elif method in ['direct', 'pdoo']:
+      self.hp_tune_max_evals = min(1e4, max(500, self.num_hps * 50))
     elif method == 'rand':
       self.hp_tune_max_evals = min(1e4, max(500, self.num_hps * 200))
     else:
       self.hp_tune_max_evals = min(1e5, max(500, self.num_hps * 400))
-    # The reference evaluates the sampled candidates one at a time (vectorised=False,
-    # gp_core.py:437,441); here the whole sample goes to the device as one batch.  The random
-    # draws are the same calls in the same order, so a seeded run picks the same candidates.
     def _rand_wrap(obj, max_evals):
       opt_val, opt_pt, _ = random_maximise(obj, self.cts_hp_bounds, max_evals, vectorised=True)
+      return opt_val, opt_pt, None
+    def _tree_wrap(obj, max_evals):
+      opt_val, opt_pt, _ = pdoo_maximise_batched(obj, self.cts_hp_bounds, max_evals,
+                                                 frontier=self.pdoo_frontier,
+                                                 depth=2 if self.pdoo_frontier > 0 else 0)
       return opt_val, opt_pt, None
     def _rand_exp_sampling_wrap(obj, max_evals):
       sample_cts_hps, sample_dscr_hps, lml_vals = \
@@ -322,7 +334,7 @@ class EuclideanGPFitter(object):
       sample_probs = np.exp(lml_vals - max(lml_vals))
       sample_probs = sample_probs / sample_probs.sum()
       return sample_cts_hps, sample_dscr_hps, sample_probs
-    self.cts_hp_optimise = _rand_wrap
+    self.cts_hp_optimise = _rand_wrap if method == 'rand' else _tree_wrap
     self.hp_sampler = _rand_exp_sampling_wrap
 
   # -- building GPs (gp_core.py:501-543; euclidean_gp.py:325-339) ----------------------------------
@@ -451,7 +463,7 @@ class EuclideanGPFitter(object):
       hp_tune_criterion = self.options.hp_tune_criterion
     if hp_tune_criterion != 'ml':
       raise NotImplementedError('Only hp_tune_criterion="ml" runs on the device engine.')
-    if self.ml_hp_tune_opt_method == 'rand':
+    if self.ml_hp_tune_opt_method in ['direct', 'rand', 'pdoo']:
       best_cts_hps = None
       best_dscr_hps = None
       best_other_params = None

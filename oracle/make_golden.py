@@ -298,6 +298,18 @@ def gen_pdoo_cases():
         warnings.simplefilter('ignore')
         out['%s_%s_%s' % (case_name, method, acq)] = np.asarray(getattr(A.asy, acq)(gp, anc))
       print('gp %s %s %s ->' % (case_name, method, acq), out['%s_%s_%s' % (case_name, method, acq)])
+  # the fitter's maximum-likelihood tuning by tree search (gp_core.py:427-434, 463-468)
+  from dragonfly.gp.euclidean_gp import EuclideanGPFitter
+  f = np.load(os.path.join(OUT, 'fitter_d3_n45.npz'))
+  for kt, method in (('se', 'pdoo'), ('matern', 'direct')):
+    opts = Namespace(kernel_type=kt, ml_hp_tune_opt=method, hp_tune_max_evals=250, hp_tune_criterion='ml')
+    np.random.seed(4343)
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      _, gp, hps = EuclideanGPFitter(list(f['X']), list(f['Y']), options=opts).fit_gp()
+    out['fit_%s_%s_cts_hps' % (kt, method)] = np.array(hps[0], dtype=float)
+    out['fit_%s_%s_lml' % (kt, method)] = gp.compute_log_marginal_likelihood()
+    print('fitter %s %s ->' % (kt, method), hps[0], gp.compute_log_marginal_likelihood())
   np.savez_compressed(os.path.join(OUT, 'pdoo_cases.npz'), **out)
   print('wrote pdoo_cases')
 

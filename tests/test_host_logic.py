@@ -134,8 +134,12 @@ def test_fitter_set_up_matches_reference_bounds():
   xn = np.linalg.norm(X, 'fro') + 1e-4
   assert np.allclose(f.cts_hp_bounds[3], [np.log(0.01 * xn), np.log(10 * xn)])
   assert f.num_hps == 2 + 1 + 3 and f.hp_tune_max_evals == min(1e4, max(500, 6 * 200))
-  with pytest.raises(NotImplementedError):
-    EuclideanGPFitter(list(X), list(Y), options=Namespace(ml_hp_tune_opt='direct'))
+  # gp_core.py:77-82, 455-457: 'default' is direct up to 60 hyper-parameters (served by the PDOO
+  # fall-back, oper_utils.py:130-133), with its own evaluation budget
+  g = EuclideanGPFitter(list(X), list(Y), options=Namespace(kernel_type='se'))
+  assert g.ml_hp_tune_opt_method == 'direct' and g.hp_tune_max_evals == min(1e4, max(500, 6 * 50))
+  with pytest.raises(ValueError):
+    EuclideanGPFitter(list(X), list(Y), options=Namespace(ml_hp_tune_opt='anneal'))
   with pytest.raises(ValueError):
     EuclideanGPFitter(list(X), list(Y), options=Namespace(kernel_type='poly'))
 

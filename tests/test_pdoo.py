@@ -85,3 +85,25 @@ def test_pdoo_frontier_cuts_device_calls_and_keeps_the_answer(engine):
   assert v0 == v1 and np.array_equal(p0, p1)
   assert np.array_equal(np.array(h0.query_points), np.array(h1.query_points))
   assert h1.device_calls * 4 <= h0.device_calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kt,method', [('se', 'pdoo'), ('matern', 'direct')])
+def test_fitter_tree_search_tuning_picks_reference_hyperparameters(engine, kt, method):
+  """ EuclideanGPFitter with ml_hp_tune_opt 'pdoo' / 'direct' (gp_core.py:427-434, 463-468): the
+      tree search sees the log marginal likelihoods a frontier per dfh_gp_lml_batch call and ends
+      at the hyper-parameters the reference's one-fit-per-callback search ends at. """
+  from dragonfly_amd.euclidean_gp import EuclideanGPFitter
+  ref, data = load_golden('pdoo_cases'), load_golden('fitter_d3_n45')
+  opts = Namespace(kernel_type=kt, ml_hp_tune_opt=method, hp_tune_max_evals=250, hp_tune_criterion='ml')
+  results = []
+  for frontier in (32, 0):
+    fitter = EuclideanGPFitter(list(data['X']), list(data['Y']), options=opts)
+    fitter.pdoo_frontier = frontier
+    kind, gp, hps = fitter.fit_gp()
+    assert kind == 'fitted_gp'
+    results.append((np.array(hps[0], dtype=float), gp.compute_log_marginal_likelihood()))
+  for cts_hps, lml in results:
+    assert np.array_equal(cts_hps, ref['fit_%s_%s_cts_hps' % (kt, method)])
+    want = float(ref['fit_%s_%s_lml' % (kt, method)])
+    assert abs(lml - want) <= 1e-9 * abs(want)
