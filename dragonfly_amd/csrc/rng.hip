@@ -28,9 +28,11 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t cur, uint32_t nxt, uint32_t 
 }
 
 // One workgroup.  state[624] (device) is the current block, `pos` the next unread word in it.
-// Writes n_words raw (untempered) words to raw[], and leaves the last block in state[].
+// Walks n_words raw (untempered) words of the stream, keeps those with index in [keep_lo, keep_hi)
+// in raw[0 .. keep_hi - keep_lo), and leaves the last block in state[].
 __global__ __launch_bounds__(MT_THREADS) void mt19937_stream_kernel(uint32_t* __restrict__ state, int pos,
-                                                                      int64_t n_words,
+                                                                      int64_t n_words, int64_t keep_lo,
+                                                                      int64_t keep_hi,
                                                                       uint32_t* __restrict__ raw) {
   __shared__ uint32_t buf[2][MT_N];
   const int t = threadIdx.x;
@@ -43,12 +45,15 @@ __global__ __launch_bounds__(MT_THREADS) void mt19937_stream_kernel(uint32_t* __
   {  // what is left of the current block
     const int64_t left = MT_N - pos;
     const int64_t take = left < n_words ? left : n_words;
-    for (int64_t k = t; k < take; k += MT_THREADS) raw[k] = cur[pos + k];
+    for (int64_t k = t; k < take; k += MT_THREADS)
+      if (k >= keep_lo && k < keep_hi) raw[k - keep_lo] = cur[pos + k];
     done = take;
   }
   while (done < n_words) {
-    const int64_t room = n_words - done;   // words of this block that are wanted (>= 1)
-    uint32_t* dst = raw + done;
+    // words [lo, hi) of this block are kept (block-local indices; empty when lo >= hi)
+    const int64_t room = n_words - done;
+    const int64_t lo = keep_lo - done, hi = (keep_hi < n_words ? keep_hi : n_words) - done;
+    const int64_t shift = done - keep_lo;   // raw index of this block's word 0 (may be negative)
     // The new block goes to the other LDS buffer, so a phase never overwrites what a neighbour
     // still has to read and one barrier per phase is enough:
     //   phase A: k in [0, 227)    old[k], old[k+1], old[k+397]
@@ -57,21 +62,21 @@ __global__ __launch_bounds__(MT_THREADS) void mt19937_stream_kernel(uint32_t* __
     if (t < LAG) {
       const uint32_t v = mt_mix(cur[t], cur[t + 1], cur[t + MT_M]);
       nxt[t] = v;
-      if (t < room) dst[t] = v;
+      if (t >= lo && t < hi) raw[shift + t] = v;
     }
     __syncthreads();
     if (t < LAG) {
       const int k = LAG + t;
       const uint32_t v = mt_mix(cur[k], cur[k + 1], nxt[t]);
       nxt[k] = v;
-      if (k < room) dst[k] = v;
+      if (k >= lo && k < hi) raw[shift + k] = v;
     }
     __syncthreads();
     if (t < MT_N - 2 * LAG) {
       const int k = 2 * LAG + t;
       const uint32_t v = mt_mix(cur[k], k + 1 == MT_N ? nxt[0] : cur[k + 1], nxt[k - LAG]);
       nxt[k] = v;
-      if (k < room) dst[k] = v;
+      if (k >= lo && k < hi) raw[shift + k] = v;
     }
     __syncthreads();
     uint32_t* swap = cur; cur = nxt; nxt = swap;
@@ -155,24 +160,25 @@ __host__ __device__ inline Philox4 counter_add(Philox4 c, uint64_t inc) {
 }
 
 // Thread b computes block b: counter + 1 + b (NumPy increments before it generates), whose four
-// words are the doubles [lead + 4b, lead + 4b + 4).  The first `lead` doubles come from the words
-// NumPy still holds in its buffer.
+// words are the doubles [lead + 4b, lead + 4b + 4) of the stream.  The first `lead` doubles come
+// from the words NumPy still holds in its buffer.  Doubles [keep_lo, keep_hi) are written, to
+// out[0 .. keep_hi - keep_lo); only blocks [b_lo, b_hi) overlap them.
 __global__ __launch_bounds__(256) void philox_uniform_kernel(Philox4 counter, PhiloxKey key, Philox4 held,
-                                                               int held_pos, int lead, int64_t count,
-                                                               int64_t n_blocks, int64_t d,
-                                                               const double* __restrict__ box,
+                                                               int held_pos, int lead, int64_t b_lo,
+                                                               int64_t b_hi, int64_t keep_lo, int64_t keep_hi,
+                                                               int64_t d, const double* __restrict__ box,
                                                                double* __restrict__ out) {
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (tid < lead)
-    out[tid] = to_box(double(held.v[held_pos + tid] >> 11) * (1.0 / 9007199254740992.0), box, d, tid);
-  for (int64_t b = tid; b < n_blocks; b += stride) {
+  if (tid < lead && tid >= keep_lo && tid < keep_hi)
+    out[tid - keep_lo] = to_box(double(held.v[held_pos + tid] >> 11) * (1.0 / 9007199254740992.0), box, d, tid);
+  for (int64_t b = b_lo + tid; b < b_hi; b += stride) {
     const Philox4 w = philox4x64_10(counter_add(counter, uint64_t(b) + 1), key);
     const int64_t base = lead + 4 * b;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (base + q < count)
-        out[base + q] = to_box(double(w.v[q] >> 11) * (1.0 / 9007199254740992.0), box, d, base + q);
+      if (base + q >= keep_lo && base + q < keep_hi)
+        out[base + q - keep_lo] = to_box(double(w.v[q] >> 11) * (1.0 / 9007199254740992.0), box, d, base + q);
   }
 }
 
@@ -203,16 +209,19 @@ int grid_for(const dfh_ctx* ctx, int64_t items, int threads) {
 }  // namespace
 
 extern "C" int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int64_t m, int64_t d,
-                                        const double* bounds, double* out) {
-  DFH_ARG(ctx != nullptr && key != nullptr && pos != nullptr && out != nullptr);
+                                        int64_t row_begin, int64_t row_count, const double* bounds,
+                                        double* out) {
+  DFH_ARG(ctx != nullptr && key != nullptr && pos != nullptr);
   DFH_ARG(m >= 0 && d >= 1 && *pos >= 0 && *pos <= MT_N);
+  DFH_ARG(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= m);
+  DFH_ARG(out != nullptr || row_count == 0);
   DFH_ARG(!is_device_ptr(key) && !is_device_ptr(pos));
   DFH_HIP(hipSetDevice(ctx->device));
-  const int64_t count = m * d;
-  if (count == 0) return DFH_OK;
+  if (m * d == 0) return DFH_OK;
+  const int64_t count = row_count * d;        // doubles kept
   const double* d_box = nullptr;
   DFH_TRY(upload_box(ctx, bounds, d, &d_box));
-  const bool out_on_device = is_device_ptr(out);
+  const bool out_on_device = count == 0 || is_device_ptr(out);
   void* p = nullptr;
   double* d_out = out;
   if (!out_on_device) {
@@ -222,19 +231,26 @@ extern "C" int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* po
   DFH_TRY(scratch_get(ctx, SCR_VEC2, MT_N * sizeof(uint32_t), &p));
   uint32_t* d_state = static_cast<uint32_t*>(p);
   DFH_HIP(hipMemcpyAsync(d_state, key, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  const int64_t total_words = 2 * count;
-  const int64_t chunk_words = total_words < MT_CHUNK_WORDS ? total_words : MT_CHUNK_WORDS;
-  DFH_TRY(scratch_get(ctx, SCR_TMP, size_t(chunk_words) * sizeof(uint32_t), &p));
+  const int64_t total_words = 2 * m * d;
+  const int64_t keep_lo = 2 * row_begin * d, keep_hi = keep_lo + 2 * count;
+  const int64_t chunk_words = total_words < MT_CHUNK_WORDS ? total_words : MT_CHUNK_WORDS;   // even
+  const int64_t raw_words = 2 * count < chunk_words ? 2 * count : chunk_words;
+  DFH_TRY(scratch_get(ctx, SCR_TMP, size_t(raw_words > 0 ? raw_words : 2) * sizeof(uint32_t), &p));
   uint32_t* d_raw = static_cast<uint32_t*>(p);
   int cur = *pos;
   for (int64_t w0 = 0; w0 < total_words; w0 += chunk_words) {
-    const int64_t nw = total_words - w0 < chunk_words ? total_words - w0 : chunk_words;   // even
-    mt19937_stream_kernel<<<1, MT_THREADS, 0, ctx->stream>>>(d_state, cur, nw, d_raw);
+    const int64_t nw = total_words - w0 < chunk_words ? total_words - w0 : chunk_words;
+    // the part of this chunk that belongs to the kept rows, chunk-local word indices
+    const int64_t lo = (keep_lo > w0 ? keep_lo : w0) - w0;
+    const int64_t hi = (keep_hi < w0 + nw ? keep_hi : w0 + nw) - w0;
+    mt19937_stream_kernel<<<1, MT_THREADS, 0, ctx->stream>>>(d_state, cur, nw, lo, hi > lo ? hi : lo, d_raw);
     DFH_LAUNCH_CHECK();
-    const int64_t nd = nw / 2, first = w0 / 2;
-    mt19937_uniform_kernel<<<grid_for(ctx, nd, 256), 256, 0, ctx->stream>>>(
-        reinterpret_cast<const uint2*>(d_raw), nd, first, d, d_box, d_out + first);
-    DFH_LAUNCH_CHECK();
+    if (hi > lo) {
+      const int64_t nd = (hi - lo) / 2, first = (w0 + lo) / 2;     // global index of the first double
+      mt19937_uniform_kernel<<<grid_for(ctx, nd, 256), 256, 0, ctx->stream>>>(
+          reinterpret_cast<const uint2*>(d_raw), nd, first, d, d_box, d_out + (first - row_begin * d));
+      DFH_LAUNCH_CHECK();
+    }
     const int64_t left = MT_N - cur;
     if (nw <= left) {
       cur += int(nw);
@@ -251,21 +267,24 @@ extern "C" int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* po
 }
 
 extern "C" int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64_t* counter, uint64_t* buffer,
-                                       int32_t* buffer_pos, int64_t m, int64_t d, const double* bounds,
-                                       double* out) {
-  DFH_ARG(ctx != nullptr && key != nullptr && counter != nullptr && buffer != nullptr && out != nullptr);
+                                       int32_t* buffer_pos, int64_t m, int64_t d, int64_t row_begin,
+                                       int64_t row_count, const double* bounds, double* out) {
+  DFH_ARG(ctx != nullptr && key != nullptr && counter != nullptr && buffer != nullptr);
   DFH_ARG(buffer_pos != nullptr && *buffer_pos >= 0 && *buffer_pos <= 4 && m >= 0 && d >= 1);
+  DFH_ARG(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= m);
+  DFH_ARG(out != nullptr || row_count == 0);
   DFH_ARG(!is_device_ptr(key) && !is_device_ptr(counter) && !is_device_ptr(buffer));
   DFH_HIP(hipSetDevice(ctx->device));
-  const int64_t count = m * d;
-  if (count == 0) return DFH_OK;
+  const int64_t total = m * d;
+  if (total == 0) return DFH_OK;
+  const int64_t keep_lo = row_begin * d, keep = row_count * d;
   const double* d_box = nullptr;
   DFH_TRY(upload_box(ctx, bounds, d, &d_box));
-  const bool out_on_device = is_device_ptr(out);
+  const bool out_on_device = keep == 0 || is_device_ptr(out);
   double* d_out = out;
   if (!out_on_device) {
     void* p = nullptr;
-    DFH_TRY(scratch_get(ctx, SCR_OUT, size_t(count) * sizeof(double), &p));
+    DFH_TRY(scratch_get(ctx, SCR_OUT, size_t(keep) * sizeof(double), &p));
     d_out = static_cast<double*>(p);
   }
   Philox4 ctr, held;
@@ -273,12 +292,17 @@ extern "C" int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64
   const PhiloxKey pk{key[0], key[1]};
   const int held_pos = *buffer_pos;
   const int64_t avail = 4 - held_pos;
-  const int lead = int(count < avail ? count : avail);
-  const int64_t n_blocks = (count - lead + 3) / 4;
-  const int64_t items = n_blocks > lead ? n_blocks : lead;
-  philox_uniform_kernel<<<grid_for(ctx, items, 256), 256, 0, ctx->stream>>>(ctr, pk, held, held_pos, lead, count,
-                                                                             n_blocks, d, d_box, d_out);
-  DFH_LAUNCH_CHECK();
+  const int lead = int(total < avail ? total : avail);
+  const int64_t n_blocks = (total - lead + 3) / 4;
+  if (keep > 0) {
+    // counter based: only the blocks that overlap the kept doubles are computed
+    const int64_t b_lo = keep_lo > lead ? (keep_lo - lead) / 4 : 0;
+    const int64_t b_hi = keep_lo + keep > lead ? (keep_lo + keep - lead + 3) / 4 : 0;
+    const int64_t items = (b_hi - b_lo) > lead ? (b_hi - b_lo) : lead;
+    philox_uniform_kernel<<<grid_for(ctx, items, 256), 256, 0, ctx->stream>>>(
+        ctr, pk, held, held_pos, lead, b_lo, b_hi, keep_lo, keep_lo + keep, d, d_box, d_out);
+    DFH_LAUNCH_CHECK();
+  }
   // the state NumPy would be left in: counter of the last block, its four words, words used
   if (n_blocks == 0) {
     *buffer_pos = held_pos + lead;
@@ -286,9 +310,9 @@ extern "C" int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64
     ctr = counter_add(ctr, uint64_t(n_blocks));
     const Philox4 last = philox4x64_10(ctr, pk);
     for (int i = 0; i < 4; ++i) { counter[i] = ctr.v[i]; buffer[i] = last.v[i]; }
-    *buffer_pos = int(count - lead - 4 * (n_blocks - 1));
+    *buffer_pos = int(total - lead - 4 * (n_blocks - 1));
   }
-  if (!out_on_device) DFH_TRY(from_device(ctx, out, d_out, size_t(count) * sizeof(double)));
+  if (!out_on_device) DFH_TRY(from_device(ctx, out, d_out, size_t(keep) * sizeof(double)));
   else DFH_HIP(hipStreamSynchronize(ctx->stream));
   return DFH_OK;
 }

@@ -197,14 +197,16 @@ class Engine(object):
   def empty(self, shape):
     return DeviceArray(self, shape)
 
-  def random_candidates(self, num, dim, bounds=None, rng=None, out=None):
+  def random_candidates(self, num, dim, bounds=None, rng=None, out=None, rows=None):
     """ `num` uniform points of the box `bounds` ([dim][2]; None = unit cube) generated in HBM:
         the draw np.random.random((num, dim)) mapped to the bounds (oper_utils.py:62,
         general_utils.py:25-27), bit for bit, from the state of `rng` -- None / the np.random module
         (the global legacy state the reference uses), a np.random.RandomState, or a
         np.random.Generator over a Philox bit generator.  The generator is advanced exactly as
         the host draw would have advanced it.  Returns a DeviceArray [num x dim] (or fills `out`,
-        a DeviceArray or a host array). """
+        a DeviceArray or a host array).  rows=(begin, count) keeps only that slice of the rows (the
+        result is [count x dim]) while the generator still advances over all `num` rows: the shard
+        of one rank in a multi-GPU run. """
     num, dim = int(num), int(dim)
     if num < 0 or dim < 1:
       raise ValueError('random_candidates needs num >= 0 and dim >= 1.')
@@ -212,9 +214,12 @@ class Engine(object):
       bounds = _f64(bounds)
       if bounds.shape != (dim, 2):
         raise ValueError('bounds must have shape (dim, 2).')
+    row_begin, row_count = (0, num) if rows is None else (int(rows[0]), int(rows[1]))
+    if row_begin < 0 or row_count < 0 or row_begin + row_count > num:
+      raise ValueError('rows must lie inside [0, num).')
     if out is None:
-      out = DeviceArray(self, (max(num, 1), dim))
-      out.shape, out.size = (num, dim), num * dim
+      out = DeviceArray(self, (max(row_count, 1), dim))
+      out.shape, out.size = (row_count, dim), row_count * dim
     if rng is None or rng is np.random or isinstance(rng, np.random.RandomState):
       legacy = np.random if (rng is None or rng is np.random) else rng
       state = legacy.get_state()
@@ -222,8 +227,8 @@ class Engine(object):
         raise ValueError('The legacy NumPy state is not MT19937.')
       key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
       pos = C.c_int32(int(state[2]))
-      check(self.lib.dfh_rand_mt19937_uniform(self.ctx, _ptr(key), C.byref(pos), num, dim, _ptr(bounds),
-                                              _ptr(out)))
+      check(self.lib.dfh_rand_mt19937_uniform(self.ctx, _ptr(key), C.byref(pos), num, dim, row_begin,
+                                              row_count, _ptr(bounds), _ptr(out)))
       legacy.set_state((state[0], key, int(pos.value)) + tuple(state[3:]))
       return out
     bit_gen = getattr(rng, 'bit_generator', rng)
@@ -238,7 +243,8 @@ class Engine(object):
     held = np.ascontiguousarray(state['buffer'], dtype=np.uint64).copy()
     held_pos = C.c_int32(int(state['buffer_pos']))
     check(self.lib.dfh_rand_philox_uniform(self.ctx, _ptr(key), _ptr(counter), _ptr(held),
-                                           C.byref(held_pos), num, dim, _ptr(bounds), _ptr(out)))
+                                           C.byref(held_pos), num, dim, row_begin, row_count,
+                                           _ptr(bounds), _ptr(out)))
     state['state']['counter'] = counter
     state['buffer'] = held
     state['buffer_pos'] = int(held_pos.value)

@@ -97,3 +97,53 @@ def sharded_thompson(fitted_gp, cands, U, block, mean_const=0.0, rank=0, world_s
   if world_size == 1:
     return v, i
   return allgather_argmax(v, i, group=group, device=device)
+
+
+def sharded_random_candidates(engine, m, bounds, rank=0, world_size=1, align=1, rng=None):
+  """ This rank's shard of the m random candidates of a 'rand' acquisition, generated in HBM
+      (Engine.random_candidates, rows=...).  Every rank must call this with the generator in the
+      same state -- seed the ranks alike, as the single process of the reference is seeded once --
+      and every rank's generator ends in the state of the full draw, so the draws that follow
+      (the TS normals) are the same everywhere.  Returns (DeviceArray [hi - lo x d], lo, hi). """
+  bounds = np.asarray(bounds, dtype=np.float64)
+  lo, hi = shard_bounds(int(m), rank, world_size, align=align)
+  shard = engine.random_candidates(int(m), len(bounds), bounds=bounds, rng=rng, rows=(lo, hi - lo))
+  return shard, lo, hi
+
+
+def sharded_rand_acq_argmax(fitted_gp, acq, m, bounds, params=(0.0, 0.0), mean_const=0.0, rank=0,
+                            world_size=1, group=None, device=None, rng=None):
+  """ random_maximise of an acquisition over m candidates (oper_utils.py:70-80), candidates
+      generated and evaluated shard by shard on the GPUs.  Returns (best value, global index, the
+      winning point); identical on every rank: the point travels from its owner in a second tiny
+      all-gather. """
+  shard, lo, hi = sharded_random_candidates(fitted_gp.engine, m, bounds, rank, world_size, rng=rng)
+  if hi > lo:
+    v, i = fitted_gp.acq_argmax(acq, shard, params=params, mean_const=mean_const)
+    i += lo
+  else:
+    v, i = float('nan'), -1
+  if world_size > 1:
+    v, i = allgather_argmax(v, i, group=group, device=device)
+  mine = lo <= i < hi
+  point = shard.row(i - lo) if mine else np.zeros(len(bounds))
+  if world_size > 1:
+    point = allgather_rows(point, mine, group=group, device=device)
+  return v, i, point
+
+
+def allgather_rows(row, is_owner, group=None, device=None):
+  """ The row held by the one rank with is_owner set, on every rank. """
+  import torch
+  import torch.distributed as dist
+  world = dist.get_world_size(group)
+  if device is None:
+    device = 'cuda:%d' % torch.cuda.current_device() if dist.get_backend(group) == 'nccl' else 'cpu'
+  payload = torch.tensor(np.concatenate([[1.0 if is_owner else 0.0], np.asarray(row, dtype=np.float64)]),
+                         dtype=torch.float64, device=device)
+  gathered = [torch.empty_like(payload) for _ in range(world)]
+  dist.all_gather(gathered, payload, group=group)
+  for t in gathered:
+    if float(t[0].item()) == 1.0:
+      return t[1:].cpu().numpy()
+  raise RuntimeError('allgather_rows: no rank owns the row.')

@@ -261,11 +261,17 @@ int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double* Xg_all, co
  * np.random.get_state() -- and updates both in place to the state NumPy would be left in, so the
  * caller hands them back with np.random.set_state() and later host draws continue the stream.
  * dfh_rand_philox_uniform does the same for numpy.random.Philox (Philox4x64-10): key[2], and in/out
- * counter[4], buffer[4], buffer_pos of the bit generator's state.                                */
+ * counter[4], buffer[4], buffer_pos of the bit generator's state.
+ * Only rows [row_begin, row_begin + row_count) of the m x d block are written (`out` is
+ * [row_count x d]) while the state advances over the whole block: every rank of a multi-GPU run
+ * starts from the same state, keeps its own shard of the candidates, and ends in the same state
+ * (one process draws them all in the reference).  MT19937 has to walk the stream up to the end
+ * whatever the shard; Philox computes the shard's blocks only.                                   */
 int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int64_t m, int64_t d,
-                             const double* bounds, double* out);
+                             int64_t row_begin, int64_t row_count, const double* bounds, double* out);
 int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64_t* counter, uint64_t* buffer,
-                            int32_t* buffer_pos, int64_t m, int64_t d, const double* bounds, double* out);
+                            int32_t* buffer_pos, int64_t m, int64_t d, int64_t row_begin,
+                            int64_t row_count, const double* bounds, double* out);
 
 /* ---- timing of the last call's dominant kernels (HIP events, ms) ------------------------- */
 #define DFH_T_KERNMAT  0   /* training kernel-matrix build                                   */

@@ -113,3 +113,35 @@ def test_acquisitions_pick_the_same_point_with_device_and_host_candidates(engine
       tails.append(np.random.random(4))
     assert np.array_equal(picks[0], picks[1]), acq
     assert np.array_equal(tails[0], tails[1]), acq
+
+
+@pytest.mark.parametrize('kind', ['mt19937', 'philox'])
+def test_row_shards_tile_the_full_draw_and_leave_the_same_state(engine, kind):
+  """ Multi-GPU candidate generation: every rank starts from the same generator state, keeps its
+      own rows of the m x d block and ends in the state of the full draw. """
+  m, d = 5000, 7
+  def fresh():
+    if kind == 'mt19937':
+      rs = np.random.RandomState(77)
+      rs.random_sample(3)
+      return rs
+    gen = np.random.Generator(np.random.Philox(key=np.array([3, 4], dtype=np.uint64)))
+    gen.random(2)
+    return gen
+  state_of = lambda g: (g.get_state()[1].tolist(), g.get_state()[2]) if kind == 'mt19937' else \
+                       (g.bit_generator.state['state']['counter'].tolist(), g.bit_generator.state['buffer_pos'])
+  ref = fresh()
+  full = engine.random_candidates(m, d, bounds=np.tile(BOX, (2, 1))[:d], rng=ref).download()
+  for world in (1, 3, 8):
+    from dragonfly_amd.parallel import shard_bounds
+    parts = []
+    for rank in range(world):
+      lo, hi = shard_bounds(m, rank, world, align=64)
+      g = fresh()
+      part = engine.random_candidates(m, d, bounds=np.tile(BOX, (2, 1))[:d], rng=g, rows=(lo, hi - lo))
+      assert part.shape == (hi - lo, d)
+      parts.append(part.download() if hi > lo else np.zeros((0, d)))
+      assert state_of(g) == state_of(ref)
+    assert np.array_equal(np.concatenate(parts), full)
+  with pytest.raises(ValueError):
+    engine.random_candidates(10, 2, rows=(5, 6))

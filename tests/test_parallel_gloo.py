@@ -33,6 +33,30 @@ WORKER = textwrap.dedent('''
       v, i = parallel.allgather_argmax(lv, li)
       ok &= (i == int(np.argmax(vals)))
       ok &= (v != v) if np.isnan(vals[i]) else (v == vals[i])
+    # sharded device-generated candidates: a stand-in engine / GP with the product's interface
+    # (rows of the seeded host draw; a fixed linear acquisition), so that the sharding, the
+    # exchange of the winner and of its point are exercised without a GPU
+    class Shard(object):
+      def __init__(self, a): self.a, self.shape = a, a.shape
+      def row(self, i): return self.a[i].copy()
+    class Eng(object):
+      def random_candidates(self, num, dim, bounds=None, rng=None, out=None, rows=None):
+        full = rng.random_sample((num, dim)) * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+        return Shard(full[rows[0]:rows[0] + rows[1]])
+    class FakeGP(object):
+      engine = Eng()
+      def acq_argmax(self, acq, cands, params=(0.0, 0.0), mean_const=0.0):
+        vals = cands.a.dot(np.arange(1, cands.a.shape[1] + 1.0)) if len(cands.a) else np.zeros(0)
+        j = int(np.argmax(vals)); return float(vals[j]), j
+    bounds = np.array([[-1.0, 2.0], [0.0, 1.0], [3.0, 5.0]])
+    for m in (1, 2, 7, 100):
+      rs_all = np.random.RandomState(5)
+      full = rs_all.random_sample((m, 3)) * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+      want = int(np.argmax(full.dot(np.arange(1, 4.0))))
+      rs_rank = np.random.RandomState(5)
+      v, i, pt = parallel.sharded_rand_acq_argmax(FakeGP(), 'ucb', m, bounds, rank=rank, world_size=world, rng=rs_rank)
+      ok &= (i == want) and np.array_equal(pt, full[want]) and v == float(full[want].dot(np.arange(1, 4.0)))
+      ok &= np.array_equal(rs_rank.random_sample(3), rs_all.random_sample(3))
     print('RANK', rank, 'OK' if ok else 'FAIL')
     dist.destroy_process_group()
 ''') % ROOT
