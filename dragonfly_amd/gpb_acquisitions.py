@@ -72,10 +72,12 @@ def _can_fuse(gp, anc_data):
 
 def _fortran_direct_available():
   """ True when a Dragonfly with its compiled DIRECT is importable (oper_utils.py:21-25). """
+  if external_maximise_with_method is None:      # not installed under a Dragonfly
+    return False
   try:
     from dragonfly.utils import oper_utils as ref_oper_utils
     return ref_oper_utils.direct_ft_wrap is not None
-  except ImportError:
+  except Exception:     # pylint: disable=broad-except
     return False
 
 
