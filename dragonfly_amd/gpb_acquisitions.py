@@ -111,6 +111,20 @@ def maximise_acquisition(acq_fn, anc_data, *args, **kwargs):
   return opt_pt
 
 
+class _BoxDomain(object):
+  """ The Euclidean sub-domain of one additive group (EuclideanDomain(domain_bounds[group_j]),
+      gpb_acquisitions.py:180). """
+
+  def __init__(self, bounds):
+    self.bounds = np.asarray(bounds, dtype=np.float64)
+
+  def get_type(self):
+    return 'euclidean'
+
+  def get_dim(self):
+    return len(self.bounds)
+
+
 def _halluc_points(anc_data):
   """ gpb_acquisitions.py:56-64: the in-progress points when handle_parallel == 'halluc'. """
   if getattr(anc_data, 'handle_parallel', None) == 'halluc' and \
@@ -228,19 +242,33 @@ def _add_ucb(gp, add_kernel, mean_funcs, anc_data):
   """ gpb_acquisitions.py:139-189: one UCB maximisation per additive group, each over its own
       candidate set (max_evals // number of groups points, drawn group by group from the global
       np.random state as the reference's loop draws them; the acquisition itself consumes no random
-      numbers), the winners assembled coordinate-wise.  All groups go to the device in ONE call:
-      the per-group posteriors share the factor L and alpha in HBM and one triangular solve. """
+      numbers), the winners assembled coordinate-wise.  With 'rand' all groups go to the device in
+      ONE call: the per-group posteriors share the factor L and alpha in HBM and one triangular
+      solve.  Other maximisers, and per-group mean functions, take the reference's loop. """
   if not isinstance(add_kernel, AdditiveKernel):
     raise TypeError('add_ucb needs a GP with an AdditiveKernel.')
-  if mean_funcs is not None:
-    raise NotImplementedError('Per-group mean functions are not used by the reference (None).')
-  if not str(anc_data.acq_opt_method).lower().startswith('rand'):
-    raise NotImplementedError('add_ucb on the device engine uses acq_opt_method="rand".')
   groupings = add_kernel.groupings
   all_bounds = np.asarray(anc_data.domain_bounds, dtype=np.float64)
   per_group_evals = int(anc_data.max_evals // len(add_kernel.kernel_list))
   betas = [_get_add_ucb_beta_th(len(grp), anc_data.t) for grp in groupings]
   point = np.zeros((sum(len(grp) for grp in groupings),))
+  if mean_funcs is not None or not _is_rand_euclidean(anc_data):
+    # the reference's loop shape (gpb_acquisitions.py:159-183): one maximisation per group over
+    # the group's own box, by whatever maximiser is configured (the tree search for 'pdoo' /
+    # 'direct'), the group's posterior evaluated on the device for the rows the maximiser asks for
+    if mean_funcs is None:
+      mean_funcs = lambda x: np.array([0] * len(x))
+    if not hasattr(mean_funcs, '__iter__'):
+      mean_funcs = [mean_funcs] * len(groupings)
+    for j, (grp, beta, mean_func_j) in enumerate(zip(groupings, betas, mean_funcs)):
+      def _group_acq(X_j, _j=j, _beta=beta, _mean=mean_func_j):
+        X_j = _as_2d_array(X_j)
+        return gp.device_gp.add_ucb_group(_j, _beta, X_j, return_vals=True)[2] + _mean(X_j)
+      anc_j = copy(anc_data)
+      anc_j.max_evals = per_group_evals
+      anc_j.domain = _BoxDomain(all_bounds[grp])
+      point[grp] = maximise_acquisition(_group_acq, anc_j)
+    return point
   if DEVICE_CANDIDATES:
     engine = gp.device_gp.engine
     widths = [len(grp) for grp in groupings]

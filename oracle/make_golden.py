@@ -298,6 +298,22 @@ def gen_pdoo_cases():
         warnings.simplefilter('ignore')
         out['%s_%s_%s' % (case_name, method, acq)] = np.asarray(getattr(A.asy, acq)(gp, anc))
       print('gp %s %s %s ->' % (case_name, method, acq), out['%s_%s_%s' % (case_name, method, acq)])
+  # add-UCB with a tree-search maximiser: one PDOO run per additive group (gpb_acquisitions.py:159-183)
+  g = np.load(os.path.join(OUT, 'gp_additive_d10_n80.npz'))
+  groups = [[int(c) for c in row if c >= 0] for row in g['kern_groups']]
+  subs = []
+  for grp, bw, kd in zip(groups, g['kern_sub_bws'], g['kern_sub_kinds']):
+    bw = np.array(bw[:len(grp)])
+    subs.append(K.SEKernel(len(grp), 1.0, bw) if kd == 0 else K.MaternKernel(len(grp), 2.5, 1.0, bw))
+  add_kern = K.AdditiveKernel(float(g['kern_scale']), subs, groups)
+  mean_c = float(g['mean_c'])
+  add_gp = GP(list(g['X']), list(g['Y']), add_kern, lambda x, _c=mean_c: np.array([_c] * len(x)), float(g['noise']))
+  bounds = np.array([[0.0, 1.0]] * g['X'].shape[1])
+  anc = Namespace(max_evals=800, t=len(g['Y']), domain=EuclideanDomain(bounds), curr_max_val=float(g['Y'].max()),
+                  eval_points_in_progress=[], acq_opt_method='pdoo', handle_parallel='halluc', is_mf=False,
+                  domain_bounds=bounds)
+  out['additive_d10_n80_pdoo_add_ucb'] = np.asarray(A.asy.add_ucb(add_gp, anc))
+  print('gp additive pdoo add_ucb ->', out['additive_d10_n80_pdoo_add_ucb'])
   # the fitter's maximum-likelihood tuning by tree search (gp_core.py:427-434, 463-468)
   from dragonfly.gp.euclidean_gp import EuclideanGPFitter
   f = np.load(os.path.join(OUT, 'fitter_d3_n45.npz'))

@@ -107,3 +107,14 @@ def test_fitter_tree_search_tuning_picks_reference_hyperparameters(engine, kt, m
     assert np.array_equal(cts_hps, ref['fit_%s_%s_cts_hps' % (kt, method)])
     want = float(ref['fit_%s_%s_lml' % (kt, method)])
     assert abs(lml - want) <= 1e-9 * abs(want)
+
+
+@pytest.mark.gpu
+def test_add_ucb_with_tree_search_matches_reference(engine):
+  """ asy.add_ucb with acq_opt_method='pdoo': one tree search per additive group over the group's
+      box (gpb_acquisitions.py:159-183), group posteriors from dfh_gp_add_ucb_group. """
+  from dragonfly_amd import gpb_acquisitions as A
+  ref = load_golden('pdoo_cases')
+  g, gp, anc = _gp_and_anc('additive_d10_n80', 'pdoo', max_evals=800)
+  assert np.array_equal(np.asarray(A.asy.add_ucb(gp, anc)), ref['additive_d10_n80_pdoo_add_ucb'])
+  assert anc.max_evals == 800
