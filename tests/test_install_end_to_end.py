@@ -1,0 +1,89 @@
+"""CPU plumbing test of the drop-in seams: the REAL
+reference optimiser (dragonfly.opt.gp_bandit.EuclideanGPBandit, ask/tell) runs once as it is and
+once with dragonfly_amd.install(); with the same seed it must recommend the same point, through
+hyper-parameter tuning by the reference's own fitter, the GP, and the acquisition.
+
+There is no GPU in the build container and no reference on the GPU box, so here the mirrors talk
+to tests/oracle_engine.py (NumPy arithmetic behind the Engine interface -- test infrastructure).
+What this pins is everything ABOVE the C-ABI: constructor signatures, attributes the reference
+reads (gp.X, gp.kernel.hyperparams, ...), anc_data fields, random-number call order, return types.
+The C-ABI side of the same acquisitions is pinned on the MI355X by tests/test_gpu_golden.py."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+REF = os.environ.get('DRAGONFLY_REFERENCE', '/root/reference')
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'dragonfly')),
+                                reason='needs the reference tree (build container only)')
+
+
+def _branin_data():
+  from dragonfly.utils.euclidean_synthetic_functions import get_mf_branin_function
+  branin = get_mf_branin_function(1)[1]
+  Xraw = np.random.RandomState(101).random_sample((60, 2)) * np.array([15.0, 15.0]) + np.array([-5.0, 0.0])
+  return Xraw, np.array([branin(x) for x in Xraw])
+
+
+def _ask(options_update, num_asks=2):
+  """ tell 60 Branin evaluations, then ask; returns the recommended points and the fitted GP's
+      hyper-parameters. """
+  from dragonfly.opt import gp_bandit
+  from dragonfly.exd.domains import EuclideanDomain
+  from dragonfly.exd.experiment_caller import EuclideanFunctionCaller
+  from dragonfly.utils.option_handler import load_options
+  opts = load_options(gp_bandit.get_all_euc_gp_bandit_args())
+  opts.gpb_hp_tune_criterion = 'ml'
+  opts.hp_tune_max_evals = 40
+  for k, v in options_update.items():
+    setattr(opts, k, v)
+  np.random.seed(2024)
+  caller = EuclideanFunctionCaller(None, EuclideanDomain([[-5, 10], [0, 15]]))
+  opt = gp_bandit.EuclideanGPBandit(caller, ask_tell_mode=True, options=opts, reporter='silent')
+  opt.initialise()
+  Xraw, Y = _branin_data()
+  opt.tell([(x, y) for x, y in zip(Xraw, Y)])
+  opt.first_qinfos = []
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    points = [np.array(opt.ask()) for _ in range(num_asks)]
+  gp = opt.gp
+  hps = (gp.kernel.hyperparams['scale'], np.asarray(gp.kernel.hyperparams['dim_bandwidths'], dtype=float),
+         gp.noise_var, type(gp).__module__)
+  return points, hps
+
+
+CONFIGS = [
+  dict(kernel_type='se', acq='ucb', acq_opt_method='rand', acq_opt_max_evals=300, gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='matern', acq='ei', acq_opt_method='rand', acq_opt_max_evals=300, gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='se', acq='ts', acq_opt_method='rand', acq_opt_max_evals=200, gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='se', acq='ttei', acq_opt_method='rand', acq_opt_max_evals=200, gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='se', acq='ucb', acq_opt_method='pdoo', acq_opt_max_evals=150, gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='se', acq='pi', acq_opt_method='direct', acq_opt_max_evals=150, gpb_ml_hp_tune_opt='pdoo'),
+  dict(kernel_type='se', acq='add_ucb', acq_opt_method='rand', acq_opt_max_evals=300,
+       gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='matern', acq='add_ucb', acq_opt_method='pdoo', acq_opt_max_evals=150,
+       gpb_ml_hp_tune_opt='rand'),
+  dict(kernel_type='default', acq='default', acq_opt_method='default', gpb_ml_hp_tune_opt='rand'),
+]
+
+
+@pytest.mark.parametrize('cfg', CONFIGS, ids=['%s-%s-%s-%d' % (c['kernel_type'], c['acq'], c['acq_opt_method'], i) for i, c in enumerate(CONFIGS)])
+def test_reference_bandit_recommends_the_same_points_with_the_engine_installed(cfg, monkeypatch):
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  want_points, want_hps = _ask(cfg)
+  assert want_hps[3].startswith('dragonfly.')
+  patch_engine(monkeypatch)
+  install.install()
+  try:
+    got_points, got_hps = _ask(cfg)
+  finally:
+    install.uninstall()
+  assert got_hps[3].startswith('dragonfly_amd.')               # the bandit's GP is the mirror
+  assert got_hps[0] == want_hps[0] and np.array_equal(got_hps[1], want_hps[1]) and got_hps[2] == want_hps[2]
+  for got, want in zip(got_points, want_points):
+    assert np.array_equal(got, want)
