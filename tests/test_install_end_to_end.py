@@ -87,3 +87,55 @@ def test_reference_bandit_recommends_the_same_points_with_the_engine_installed(c
   assert got_hps[0] == want_hps[0] and np.array_equal(got_hps[1], want_hps[1]) and got_hps[2] == want_hps[2]
   for got, want in zip(got_points, want_points):
     assert np.array_equal(got, want)
+
+
+def _moo_run(acq):
+  """ A short multi-objective run of the reference (opt/multiobjective_gp_bandit.py): two
+      objectives on [0,1]^3, synthetic worker, 14 evaluations. """
+  from dragonfly.opt.multiobjective_gp_bandit import multiobjective_gpb_from_multi_func_caller, \
+      get_all_euc_moo_gp_bandit_args
+  from dragonfly.exd.experiment_caller import EuclideanMultiFunctionCaller
+  from dragonfly.exd.domains import EuclideanDomain
+  from dragonfly.exd.worker_manager import SyntheticWorkerManager
+  from dragonfly.utils.option_handler import load_options
+  f1 = lambda x: -float(np.sum((np.asarray(x) - 0.2) ** 2))
+  f2 = lambda x: -float(np.sum((np.asarray(x) - 0.8) ** 2))
+  caller = EuclideanMultiFunctionCaller([f1, f2], EuclideanDomain([[0, 1]] * 3), vectorised=False)
+  opts = load_options(get_all_euc_moo_gp_bandit_args())
+  opts.gpb_hp_tune_criterion = 'ml'
+  opts.gpb_ml_hp_tune_opt = 'rand'
+  opts.hp_tune_max_evals = 30
+  opts.acq_opt_max_evals = 100
+  opts.acq_opt_method = 'rand'
+  opts.acq = acq
+  np.random.seed(7)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    _, _, history = multiobjective_gpb_from_multi_func_caller(
+        caller, SyntheticWorkerManager(1, time_distro='const'), 14, is_mf=False, options=opts,
+        reporter='silent')
+  return np.array(history.query_points)
+
+
+@pytest.mark.parametrize('acq', ['ts', 'ucb'])
+def test_reference_multiobjective_bandit_inherits_the_engine(acq, monkeypatch):
+  """ the multi-objective acquisitions (opt/multiobjective_gpb_acquisitions.py:
+      19-107) only use gp.eval / gp.draw_samples of the GPs their Euclidean fitters build through the
+      rebound module global, so they run on the engine without a line of their own. """
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  import dragonfly_amd.gp_core as mirror_gp
+  want = _moo_run(acq)
+  patch_engine(monkeypatch)
+  built = []
+  orig = mirror_gp.GP.build_posterior
+  monkeypatch.setattr(mirror_gp.GP, 'build_posterior', lambda self: (built.append(1), orig(self))[1])
+  install.install()
+  try:
+    got = _moo_run(acq)
+  finally:
+    install.uninstall()
+  assert len(built) > 0                       # the mirror GP did the fitting
+  assert got.shape == want.shape and np.array_equal(got, want)
