@@ -536,11 +536,11 @@ extern "C" int dfh_gp_free(dfh_gp* gp) {
     (void)hipStreamSynchronize(gp->ctx->stream);
   }
   kerndev_free(&gp->kd);
-  if (gp->Xp) (void)hipFree(gp->Xp);
-  if (gp->Np) (void)hipFree(gp->Np);
-  if (gp->L) (void)hipFree(gp->L);
-  if (gp->inv) (void)hipFree(gp->inv);
-  if (gp->alpha) (void)hipFree(gp->alpha);
+  dev_release(gp->ctx, gp->Xp);
+  dev_release(gp->ctx, gp->Np);
+  dev_release(gp->ctx, gp->L);
+  dev_release(gp->ctx, gp->inv);
+  dev_release(gp->ctx, gp->alpha);
   delete gp;
   return DFH_OK;
 }
@@ -575,11 +575,11 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
   auto body = [&]() -> int {
     DFH_TRY(kerndev_build(ctx, k, &gp->kd));
     const KernDev& kd = gp->kd;
-    DFH_HIP(hipMalloc(&gp->Xp, (size_t)n * kd.P * 8));
-    DFH_HIP(hipMalloc(&gp->Np, (size_t)n * kd.n_parts * 8));
-    DFH_HIP(hipMalloc(&gp->L, (size_t)n * n * 8));
-    DFH_HIP(hipMalloc(&gp->inv, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8));
-    DFH_HIP(hipMalloc(&gp->alpha, (size_t)n * 8));
+    DFH_TRY(dev_alloc(ctx, (size_t)n * kd.P * 8, (void**)&gp->Xp));
+    DFH_TRY(dev_alloc(ctx, (size_t)n * kd.n_parts * 8, (void**)&gp->Np));
+    DFH_TRY(dev_alloc(ctx, (size_t)n * n * 8, (void**)&gp->L));
+    DFH_TRY(dev_alloc(ctx, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8, (void**)&gp->inv));
+    DFH_TRY(dev_alloc(ctx, (size_t)n * 8, (void**)&gp->alpha));
     const double *dX = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
     DFH_TRY(to_device(ctx, y_centred, (size_t)n * 8, SCR_STAGE_B, &dy));
@@ -628,9 +628,9 @@ extern "C" int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const d
   gp->ctx = ctx; gp->n = n; gp->d = 0; gp->noise_var = noise_var; gp->gram = true;
   gp->nblk = (n + CHOL_NB - 1) / CHOL_NB;
   auto body = [&]() -> int {
-    DFH_HIP(hipMalloc(&gp->L, (size_t)n * n * 8));
-    DFH_HIP(hipMalloc(&gp->inv, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8));
-    DFH_HIP(hipMalloc(&gp->alpha, (size_t)n * 8));
+    DFH_TRY(dev_alloc(ctx, (size_t)n * n * 8, (void**)&gp->L));
+    DFH_TRY(dev_alloc(ctx, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8, (void**)&gp->inv));
+    DFH_TRY(dev_alloc(ctx, (size_t)n * 8, (void**)&gp->alpha));
     const double *dK = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, K, (size_t)n * n * 8, SCR_KCT, &dK));
     DFH_TRY(to_device(ctx, y_centred, (size_t)n * 8, SCR_STAGE_B, &dy));
@@ -763,11 +763,11 @@ extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const do
     DFH_TRY(kerndev_clone(ctx, gp->kd, &g2->kd));
     const KernDev& kd = g2->kd;
     const int64_t P = kd.P, parts = kd.n_parts;
-    DFH_HIP(hipMalloc(&g2->Xp, (size_t)n2 * P * 8));
-    DFH_HIP(hipMalloc(&g2->Np, (size_t)n2 * parts * 8));
-    DFH_HIP(hipMalloc(&g2->L, (size_t)n2 * n2 * 8));
-    DFH_HIP(hipMalloc(&g2->inv, (size_t)g2->nblk * NB * NB * 8));
-    DFH_HIP(hipMalloc(&g2->alpha, (size_t)n2 * 8));
+    DFH_TRY(dev_alloc(ctx, (size_t)n2 * P * 8, (void**)&g2->Xp));
+    DFH_TRY(dev_alloc(ctx, (size_t)n2 * parts * 8, (void**)&g2->Np));
+    DFH_TRY(dev_alloc(ctx, (size_t)n2 * n2 * 8, (void**)&g2->L));
+    DFH_TRY(dev_alloc(ctx, (size_t)g2->nblk * NB * NB * 8, (void**)&g2->inv));
+    DFH_TRY(dev_alloc(ctx, (size_t)n2 * 8, (void**)&g2->alpha));
     const double *dXn = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, Xnew, (size_t)q * d * 8, SCR_STAGE_A, &dXn));
     DFH_TRY(to_device(ctx, y_centred, (size_t)n2 * 8, SCR_STAGE_B, &dy));

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include "../../include/dfhip.h"
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -76,6 +77,14 @@ struct dfh_ctx {
   std::vector<GemmRec> gemm_recs;
   size_t gemm_used = 0;
   hipEvent_t gemm_base = nullptr;   // time origin of the per-launch intervals
+  // Block cache behind dev_alloc / dev_release: hipMalloc + hipFree of anything beyond the
+  // runtime's small-block arena costs ~0.3 ms (2 MiB), which is most of a GP fit at n < 1000 --
+  // the hyper-parameter searches of the reference fit and drop thousands of those in a row.
+  struct PoolBlock { void* p; size_t cap; };
+  std::vector<PoolBlock> pool_idle;                 // released blocks, ready for reuse
+  std::unordered_map<void*, size_t> pool_caps;      // capacity of every block handed out or idle
+  size_t pool_idle_bytes = 0;
+  size_t pool_idle_limit = size_t(2) << 30;         // DFH_POOL_MAX_MIB (0 disables the cache)
 };
 
 enum ScratchSlot {
@@ -106,6 +115,12 @@ enum ScratchSlot {
   SCR_OUT2,
   SCR_COUNT
 };
+
+// Device memory that outlives a call (GP state, caller-visible buffers): cached by size on release.
+// The context's stream is idle whenever a block is released (callers synchronise first), so a
+// reused block is never still being written by an earlier launch.
+int dev_alloc(dfh_ctx* ctx, size_t bytes, void** out);
+void dev_release(dfh_ctx* ctx, void* p);      // ctx may be null / already destroyed: plain hipFree
 
 // returns a device pointer with at least `bytes` capacity (contents undefined)
 int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out);

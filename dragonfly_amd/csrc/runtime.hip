@@ -1,6 +1,7 @@
 // Context, memory and error plumbing of libdfhip.so, plus the small elementwise / reduction
 // kernels every stage shares.
 #include "common.h"
+#include <cstdlib>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -85,6 +86,7 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live_ctx.insert(ctx);
   }
+  if (const char* e = getenv("DFH_POOL_MAX_MIB")) ctx->pool_idle_limit = size_t(strtoull(e, nullptr, 10)) << 20;
   *out = ctx;
   return DFH_OK;
 }
@@ -99,6 +101,7 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& b : ctx->scratch)
     if (b.p) (void)hipFree(b.p);
+  for (auto& b : ctx->pool_idle) (void)hipFree(b.p);     // blocks still held by live GPs stay theirs
   if (ctx->d_info) (void)hipFree(ctx->d_info);
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
   (void)hipEventDestroy(ctx->ev0);
@@ -141,17 +144,74 @@ extern "C" int dfh_device_name(dfh_ctx* ctx, char* buf, size_t buflen) {
   return DFH_OK;
 }
 
+// Capacity classes: powers of two up to 4 MiB, multiples of 2 MiB beyond, so that the buffers of
+// consecutive fits of similar size land in the same class.
+static size_t pool_capacity(size_t bytes) {
+  if (bytes <= 256) return 256;
+  if (bytes <= (size_t(4) << 20)) {
+    size_t cap = 256;
+    while (cap < bytes) cap <<= 1;
+    return cap;
+  }
+  const size_t step = size_t(2) << 20;
+  return (bytes + step - 1) / step * step;
+}
+
+int dev_alloc(dfh_ctx* ctx, size_t bytes, void** out) {
+  *out = nullptr;
+  const size_t cap = pool_capacity(bytes);
+  for (size_t i = 0; i < ctx->pool_idle.size(); ++i) {
+    if (ctx->pool_idle[i].cap == cap) {
+      *out = ctx->pool_idle[i].p;
+      ctx->pool_idle_bytes -= cap;
+      ctx->pool_idle[i] = ctx->pool_idle.back();
+      ctx->pool_idle.pop_back();
+      return DFH_OK;
+    }
+  }
+  hipError_t e = hipMalloc(out, cap);
+  if (e != hipSuccess && !ctx->pool_idle.empty()) {
+    // out of memory with blocks parked in the cache: give them back and try once more
+    (void)hipGetLastError();
+    for (auto& b : ctx->pool_idle) { ctx->pool_caps.erase(b.p); (void)hipFree(b.p); }
+    ctx->pool_idle.clear();
+    ctx->pool_idle_bytes = 0;
+    e = hipMalloc(out, cap);
+  }
+  if (e != hipSuccess) {
+    dfh_set_error("%s:%d: hipMalloc(%zu) -> %s", __FILE__, __LINE__, cap, hipGetErrorString(e));
+    return DFH_ERR_HIP;
+  }
+  ctx->pool_caps[*out] = cap;
+  return DFH_OK;
+}
+
+void dev_release(dfh_ctx* ctx, void* p) {
+  if (!p) return;
+  if (ctx == nullptr || !ctx_is_live(ctx)) { (void)hipFree(p); return; }   // context gone: nothing to cache in
+  auto it = ctx->pool_caps.find(p);
+  if (it == ctx->pool_caps.end()) { (void)hipFree(p); return; }
+  const size_t cap = it->second;
+  if (ctx->pool_idle_bytes + cap <= ctx->pool_idle_limit) {
+    ctx->pool_idle.push_back({p, cap});
+    ctx->pool_idle_bytes += cap;
+    return;
+  }
+  ctx->pool_caps.erase(it);
+  (void)hipFree(p);
+}
+
 extern "C" int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr) {
   DFH_ARG(ctx && dptr);
   DFH_HIP(hipSetDevice(ctx->device));
-  DFH_HIP(hipMalloc(dptr, bytes ? bytes : 8));
-  return DFH_OK;
+  return dev_alloc(ctx, bytes ? bytes : 8, dptr);
 }
 
 extern "C" int dfh_free(dfh_ctx* ctx, void* dptr) {
   if (!dptr) return DFH_OK;
-  if (ctx && ctx_is_live(ctx)) DFH_HIP(hipStreamSynchronize(ctx->stream));   // else: context already destroyed
-  DFH_HIP(hipFree(dptr));
+  const bool live = ctx && ctx_is_live(ctx);
+  if (live) DFH_HIP(hipStreamSynchronize(ctx->stream));   // else: context already destroyed
+  dev_release(live ? ctx : nullptr, dptr);
   return DFH_OK;
 }
 
