@@ -24,13 +24,27 @@ edited):
   S4 acquisitions  the fused callables are written into the namespaces
                dragonfly.opt.gpb_acquisitions.asy / syn / seq (looked up with getattr at
                dragonfly/opt/gp_bandit.py:490,510,651,681)
-Dragonfly's own serial maximisers (DIRECT / PDOO) keep working: they call gp.eval per point, which
-now runs on the device, through `external_maximise_with_method`.
+  S3 fitter    dragonfly.opt.gp_bandit.EuclideanGPFitter and
+               dragonfly.opt.multiobjective_gp_bandit.EuclideanGPFitter (the names the bandits
+               construct their fitters by, gp_bandit.py:22,584; multiobjective_gp_bandit.py:27,481)
+               -> a subclass OF THE REFERENCE'S fitter that only changes how the maximum-likelihood
+               tuners see their objective: as a batch (candidates in, log marginal likelihoods
+               out, one dfh_gp_lml_batch call) instead of one fit per callback.  'rand' and
+               'rand_exp_sampling' evaluate their whole sample in one call, 'pdoo' -- and 'direct'
+               without the Fortran library, the reference's own fall-back and its default -- run
+               the tree search of dragonfly_amd.doo a frontier per call.  Everything else of the
+               fitter (options, bounds, posterior sampling, the bandit bookkeeping) is the
+               reference's code.  install(batched_tuning=False) leaves the fitter alone.
+A compiled Fortran DIRECT, when present, keeps working: it calls gp.eval per point, which now
+runs on the device, through `external_maximise_with_method`.
 """
+import numpy as np
+
+
 _saved = []     # (object, attribute name, original value)
 
 
-def install(multi_fidelity=False):
+def install(multi_fidelity=False, batched_tuning=True):
   """ Rebinds the names listed above; returns the list of patched attributes. """
   import dragonfly.gp.kernel as ref_kernel
   import dragonfly.gp.euclidean_gp as ref_egp
@@ -56,7 +70,103 @@ def install(multi_fidelity=False):
       setattr(ref_ns, acq, getattr(our_ns, acq))
       patched.append('dragonfly.opt.gpb_acquisitions.%s.%s' % (ns_name, acq))
   gpb_acquisitions.external_maximise_with_method = maximise_with_method
+  if batched_tuning:
+    import dragonfly.opt.gp_bandit as ref_gp_bandit
+    import dragonfly.opt.multiobjective_gp_bandit as ref_moo_bandit
+    batched = make_batched_fitter(ref_egp.EuclideanGPFitter)
+    _set(ref_gp_bandit, 'EuclideanGPFitter', batched)
+    _set(ref_moo_bandit, 'EuclideanGPFitter', batched)
   return patched
+
+
+def make_batched_fitter(ref_fitter_cls):
+  """ A subclass of the reference's EuclideanGPFitter whose maximum-likelihood tuners evaluate the
+      tuning objective (gp_core.py:551-564) in batches on the device. """
+  from .doo import pdoo_maximise_batched
+  from .engine import get_engine
+  from .gpb_acquisitions import _fortran_direct_available
+  from .kernel import _as_2d_array
+  from .oper_utils import random_maximise, random_sample_cts_dscr
+
+  class BatchedEuclideanGPFitter(ref_fitter_cls):
+    """ dragonfly.gp.euclidean_gp.EuclideanGPFitter with batched ML tuning (dragonfly_amd.install). """
+    pdoo_frontier = 32
+
+    def _set_up_ml_hp_tune(self):
+      """ gp_core.py:423-474, then the optimisers are swapped for their batch-objective forms
+          (same random draws / same boxes, so the same hyper-parameters win). """
+      ref_fitter_cls._set_up_ml_hp_tune(self)
+      self._X_dev = None
+      method = self.ml_hp_tune_opt_method
+      def _rand(obj, max_evals):
+        val, pt, _ = random_maximise(obj, self.cts_hp_bounds, max_evals, vectorised=True)
+        return val, pt, None
+      def _tree(obj, max_evals):
+        val, pt, _ = pdoo_maximise_batched(obj, self.cts_hp_bounds, max_evals, frontier=self.pdoo_frontier,
+                                           depth=2 if self.pdoo_frontier > 0 else 0)
+        return val, pt, None
+      def _rand_exp(obj, max_evals):
+        cts, dscr, lml_vals = random_sample_cts_dscr(obj, self.cts_hp_bounds, self.dscr_hp_vals, max_evals,
+                                                     vectorised=True)
+        probs = np.exp(lml_vals - max(lml_vals))
+        return cts, dscr, probs / probs.sum()
+      self._batched_ml = True
+      if method == 'rand':
+        self.cts_hp_optimise = _rand
+      elif method == 'pdoo' or (method == 'direct' and not _fortran_direct_available()):
+        self.cts_hp_optimise = _tree
+      elif method == 'rand_exp_sampling':
+        self.hp_sampler = _rand_exp
+      else:
+        self._batched_ml = False          # a compiled DIRECT drives the search one point at a time
+
+    def _lml_batch(self, cts_hps_list, dscr_hps, other_gp_params=None):
+      """ Log marginal likelihoods of a list of candidates.  Each candidate goes through the
+          reference's own build_gp (gp_core.py:501-543) without building a posterior -- that gives
+          the kernel, the constant mean and the noise variance it would be fitted with -- and the
+          whole list is fitted in one device call. """
+      per_cand = len(dscr_hps) > 0 and isinstance(dscr_hps[0], (list, tuple, np.ndarray))
+      if len(cts_hps_list) == 0:
+        return np.zeros((0,))
+      user_mean = getattr(self.options, 'mean_func', None) is not None
+      specs, means, noises = [], [], []
+      probe = [np.zeros(self.dim)]
+      for i, cts in enumerate(cts_hps_list):
+        dscr = list(dscr_hps[i]) if per_cand else list(dscr_hps)
+        gp = self.build_gp(cts, dscr, other_gp_params=other_gp_params, build_posterior=False)
+        if user_mean or getattr(gp, '_generic', True):
+          # an arbitrary mean function, or a kernel the host evaluates: one fit per candidate
+          return np.array([self._tuning_objective(c, list(dscr_hps[j]) if per_cand else list(dscr_hps),
+                                                  other_gp_params=other_gp_params)
+                           for j, c in enumerate(cts_hps_list)])
+        specs.append(gp.kernel.to_spec(self.dim))
+        means.append(float(gp.mean_func(probe)[0]))
+        noises.append(float(gp.noise_var))
+      if self._X_dev is None:
+        self._X_dev = get_engine().to_device(_as_2d_array(self.X))
+      return get_engine().gp_lml_batch(specs, self._X_dev, np.asarray(self.Y, dtype=np.float64), means, noises)
+
+    def _optimise_cts_hps_for_given_dscr_hps(self, given_dscr_hps):
+      """ gp_core.py:576-583 / euclidean_gp.py:303-313 with the batch objective. """
+      if not getattr(self, '_batched_ml', False):
+        return ref_fitter_cls._optimise_cts_hps_for_given_dscr_hps(self, given_dscr_hps)
+      if self.options.use_additive_gp:
+        from dragonfly.gp.euclidean_gp import optimise_cts_hps_for_given_dscr_hps_in_add_model
+        return optimise_cts_hps_for_given_dscr_hps_in_add_model(
+            given_dscr_hps, self.options.num_groups_per_group_size, self.dim, self.hp_tune_max_evals,
+            self.cts_hp_optimise, self._lml_batch)
+      objective = lambda arg: self._lml_batch(arg, list(given_dscr_hps))
+      val, cts_hps, _ = self.cts_hp_optimise(objective, self.hp_tune_max_evals)
+      return val, cts_hps, None
+
+    def _sample_cts_dscr_hps_for_rand_exp_sampling(self):
+      """ gp_core.py:585-590 (non-additive models) with the batch objective. """
+      if not getattr(self, '_batched_ml', False) or self.options.use_additive_gp:
+        return ref_fitter_cls._sample_cts_dscr_hps_for_rand_exp_sampling(self)
+      cts, dscr, probs = self.hp_sampler(self._lml_batch, self.hp_tune_max_evals)
+      return cts, dscr, [None] * len(cts), probs
+
+  return BatchedEuclideanGPFitter
 
 
 def uninstall():

@@ -126,7 +126,11 @@ class OracleEngine(object):
   def solve_triangular(self, L_lower, b, upper=False):
     return O.solve_upper_triangular(L_lower.T, b) if upper else O.solve_lower_triangular(L_lower, b)
 
+  lml_batch_sizes = None     # set to a list to record the batch sizes
+
   def gp_lml_batch(self, specs, X, y, mean_consts, noise_vars, allow_jitter=True, return_powers=False):
+    if self.lml_batch_sizes is not None:
+      self.lml_batch_sizes.append(len(specs))
     y = np.asarray(y, dtype=np.float64)
     return np.array([OracleFittedGP(self, s, X, y - c, nv).lml for s, c, nv in zip(specs, mean_consts, noise_vars)])
 

@@ -77,13 +77,17 @@ def test_reference_bandit_recommends_the_same_points_with_the_engine_installed(c
   from dragonfly_amd import install
   want_points, want_hps = _ask(cfg)
   assert want_hps[3].startswith('dragonfly.')
-  patch_engine(monkeypatch)
+  eng = patch_engine(monkeypatch)
+  eng.lml_batch_sizes = []
   install.install()
   try:
     got_points, got_hps = _ask(cfg)
   finally:
     install.uninstall()
   assert got_hps[3].startswith('dragonfly_amd.')               # the bandit's GP is the mirror
+  # ... and its fitter tuned in batches: the whole random sample in one call, the tree search a
+  # frontier per call (the reference makes one fit per candidate: hp_tune_max_evals = 40 of them)
+  assert len(eng.lml_batch_sizes) > 0 and max(eng.lml_batch_sizes) >= 10
   assert got_hps[0] == want_hps[0] and np.array_equal(got_hps[1], want_hps[1]) and got_hps[2] == want_hps[2]
   for got, want in zip(got_points, want_points):
     assert np.array_equal(got, want)
@@ -139,3 +143,30 @@ def test_reference_multiobjective_bandit_inherits_the_engine(acq, monkeypatch):
     install.uninstall()
   assert len(built) > 0                       # the mirror GP did the fitting
   assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_install_without_batched_tuning_leaves_the_fitter_alone(monkeypatch):
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  import dragonfly.opt.gp_bandit as ref_gp_bandit
+  import dragonfly.gp.euclidean_gp as ref_egp
+  cfg = CONFIGS[0]
+  want_points, _ = _ask(cfg)
+  eng = patch_engine(monkeypatch)
+  eng.lml_batch_sizes = []
+  install.install(batched_tuning=False)
+  try:
+    assert ref_gp_bandit.EuclideanGPFitter is ref_egp.EuclideanGPFitter
+    got_points, _ = _ask(cfg)
+  finally:
+    install.uninstall()
+  assert eng.lml_batch_sizes == [] and all(np.array_equal(a, b) for a, b in zip(got_points, want_points))
+  install.install()
+  try:
+    assert ref_gp_bandit.EuclideanGPFitter is not ref_egp.EuclideanGPFitter
+    assert issubclass(ref_gp_bandit.EuclideanGPFitter, ref_egp.EuclideanGPFitter)
+  finally:
+    install.uninstall()
+  assert ref_gp_bandit.EuclideanGPFitter is ref_egp.EuclideanGPFitter
