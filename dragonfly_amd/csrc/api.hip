@@ -1,6 +1,7 @@
 // extern "C" entry points of libdfhip.so (see include/dfhip.h for the contract and the
 // reference functions each one replaces) and the GP object that lives in HBM.
 #include "common.h"
+#include <cstring>
 #include <math.h>
 #include <limits.h>
 #include <string.h>
@@ -904,6 +905,27 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   std::vector<KernDev> kds((size_t)G);       // device images live in one scratch blob: nothing to free
   const double *dX = nullptr, *dy = nullptr;
   DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
+  if (n <= TINY_MAX_N) {
+    // small problems: pack, Gram matrix, stable_cholesky and the solve of every candidate in ONE
+    // launch (kernmat.hip: k_lml_tiny)
+    std::vector<KernDev> all((size_t)nb);
+    for (int c = 0; c < nb; ++c) DFH_TRY(kerndev_build_host(&descs[c], &all[c]));
+    if (lml_tiny_applies(all.data(), nb, n)) {
+      std::vector<double> y_host((size_t)n), ld_dot((size_t)nb * 2);
+      if (is_device_ptr(y)) {
+        DFH_HIP(hipMemcpyAsync(y_host.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        DFH_HIP(hipStreamSynchronize(ctx->stream));
+      } else {
+        std::memcpy(y_host.data(), y, (size_t)n * 8);
+      }
+      SectionTimer t(ctx, DFH_T_CHOL);
+      DFH_TRY(lml_tiny_batch(ctx, all.data(), nb, dX, n, d, y_host.data(), noise_vars, mean_consts,
+                             !(flags & DFH_FIT_NO_JITTER), ld_dot.data(), jitter_powers));
+      for (int c = 0; c < nb; ++c)     // gp_core.py:224-226
+        lml_out[c] = -0.5 * ld_dot[2 * c + 1] - ld_dot[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);
+      return DFH_OK;
+    }
+  }
   DFH_TRY(to_device(ctx, y, (size_t)n * 8, SCR_STAGE_B, &dy));
   double *Kb = nullptr, *invb = nullptr, *vecs = nullptr, *red = nullptr, *dpar = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * strideK * 8, (void**)&Kb));

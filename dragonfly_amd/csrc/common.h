@@ -205,6 +205,14 @@ int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* out);
 int kerndev_build_host(const dfh_kernel_desc* k, KernDev* out);
 size_t kerndev_blob_bytes(const KernDev& kd);
 int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, size_t blob_bytes);
+// One-launch tuning objective for small problems (kernmat.hip: k_lml_tiny): applies when
+// n <= TINY_MAX_N and every candidate's packed width / part count fits the LDS budget.
+constexpr int64_t TINY_MAX_N = 128;
+constexpr int TINY_MAX_P = 64, TINY_MAX_PARTS = 16;
+bool lml_tiny_applies(const KernDev* kds, int count, int64_t n);
+int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
+                   const double* y_host, const double* noise_vars, const double* mean_consts,
+                   bool allow_jitter, double* logdet_dot, int32_t* powers);
 int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* out);
 int kerndev_clone(dfh_ctx* ctx, const KernDev& src, KernDev* out);   // deep copy with its own device image
 void kerndev_free(KernDev* kd);

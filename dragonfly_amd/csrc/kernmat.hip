@@ -541,7 +541,240 @@ void add_part_cols(KernDev* kd, PartDev& pd, const int* cols, const double* bw, 
   kd->P += pd.kc;
 }
 
+// ---------------------------------------------------------------------------------------
+// The whole tuning objective of SMALL problems in one launch (n <= TINY_MAX_N): workgroup c packs
+// the inputs for candidate c's kernel, builds K + noise I, factors it (stable_cholesky's jitter
+// ladder included) and solves for the log marginal likelihood -- all in LDS, nothing but the two
+// result numbers goes back to HBM.  Sequential hyper-parameter searches (the reference's slice
+// sampler, its PDOO) ask for a handful of such values per call thousands of times; with one
+// launch per stage a call costs ~0.3 ms of launches and synchronisations, far more than the
+// arithmetic of a 50 x 50 Cholesky.
+// ---------------------------------------------------------------------------------------
+struct TinyCand {
+  long image;              // byte offset of the kernel image (blob_layout) in the blob
+  int P, n_parts, multi, product;
+  double outer, noise, mean;
+};
+struct TinyArgs {
+  ExpConsts ec;
+  const double* X; long ldx;       // [n x d] raw inputs (device)
+  const char* blob;                // TinyCand[count] | kernel images | y[n] | pow10[16]
+  long y_off, pow_off;
+  int n, count, allow_jitter;
+  double* out;                     // [count][4] = {sum log L_ii, |L^-1 (y - m)|^2, jitter power or -100, status}
+};
+
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, j <= i
+
+__global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int c = blockIdx.x, tid = threadIdx.x, n = a.n;
+  const TinyCand cand = reinterpret_cast<const TinyCand*>(a.blob)[c];
+  const char* image = a.blob + cand.image;
+  const int P = cand.P, n_parts = cand.n_parts;
+  // kernel image sections (blob_layout): parts | bw | cols | lcols
+  const size_t off_bw = (sizeof(PartDev) * n_parts + 15) & ~size_t(15);
+  const size_t off_cols = off_bw + ((sizeof(double) * (P ? P : 1) + 15) & ~size_t(15));
+  const PartDev* parts = reinterpret_cast<const PartDev*>(image);
+  const double* bw = reinterpret_cast<const double*>(image + off_bw);
+  const int* cols = reinterpret_cast<const int*>(image + off_cols);
+  const double* y = reinterpret_cast<const double*>(a.blob + a.y_off);
+  const double* pow10 = reinterpret_cast<const double*>(a.blob + a.pow_off);
+
+  double* A = lds;                                   // packed lower triangle of the (n+1) x (n+1) system
+  double* Xp = A + (n + 1) * (n + 2) / 2;            // [n][P]
+  double* Np = Xp + n * P;                           // [n][n_parts]
+  __shared__ int s_fail;
+
+  // get_scaled_repr (kernel.py:179-181) and the squared row norms (general_utils.py:66-67)
+  for (int idx = tid; idx < n * P; idx += 256) {
+    const int row = idx / P, pc = idx - row * P;
+    const int col = cols[pc];
+    Xp[idx] = col >= 0 ? a.X[(long)row * a.ldx + col] / bw[pc] : 0.0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * n_parts; idx += 256) {
+    const int row = idx / n_parts, part = idx - row * n_parts;
+    const PartDev& pd = parts[part];
+    int nreal = 0;
+    for (int q = 0; q < pd.kc; ++q) nreal += cols[pd.poff + q] >= 0;
+    Np[idx] = np_sumsq(Xp + row * P + pd.poff, nreal);
+  }
+  __syncthreads();
+
+  const int tx = tid & 15, ty = tid >> 4;
+  double max_diag = 0.0;                             // max(diag(K + noise I)), for the ladder
+  int power = -100;                                  // -100: no jitter needed
+  for (int attempt = 0; attempt < 17; ++attempt) {
+    double jitter = 0.0;
+    if (attempt > 0) {
+      power = attempt - 12;                          // -11 ... 4 (general_utils.py:183-203)
+      jitter = pow10[attempt - 1] * max_diag;
+    }
+    // K + noise I (+ jitter I), lower triangle; row n of the system is y - m
+    for (int i = ty; i < n; i += 16) {
+      for (int j = tx; j <= i; j += 16) {
+        double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
+        for (int part = 0; part < n_parts; ++part) {
+          const PartDev& pd = parts[part];
+          const double* xi = Xp + i * P + pd.poff;
+          const double* xj = Xp + j * P + pd.poff;
+          double dot = 0.0;
+          for (int q = 0; q < pd.kc; ++q) dot = fma(xi[q], xj[q], dot);
+          double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
+          dsq = dsq < 0.0 ? 0.0 : dsq;
+          const double kv = kern_eval(pd, dsq, a.ec);
+          if (cand.multi) res = cand.product ? res * kv : res + kv;
+          else res = kv;
+        }
+        if (cand.multi && !cand.product) res = cand.outer * res;
+        if (i == j) {
+          res += cand.noise;                         // gp_core.py:843
+          if (attempt > 0) res += jitter;            // M + diag_noise * np.eye(n)
+        }
+        A[tri(i, j)] = res;
+      }
+    }
+    for (int j = tid; j < n; j += 256) A[tri(n, j)] = y[j] - cand.mean;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (attempt == 0) {                              // np.diag(M).max() of the un-jittered matrix
+      double m = -INFINITY;
+      bool any_nan = false;
+      for (int i = 0; i < n; ++i) { const double v = A[tri(i, i)]; any_nan |= (v != v); m = v > m ? v : m; }
+      max_diag = any_nan ? NAN : m;
+    }
+    // right-looking Cholesky; the extra row turns into z = L^-1 (y - m) along the way
+    for (int k = 0; k < n; ++k) {
+      const double pivot = A[tri(k, k)];
+      if (!(pivot > 0.0)) {                          // not positive definite (or NaN)
+        if (tid == 0) s_fail = 1;
+        break;                                       // uniform: every thread reads the same pivot
+      }
+      const double lkk = sqrt(pivot);
+      __syncthreads();                               // everyone has read the pivot
+      for (int i = k + tid; i <= n; i += 256) A[tri(i, k)] = (i == k) ? lkk : A[tri(i, k)] / lkk;
+      __syncthreads();
+      for (int i = k + 1 + ty; i <= n; i += 16) {
+        const double lik = A[tri(i, k)];
+        const int jmax = i < n ? i : n - 1;          // row n has no diagonal entry
+        for (int j = k + 1 + tx; j <= jmax; j += 16) A[tri(i, j)] -= lik * A[tri(j, k)];
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    if (!s_fail) break;
+    __syncthreads();
+    if (!a.allow_jitter || attempt == 16) { power = attempt == 16 ? 99 : 98; break; }   // status below
+  }
+
+  double* out = a.out + 4 * (long)c;
+  if (s_fail) {
+    if (tid == 0) { out[0] = NAN; out[1] = NAN; out[2] = (double)power; out[3] = power == 98 ? 1.0 : 2.0; }
+    return;
+  }
+  double ld = 0.0, zz = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    ld += log(A[tri(i, i)]);
+    const double z = A[tri(n, i)];
+    zz = fma(z, z, zz);
+  }
+  for (int o = 32; o > 0; o >>= 1) { ld += __shfl_down(ld, o, 64); zz += __shfl_down(zz, o, 64); }
+  __shared__ double s_ld[4], s_zz[4];
+  if ((tid & 63) == 0) { s_ld[tid >> 6] = ld; s_zz[tid >> 6] = zz; }
+  __syncthreads();
+  if (tid == 0) {
+    out[0] = (s_ld[0] + s_ld[1]) + (s_ld[2] + s_ld[3]);
+    out[1] = (s_zz[0] + s_zz[1]) + (s_zz[2] + s_zz[3]);
+    out[2] = (double)power;
+    out[3] = 0.0;
+  }
+}
+
 }  // namespace
+
+bool lml_tiny_applies(const KernDev* kds, int count, int64_t n) {
+  if (n > TINY_MAX_N) return false;
+  for (int c = 0; c < count; ++c)
+    if (kds[c].P > TINY_MAX_P || kds[c].n_parts > TINY_MAX_PARTS || kds[c].P < 1) return false;
+  return true;
+}
+
+// logdet_dot[2c], [2c+1] = sum(log(diag(L_c))), (y - m_c)^T (K_c + noise_c I)^-1 (y - m_c);
+// powers[c] = jitter power used (INT32_MIN: none).  Returns DFH_ERR_NOT_PD / DFH_ERR_JITTER as the
+// one-fit path would.
+int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
+                   const double* y_host, const double* noise_vars, const double* mean_consts,
+                   bool allow_jitter, double* logdet_dot, int32_t* powers) {
+  std::vector<size_t> image_off((size_t)count);
+  size_t at = ((sizeof(TinyCand) * (size_t)count) + 15) & ~size_t(15);
+  int Pmax = 1, parts_max = 1;
+  for (int c = 0; c < count; ++c) {
+    image_off[c] = at;
+    at += kerndev_blob_bytes(kds[c]);
+    Pmax = std::max(Pmax, kds[c].P);
+    parts_max = std::max(parts_max, kds[c].n_parts);
+  }
+  const size_t y_off = at;
+  at += sizeof(double) * (size_t)n;
+  const size_t pow_off = at;
+  at += sizeof(double) * 16;
+  std::vector<char> host(at, 0);
+  TinyCand* cands = reinterpret_cast<TinyCand*>(host.data());
+  for (int c = 0; c < count; ++c) {
+    cands[c].image = (long)image_off[c];
+    cands[c].P = kds[c].P; cands[c].n_parts = kds[c].n_parts;
+    cands[c].multi = kds[c].multi ? 1 : 0; cands[c].product = kds[c].product ? 1 : 0;
+    cands[c].outer = kds[c].outer_scale;
+    cands[c].noise = noise_vars[c];
+    cands[c].mean = mean_consts ? mean_consts[c] : 0.0;
+    blob_fill(kds[c], host.data() + image_off[c]);
+  }
+  std::memcpy(host.data() + y_off, y_host, sizeof(double) * (size_t)n);
+  double* pw = reinterpret_cast<double*>(host.data() + pow_off);
+  for (int p = -11; p < 5; ++p) pw[p + 11] = pow(10.0, (double)p);      // 10 ** diag_noise_power
+  void* d_blob = nullptr;
+  double* d_out = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_AUG2, at, &d_blob));
+  DFH_TRY(scratch_get(ctx, SCR_OUT2, sizeof(double) * 4 * (size_t)count, (void**)&d_out));
+  DFH_HIP(hipMemcpyAsync(d_blob, host.data(), at, hipMemcpyHostToDevice, ctx->stream));
+  TinyArgs a;
+  a.ec = kExpConsts;
+  a.X = dX; a.ldx = ldx;
+  a.blob = static_cast<const char*>(d_blob);
+  a.y_off = (long)y_off; a.pow_off = (long)pow_off;
+  a.n = (int)n; a.count = count; a.allow_jitter = allow_jitter ? 1 : 0;
+  a.out = d_out;
+  const size_t lds_bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n * Pmax + (size_t)n * parts_max);
+  static bool attr_set[DFH_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device]) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lml_tiny), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 256));
+    attr_set[ctx->device] = true;
+  }
+  hipLaunchKernelGGL(k_lml_tiny, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
+  DFH_LAUNCH_CHECK();
+  std::vector<double> res((size_t)count * 4);
+  DFH_HIP(hipMemcpyAsync(res.data(), d_out, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int c = 0; c < count; ++c) {
+    const int status = (int)res[4 * c + 3];
+    if (status == 1) {
+      dfh_set_error("Matrix is not positive definite (candidate %d)", c);
+      return DFH_ERR_NOT_PD;
+    }
+    if (status == 2) {
+      dfh_set_error("Could not compute Cholesky decomposition despite adding jitter to the diagonal (candidate %d). "
+                    "This is likely because the M is not positive semi-definite or has infinities/nans.", c);
+      return DFH_ERR_JITTER;
+    }
+    logdet_dot[2 * c] = res[4 * c];
+    logdet_dot[2 * c + 1] = res[4 * c + 1];
+    const int pwr = (int)res[4 * c + 2];
+    if (powers) powers[c] = pwr == -100 ? INT32_MIN : pwr;
+  }
+  return DFH_OK;
+}
 
 int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
   DFH_ARG(k != nullptr && kd != nullptr);

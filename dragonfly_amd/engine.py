@@ -111,9 +111,11 @@ class KernelSpec(object):
             _t(self.sub_scales), _t(self.sub_nus), subs)
 
   def to_desc(self):
-    """ Builds the ctypes struct (keeps the backing arrays alive on self). """
+    """ Builds the ctypes struct.  The arrays it points at are kept alive both on the struct
+        (d.backing) and on self -- appended, never dropped, so an earlier descriptor of the same
+        spec stays valid (a list of specs may hold one object several times). """
     d = KernelDesc()
-    self._keep = []
+    first = len(self._keep)
     if self.kind in ('se', 'matern'):
       d.kind = KERNEL_SE if self.kind == 'se' else KERNEL_MATERN
       d.dim = self.dim
@@ -151,6 +153,9 @@ class KernelSpec(object):
       d.sub_bw = bws.ctypes.data_as(_lib.c_double_p)
     else:
       raise ValueError('Unidentified kernel type %s.' % (self.kind))
+    d.backing = self._keep[first:]
+    if first > 0:
+      self._keep = self._keep[first:]       # older arrays live on with the descriptors that use them
     return d
 
 
@@ -372,8 +377,11 @@ class Engine(object):
     yh = y if isinstance(y, DeviceArray) else _f64(y)
     n, d = Xh.shape
     descs = (_lib.KernelDesc * max(nb, 1))()
+    backing = []
     for i, sp in enumerate(specs):
-      descs[i] = sp.to_desc()          # the spec objects keep the arrays the descriptors point at
+      one = sp.to_desc()
+      backing.append(one.backing)       # the arrays the copied struct points at
+      descs[i] = one
     mc = _f64(np.zeros(nb) if mean_consts is None else mean_consts).reshape(-1)
     nv = _f64(noise_vars).reshape(-1)
     if len(mc) != nb or len(nv) != nb:

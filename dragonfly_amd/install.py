@@ -142,9 +142,50 @@ def make_batched_fitter(ref_fitter_cls):
         specs.append(gp.kernel.to_spec(self.dim))
         means.append(float(gp.mean_func(probe)[0]))
         noises.append(float(gp.noise_var))
-      if self._X_dev is None:
+      if getattr(self, '_X_dev', None) is None:
         self._X_dev = get_engine().to_device(_as_2d_array(self.X))
       return get_engine().gp_lml_batch(specs, self._X_dev, np.asarray(self.Y, dtype=np.float64), means, noises)
+
+    # -- posterior sampling (gp_core.py:476-487, 592-726) -------------------------------------------
+    def _set_up_post_sampling_hp_tune(self):
+      """ The continuous hyper-parameters are slice-sampled one coordinate at a time
+          (gp_core.py:687-697); the sampler is swapped for the speculative one, which follows the
+          same chain with its density evaluations batched. """
+      ref_fitter_cls._set_up_post_sampling_hp_tune(self)
+      if self.options.post_hp_tune_method == 'slice':
+        self.hp_sampler_cts = self._speculative_slice
+
+    def _speculative_slice(self, model, init_sample, num_samples, burn):
+      # pylint: disable=unused-argument
+      from .slice_sampler import SpeculativeSlice
+      return SpeculativeSlice(self._post_logp_batch).sample(init_sample, num_samples, burn)
+
+    def _post_logp_batch(self, xs):
+      """ The log density `_logp` of gp_core.py:597-622 -- log priors of all hyper-parameters, summed
+          in index order, plus the log marginal likelihood -- at each value in xs of the
+          coordinate being sampled (self.curr_hp), the others as they currently are. """
+      num_cts = len(self.cts_hp_bounds)
+      out = np.empty(len(xs))
+      pending = []
+      for k, x in enumerate(xs):
+        hps = np.array(self.hps, dtype=np.float64)
+        hps[self.curr_hp] = x
+        lp = 0
+        for i, prior in enumerate(self.hp_priors):
+          if type(prior).__name__ == 'Categorical':
+            lp += prior.logp(prior.get_id(hps[i]))
+          else:
+            lp += prior.logp(hps[i])
+        if not np.isfinite(lp):
+          out[k] = lp
+        else:
+          pending.append((k, lp, hps))
+      if pending:
+        lmls = self._lml_batch([h[:num_cts] for _, _, h in pending],
+                               [h[num_cts:self.num_hps] for _, _, h in pending], self.other_gp_params)
+        for (k, lp, _), lml in zip(pending, lmls):
+          out[k] = lp + lml
+      return out
 
     def _optimise_cts_hps_for_given_dscr_hps(self, given_dscr_hps):
       """ gp_core.py:576-583 / euclidean_gp.py:303-313 with the batch objective. """

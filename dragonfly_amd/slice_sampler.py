@@ -1,0 +1,137 @@
+"""Univariate slice sampling with speculative, batched density evaluations.
+
+The reference samples hyper-parameters from the posterior (hp_tune_criterion 'post_sampling',
+dragonfly/gp/gp_core.py:592-726) one coordinate at a time with the slice sampler of
+dragonfly/sampling/slice.py:38-89.  Every step of that sampler -- the stepping-out of the slice
+edges and the shrinking towards an accepted point -- is a `while` loop that calls the log density
+once per turn, and every call is a GP fit: this is where an ordinary Dragonfly run spends most of
+its time.
+
+The loops only *look* sequential.  The points the stepping-out loop visits are q_l - k w and
+q_r + k w, known in advance; the points the shrinking loop visits depend on the density only
+through "all earlier ones were rejected", and on the random stream, which can be read ahead and
+rewound.  So each loop's next few candidates are evaluated in ONE batched density call (one
+dfh_gp_lml_batch on the device), the first candidate that ends the loop is found, and exactly the
+random numbers the reference would have consumed are consumed.  The chain is the reference's, draw
+for draw; what changes is two device calls per step instead of six to eight.
+"""
+import numpy as np
+import numpy.random as nr
+
+
+class SpeculativeSlice(object):
+  """ slice.py:15-36 for a univariate target given as a batch log-density:
+      logp_batch([x_0, ..., x_k]) -> [log p(x_0), ..., log p(x_k)].  w, tune as in the reference;
+      `ahead_step` / `ahead_shrink`: how many candidates of each loop go into one batch. """
+
+  def __init__(self, logp_batch, w=1., tune=True, ahead_step=3, ahead_shrink=4):
+    self.logp_batch = logp_batch
+    self.w = w
+    self.tune = tune
+    self.n_tunes = 0.
+    self.ahead_step, self.ahead_shrink = int(ahead_step), int(ahead_shrink)
+    self.batches = 0          # batched density calls made
+    self.evaluated = 0        # densities evaluated in them
+    self.consumed = 0         # densities the reference's loops would have asked for
+    self._known = (None, None)
+
+  def _logp(self, xs):
+    self.batches += 1
+    self.evaluated += len(xs)
+    return np.asarray(self.logp_batch(list(xs)), dtype=np.float64).ravel()
+
+  def _step_out(self, y, ql, qr, w):
+    """ slice.py:52-63: move each edge outwards by w until the density there is below the level. """
+    need_l, need_r = True, True
+    first = True
+    while need_l or need_r:
+      lefts, rights = [], []
+      edge = ql
+      for k in range(self.ahead_step if need_l else 0):
+        lefts.append(edge)
+        edge = edge - w               # the reference's repeated `ql[i] -= w[i]`
+      edge = qr
+      for k in range(self.ahead_step if need_r else 0):
+        rights.append(edge)
+        edge = edge + w
+      vals = self._logp(lefts + rights)
+      lv, rv = vals[:len(lefts)], vals[len(lefts):]
+      if need_l:
+        stop = next((k for k, v in enumerate(lv) if not y < v), None)
+        self.consumed += (stop + 1) if stop is not None else len(lefts)
+        if stop is not None:
+          ql, need_l = lefts[stop], False
+        else:
+          ql = lefts[-1] - w
+      if need_r:
+        # the reference only starts on the right edge once the left one is settled, but the
+        # density calls of the two loops do not interact, so their order does not matter
+        stop = next((k for k, v in enumerate(rv) if not y < v), None)
+        self.consumed += (stop + 1) if stop is not None else len(rights)
+        if stop is not None:
+          qr, need_r = rights[stop], False
+        else:
+          qr = rights[-1] + w
+      first = False
+    return ql, qr
+
+  def _shrink(self, y, q0, ql, qr):
+    """ slice.py:65-76: draw uniformly from [ql, qr]; a rejected draw becomes the new edge on its
+        side of q0.  Returns the accepted point, its log density and the final edges. """
+    while True:
+      state = nr.get_state()
+      draws = nr.rand(self.ahead_shrink)
+      cands, edges = [], []
+      l, r = ql, qr
+      for u in draws:
+        q = (r - l) * u + l
+        cands.append(q)
+        edges.append((l, r))
+        if q > q0:
+          r = q
+        elif q < q0:
+          l = q
+      vals = self._logp(cands)
+      hit = next((j for j, v in enumerate(vals) if not v < y), None)
+      if hit is not None:
+        nr.set_state(state)
+        nr.rand(hit + 1)              # exactly the draws the reference's loop consumes
+        self.consumed += hit + 1
+        l, r = edges[hit]
+        return cands[hit], vals[hit], l, r
+      self.consumed += len(cands)
+      ql, qr = l, r                   # all rejected: the stream has advanced by ahead_shrink draws
+
+  def _sample(self, q0):
+    """ One slice-sampling update of the scalar q0 (slice.py:38-89 with len(q0) == 1). """
+    w = float(np.resize(self.w, 1)[0])
+    known_q, known_lp = self._known
+    if known_q is not None and known_q == q0:
+      lp0 = known_lp                  # the density of the point accepted in the previous update
+      self.consumed += 1
+    else:
+      lp0 = self._logp([q0])[0]
+      self.consumed += 1
+    y = lp0 - nr.standard_exponential()
+    ql = q0 - nr.uniform(0, w)
+    qr = q0 + w
+    ql, qr = self._step_out(y, ql, qr, w)
+    q, lp, ql, qr = self._shrink(y, q0, ql, qr)
+    if self.tune:
+      self.w = w * (self.n_tunes / (self.n_tunes + 1)) + (qr - ql) / (self.n_tunes + 1)
+      self.n_tunes += 1
+    self._known = (q, lp)
+    return q
+
+  def sample(self, q0, num_samples=1, burn=100):
+    """ slice.py:91-110: `burn` discarded updates, then num_samples kept ones; [num_samples x 1]. """
+    if num_samples is None:
+      num_samples = 1
+    q = float(np.ravel(q0)[0])
+    for _ in range(burn):
+      q = self._sample(q)
+    samples = np.zeros([num_samples, 1])
+    for i in range(num_samples):
+      q = self._sample(q)
+      samples[i] = q
+    return samples

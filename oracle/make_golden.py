@@ -330,11 +330,36 @@ def gen_pdoo_cases():
   print('wrote pdoo_cases')
 
 
+def gen_slice_cases():
+  """ The reference's slice sampler (sampling/slice.py through distributions/model.py:51-54) on
+      closed-form log densities: the chain, the number of density calls, and the next number of the
+      global random stream after it. """
+  from dragonfly.distributions.model import Model
+  from oracle.test_objectives import SLICE_CASES
+  out = {}
+  for name, logp, start, num, burn, seed in SLICE_CASES:
+    calls = [0]
+    def counted(x, _f=logp, _c=calls):
+      _c[0] += 1
+      return _f(x)
+    np.random.seed(seed)
+    chain = Model(None, counted, None).draw_samples('slice', num, start, burn)
+    out[name + '_chain'] = np.asarray(chain)
+    out[name + '_calls'] = calls[0]
+    out[name + '_next_random'] = np.random.random()
+    print('slice %s: %d samples, %d density calls, mean %.4f' % (name, len(chain), calls[0], np.mean(chain)))
+  np.savez_compressed(os.path.join(OUT, 'slice_cases.npz'), **out)
+  print('wrote slice_cases')
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   import_reference()
   if len(sys.argv) > 1 and sys.argv[1] == 'mfgp':
     gen_mfgp_case()
+    sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'slice':
+    gen_slice_cases()
     sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'pdoo':
     gen_pdoo_cases()
@@ -344,3 +369,4 @@ if __name__ == '__main__':
   gen_c1_case()
   gen_mfgp_case()
   gen_pdoo_cases()
+  gen_slice_cases()

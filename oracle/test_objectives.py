@@ -24,3 +24,25 @@ PDOO_CASES = [
   ('ridge_d2', ridge, [[-2.0, 2.0]] * 2, 300),
   ('ridge_d4', ridge, [[-2.0, 2.0], [-1.0, 1.0], [0.0, 4.0], [-2.0, 2.0]], 700),
 ]
+
+
+def bimodal_logp(x):
+  """ An unnormalised two-bump log density with hard support [-4, 6] (-inf outside, as a bounded
+      prior gives): exercises stepping out over the support edge and long shrink chains. """
+  x = float(np.ravel(x)[0])
+  if x < -4.0 or x > 6.0:
+    return -np.inf
+  return float(np.logaddexp(-0.5 * ((x + 1.0) / 0.3) ** 2, -0.5 * ((x - 2.5) / 0.8) ** 2 - 0.7))
+
+
+def heavy_tail_logp(x):
+  """ Student-t like, unbounded support: the slice is often much wider than w. """
+  x = float(np.ravel(x)[0])
+  return float(-2.0 * np.log1p(x * x / 3.0))
+
+
+SLICE_CASES = [
+  # name, log density, start, kept samples, burn, seed
+  ('bimodal', bimodal_logp, 0.3, 200, 50, 11),
+  ('heavy_tail', heavy_tail_logp, -7.0, 300, 20, 12),
+]

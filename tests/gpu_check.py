@@ -527,7 +527,44 @@ def stage_pdoo():
   print('STAGE pdoo DONE')
 
 
-STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs', 'rng', 'pdoo']
+def stage_slice():
+  """ slice sampling of one hyper-parameter (log bandwidth) with the log marginal likelihood as density:
+      one fit per density call (the reference's pattern) vs speculative batches """
+  from dragonfly_amd.engine import Engine, KernelSpec
+  from dragonfly_amd.slice_sampler import SpeculativeSlice
+  eng = Engine()
+  d = 4
+  for n in (50, 200, 1000, 4096):
+    rs = np.random.RandomState(3)
+    X = rs.random_sample((n, d)); Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+    Xd = eng.to_device(X)
+    yc = Y - np.median(Y)
+    spec_of = lambda lb: KernelSpec('se', d, float(Y.var()), float(np.exp(lb)) * np.ones(d))
+    def one_by_one(xs):
+      out = []
+      for lb in xs:
+        gp = eng.gp_fit(spec_of(lb), Xd, yc, 0.01); out.append(gp.lml); gp.free()
+      return out
+    batched = lambda xs: eng.gp_lml_batch([spec_of(lb) for lb in xs], Xd, Y, [float(np.median(Y))] * len(xs), [0.01] * len(xs))
+    iters = 60 if n <= 1000 else 20
+    res = {}
+    for label, fn, ahead in (('one fit per call', one_by_one, (1, 1)), ('batched', batched, (3, 4))):
+      sampler = SpeculativeSlice(fn, ahead_step=ahead[0], ahead_shrink=ahead[1])
+      np.random.seed(5)
+      sampler.sample(-1.0, 3, 2)                      # warm-up
+      sampler = SpeculativeSlice(fn, ahead_step=ahead[0], ahead_shrink=ahead[1])
+      np.random.seed(5)
+      t0 = time.time(); chain = sampler.sample(-1.0, iters, 0); dt = time.time() - t0
+      res[label] = (dt / iters * 1e3, chain, sampler)
+    a, b = res['one fit per call'], res['batched']
+    print('n=%d: %.2f density values per update | one fit per value %.2f ms/update | speculative batches %.2f ms/update '
+          '(%.1f calls, %.1f values per update) | max chain difference %.1e'
+          % (n, a[2].consumed / float(iters), a[0], b[0], b[2].batches / float(iters), b[2].evaluated / float(iters),
+             float(np.max(np.abs(a[1] - b[1])))), flush=True)
+  print('STAGE slice DONE')
+
+
+STAGES = ['gemm', 'kernmat', 'chol', 'gp', 'perf', 'fit16k', 'hptune', 'append', 'configs', 'rng', 'pdoo', 'slice']
 
 if __name__ == '__main__':
   if len(sys.argv) == 3 and sys.argv[1] == '--run':

@@ -134,3 +134,72 @@ def test_additive_model_tuning_batched_and_per_candidate_agree(engine):
                 [list(g) for g in gp.kernel.groupings]))
   assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][3] == out[1][3]
   assert abs(out[0][2] - out[1][2]) <= 1e-12 * abs(out[1][2])
+
+
+def _tiny_specs(rs, d, y_var):
+  """ one candidate of every kernel structure the one-launch path handles """
+  from dragonfly_amd.engine import KernelSpec
+  bw = lambda k: np.exp(rs.uniform(np.log(0.1), np.log(3.0), size=k))
+  pairs = []
+  for kind, nu in (('se', None), ('matern', 0.5), ('matern', 1.5), ('matern', 2.5)):
+    b = bw(d)
+    pairs.append((KernelSpec(kind, d, y_var, b, nu=nu or 0.0), O.KernelSpec(kind, d, y_var, b, nu=nu)))
+  if d >= 4:
+    perm = list(rs.permutation(d))
+    groups = [perm[:d // 2], perm[d // 2:]]
+    for multi in ('additive', 'product'):
+      bws = [bw(len(g)) for g in groups]
+      kinds, nus = ['se', 'matern'], [0.0, 2.5]
+      pairs.append((KernelSpec(multi, d, 0.7 * y_var, groups=groups, sub_kinds=kinds, sub_scales=[1.0, 1.0],
+                               sub_nus=nus, sub_bandwidths=bws),
+                    O.KernelSpec(multi, d, 0.7 * y_var, groups=groups,
+                                 subs=[O.KernelSpec('se', len(groups[0]), 1.0, bws[0]),
+                                       O.KernelSpec('matern', len(groups[1]), 1.0, bws[1], nu=2.5)])))
+  return pairs
+
+
+@pytest.mark.parametrize('n,d', [(1, 1), (2, 3), (17, 2), (64, 5), (100, 32), (128, 6)])
+def test_small_problems_take_the_one_launch_path_and_match(engine, n, d):
+  """ n <= 128: pack, Gram matrix, stable_cholesky and solve of every candidate are one kernel
+      (k_lml_tiny); same numbers as the oracle and as one dfh_gp_fit per candidate """
+  rs = np.random.RandomState(1000 * n + d)
+  X = rs.rand(n, d)
+  Y = np.sin(4 * X.sum(axis=1)) + 0.1 * rs.randn(n)
+  y_var = float(Y.var()) if n > 1 else 1.0
+  pairs = _tiny_specs(rs, d, y_var) * 3
+  means = [float(rs.randn()) for _ in pairs]
+  noises = [float(np.exp(rs.uniform(np.log(0.005 * y_var), np.log(0.2 * y_var)))) for _ in pairs]
+  lml, powers = engine.gp_lml_batch([p[0] for p in pairs], X, Y, means, noises, return_powers=True)
+  for c, (spec, ospec) in enumerate(pairs):
+    ref = O.GPOracle(X, Y, ospec, means[c], noises[c]).lml()
+    tol = 1e-6 if (ospec.kind == 'matern' and ospec.nu == 0.5) else TOL     # see DESIGN.md section 2
+    assert abs(lml[c] - ref) <= tol * max(abs(ref), 1.0), (c, ospec.kind, lml[c], ref)
+    one = engine.gp_fit(spec, X, Y - means[c], noises[c])
+    assert abs(lml[c] - one.lml) <= 1e-11 * max(abs(one.lml), 1.0) and powers[c] == one.jitter_power
+    one.free()
+
+
+def test_small_problem_ladder_and_failures(engine):
+  from dragonfly_amd.engine import KernelSpec
+  rs = np.random.RandomState(5)
+  n, d = 60, 2
+  X = rs.rand(n, d)
+  X[30:] = X[:30]                                   # exact duplicates: singular without noise
+  Y = np.cos(3 * X[:, 0]) + X[:, 1]
+  bws = (0.3, 2.0, 0.5)
+  specs = [KernelSpec('se', d, 1.0, np.full(d, b)) for b in bws]
+  noises = [1e-3, 0.0, 1e-2]
+  lml, powers = engine.gp_lml_batch(specs, X, Y, None, noises, return_powers=True)
+  for c, b in enumerate(bws):
+    og = O.GPOracle(X, Y, O.KernelSpec('se', d, 1.0, np.full(d, b)), 0.0, noises[c])
+    assert og.jitter_power == powers[c]
+    tol = TOL if powers[c] is None else 1e-4
+    assert abs(lml[c] - og.lml()) <= tol * abs(og.lml())
+  assert powers[0] is None and powers[1] is not None
+  with pytest.raises(np.linalg.LinAlgError):
+    engine.gp_lml_batch(specs, X, Y, None, noises, allow_jitter=False)
+  Ynan = Y.copy()
+  Xnan = X.copy()
+  Xnan[3, 1] = np.nan                               # NaN in the Gram matrix: the ladder cannot help
+  with pytest.raises(ValueError):
+    engine.gp_lml_batch(specs[:1], Xnan, Ynan, None, noises[:1])
