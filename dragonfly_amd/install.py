@@ -35,6 +35,9 @@ edited):
                the tree search of dragonfly_amd.doo a frontier per call.  Everything else of the
                fitter (options, bounds, posterior sampling, the bandit bookkeeping) is the
                reference's code.  install(batched_tuning=False) leaves the fitter alone.
+  S4' MOO      dragonfly.opt.multiobjective_gpb_acquisitions.maximise_acquisition -> ours for
+               Euclidean domains: the multi-objective closures are maximised by the batched tree
+               search / the vectorised random search too.
 A compiled Fortran DIRECT, when present, keeps working: it calls gp.eval per point, which now
 runs on the device, through `external_maximise_with_method`.
 """
@@ -70,6 +73,16 @@ def install(multi_fidelity=False, batched_tuning=True):
       setattr(ref_ns, acq, getattr(our_ns, acq))
       patched.append('dragonfly.opt.gpb_acquisitions.%s.%s' % (ns_name, acq))
   gpb_acquisitions.external_maximise_with_method = maximise_with_method
+  # the multi-objective acquisitions (opt/multiobjective_gpb_acquisitions.py:19-107) are closures
+  # over rows of points handed to maximise_acquisition, a name they import at module level: with
+  # ours they get the batched tree search / vectorised random search on Euclidean domains
+  import dragonfly.opt.multiobjective_gpb_acquisitions as ref_moo_acq
+  ref_maximise = ref_moo_acq.maximise_acquisition
+  def _moo_maximise_acquisition(acq_fn, anc_data, *args, **kwargs):
+    if anc_data.domain.get_type() == 'euclidean':
+      return gpb_acquisitions.maximise_acquisition(acq_fn, anc_data, *args, **kwargs)
+    return ref_maximise(acq_fn, anc_data, *args, **kwargs)
+  _set(ref_moo_acq, 'maximise_acquisition', _moo_maximise_acquisition)
   if batched_tuning:
     import dragonfly.opt.gp_bandit as ref_gp_bandit
     import dragonfly.opt.multiobjective_gp_bandit as ref_moo_bandit

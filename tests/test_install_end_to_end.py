@@ -98,7 +98,7 @@ def test_reference_bandit_recommends_the_same_points_with_the_engine_installed(c
     assert np.array_equal(got, want)
 
 
-def _moo_run(acq):
+def _moo_run(acq, method='rand'):
   """ A short multi-objective run of the reference (opt/multiobjective_gp_bandit.py): two
       objectives on [0,1]^3, synthetic worker, 14 evaluations. """
   from dragonfly.opt.multiobjective_gp_bandit import multiobjective_gpb_from_multi_func_caller, \
@@ -115,7 +115,7 @@ def _moo_run(acq):
   opts.gpb_ml_hp_tune_opt = 'rand'
   opts.hp_tune_max_evals = 30
   opts.acq_opt_max_evals = 100
-  opts.acq_opt_method = 'rand'
+  opts.acq_opt_method = method
   opts.acq = acq
   np.random.seed(7)
   with warnings.catch_warnings():
@@ -126,8 +126,8 @@ def _moo_run(acq):
   return np.array(history.query_points)
 
 
-@pytest.mark.parametrize('acq', ['ts', 'ucb'])
-def test_reference_multiobjective_bandit_inherits_the_engine(acq, monkeypatch):
+@pytest.mark.parametrize('acq,method', [('ts', 'rand'), ('ucb', 'rand'), ('ucb', 'pdoo'), ('ucb', 'direct')])
+def test_reference_multiobjective_bandit_inherits_the_engine(acq, method, monkeypatch):
   """ the multi-objective acquisitions (opt/multiobjective_gpb_acquisitions.py:
       19-107) only use gp.eval / gp.draw_samples of the GPs their Euclidean fitters build through the
       rebound module global, so they run on the engine without a line of their own. """
@@ -136,14 +136,14 @@ def test_reference_multiobjective_bandit_inherits_the_engine(acq, monkeypatch):
   from oracle_engine import patch_engine
   from dragonfly_amd import install
   import dragonfly_amd.gp_core as mirror_gp
-  want = _moo_run(acq)
+  want = _moo_run(acq, method)
   patch_engine(monkeypatch)
   built = []
   orig = mirror_gp.GP.build_posterior
   monkeypatch.setattr(mirror_gp.GP, 'build_posterior', lambda self: (built.append(1), orig(self))[1])
   install.install()
   try:
-    got = _moo_run(acq)
+    got = _moo_run(acq, method)
   finally:
     install.uninstall()
   assert len(built) > 0                       # the mirror GP did the fitting
