@@ -64,10 +64,18 @@ def _is_rand_euclidean(anc_data):
          str(anc_data.acq_opt_method).lower().startswith('rand')
 
 
+def _is_device_gp(gp):
+  """ A fitted mirror GP with a device kernel.  Anything else offering eval() -- e.g. the
+      Namespace BOCA hands the acquisitions for the GP restricted to the target fidelity
+      (gpb_acquisitions.py:384-395) -- is served through its eval. """
+  from .gp_core import GP
+  return isinstance(gp, GP) and gp.num_tr_data > 0 and not gp._generic    # pylint: disable=protected-access
+
+
 def _can_fuse(gp, anc_data):
   """ The fused candidates -> posterior -> acquisition -> arg-max call needs a device kernel; GPs
       whose kernel the host evaluates take the reference's closure route (batched gp.eval). """
-  return _is_rand_euclidean(anc_data) and gp.num_tr_data > 0 and not getattr(gp, '_generic', False)
+  return _is_rand_euclidean(anc_data) and _is_device_gp(gp)
 
 
 def _fortran_direct_available():
@@ -214,8 +222,7 @@ def asy_ts(gp, anc_data):
     anc_data.max_evals *= 4
     anc_data.acq_opt_method = 'rand'
   Xh = _halluc_points(anc_data)
-  fused = Xh is None and gp.num_tr_data > 0 and anc_data.domain.get_type() == 'euclidean' and \
-          not getattr(gp, '_generic', False)
+  fused = Xh is None and anc_data.domain.get_type() == 'euclidean' and _is_device_gp(gp)
   if not fused:
     return maximise_acquisition(get_gp_sampler_for_parallel_strategy(gp, anc_data), anc_data,
                                 vectorised=True)

@@ -175,3 +175,50 @@ def test_install_without_batched_tuning_leaves_the_fitter_alone(monkeypatch):
   finally:
     install.uninstall()
   assert ref_gp_bandit.EuclideanGPFitter is ref_egp.EuclideanGPFitter
+
+
+def _mf_run():
+  """ A short multi-fidelity (BOCA) run of the reference: 1-D fidelity space, 2-D domain. """
+  from dragonfly.opt import gp_bandit
+  from dragonfly.exd.domains import EuclideanDomain
+  from dragonfly.exd.experiment_caller import EuclideanFunctionCaller
+  from dragonfly.exd.worker_manager import SyntheticWorkerManager
+  from dragonfly.utils.option_handler import load_options
+  f = lambda z, x: -float(np.sum((np.asarray(x) - 0.3) ** 2)) - \
+                   0.3 * (1 - float(np.ravel(z)[0])) * float(np.sin(5 * np.sum(x)))
+  cost = lambda z: 0.2 + 0.8 * float(np.ravel(z)[0])
+  caller = EuclideanFunctionCaller(f, EuclideanDomain([[0, 1]] * 2), vectorised=False,
+                                   raw_fidel_space=EuclideanDomain([[0, 1]]), fidel_cost_func=cost,
+                                   raw_fidel_to_opt=np.array([1.0]))
+  opts = load_options(gp_bandit.get_all_mf_euc_gp_bandit_args())
+  opts.gpb_hp_tune_criterion = 'ml'
+  opts.gpb_ml_hp_tune_opt = 'rand'
+  opts.hp_tune_max_evals = 30
+  opts.acq_opt_max_evals = 100
+  opts.acq_opt_method = 'rand'
+  np.random.seed(9)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    opt = gp_bandit.EuclideanGPBandit(caller, SyntheticWorkerManager(1, time_distro='const'), is_mf=True,
+                                      options=opts, reporter='silent')
+    _, _, history = opt.optimise(8)
+  return np.array(history.query_points), np.array(history.query_fidels), type(opt.gp).__module__
+
+
+def test_reference_multifidelity_bandit_with_the_mf_gp_installed(monkeypatch):
+  """ install(multi_fidelity=True): BOCA's GP (gp/euclidean_gp.py:347-412, built at :707) is the
+      mirror EuclideanMFGP -- coordinate-product kernel on the engine -- and the run is unchanged. """
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  want_pts, want_fidels, want_mod = _mf_run()
+  assert want_mod.startswith('dragonfly.')
+  patch_engine(monkeypatch)
+  install.install(multi_fidelity=True)
+  try:
+    got_pts, got_fidels, got_mod = _mf_run()
+  finally:
+    install.uninstall()
+  assert got_mod.startswith('dragonfly_amd.')
+  assert np.array_equal(got_pts, want_pts) and np.array_equal(got_fidels, want_fidels)
