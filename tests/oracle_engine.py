@@ -114,7 +114,8 @@ class OracleEngine(object):
     return O.dist_squared(np.asarray(X1, dtype=np.float64), np.asarray(X2, dtype=np.float64))
 
   def gemm(self, A, B, C_in=None, alpha=1.0, beta=0.0, transb=False, lower_only=False):
-    prod = alpha * np.asarray(A).dot(np.asarray(B).T if transb else np.asarray(B))
+    # the engine's convention: B is [N x K] (C = A B^T) unless transb, then B is [K x N]
+    prod = alpha * np.asarray(A).dot(np.asarray(B) if transb else np.asarray(B).T)
     return prod if C_in is None else prod + beta * C_in
 
   def cholesky(self, M):

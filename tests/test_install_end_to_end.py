@@ -222,3 +222,57 @@ def test_reference_multifidelity_bandit_with_the_mf_gp_installed(monkeypatch):
     install.uninstall()
   assert got_mod.startswith('dragonfly_amd.')
   assert np.array_equal(got_pts, want_pts) and np.array_equal(got_fidels, want_fidels)
+
+
+def _full_run(mode, num_workers, extra):
+  """ A complete (short) optimisation of the reference with several synthetic workers: in-progress
+      evaluations are hallucinated (asy) or the batch is built sequentially (syn). """
+  from dragonfly.opt import gp_bandit
+  from dragonfly.exd.domains import EuclideanDomain
+  from dragonfly.exd.experiment_caller import EuclideanFunctionCaller
+  from dragonfly.exd.worker_manager import SyntheticWorkerManager
+  from dragonfly.utils.option_handler import load_options
+  f = lambda x: -float(np.sum((np.asarray(x) - np.array([0.2, 0.7, 0.5])) ** 2)) + 0.1 * float(np.sin(9 * x[0]))
+  caller = EuclideanFunctionCaller(f, EuclideanDomain([[0, 1]] * 3), vectorised=False)
+  opts = load_options(gp_bandit.get_all_euc_gp_bandit_args())
+  opts.gpb_hp_tune_criterion = 'ml'
+  opts.gpb_ml_hp_tune_opt = 'rand'
+  opts.hp_tune_max_evals = 30
+  opts.acq_opt_max_evals = 120
+  opts.acq_opt_method = 'rand'
+  opts.mode = mode
+  for k, v in extra.items():
+    setattr(opts, k, v)
+  np.random.seed(31)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    opt = gp_bandit.EuclideanGPBandit(caller, SyntheticWorkerManager(num_workers, time_distro='const'),
+                                      options=opts, reporter='silent')
+    _, _, history = opt.optimise(18)
+  return np.array(history.query_points)
+
+
+FULL_RUNS = [
+  ('asy', 3, dict(acq='ucb')),
+  ('asy', 3, dict(acq='ei-ttei-ts')),
+  ('syn', 3, dict(acq='ei')),
+  ('syn', 2, dict(acq='ucb-add_ucb')),
+  ('asy', 2, dict(acq='ucb', use_additive_gp=True, kernel_type='se')),
+  ('asy', 1, dict(acq='pi', acq_opt_method='pdoo', acq_opt_max_evals=60)),
+]
+
+
+@pytest.mark.parametrize('mode,workers,extra', FULL_RUNS, ids=['%s%d-%s' % (m, w, e['acq']) for m, w, e in FULL_RUNS])
+def test_reference_full_runs_with_parallel_workers(mode, workers, extra, monkeypatch):
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  want = _full_run(mode, workers, extra)
+  patch_engine(monkeypatch)
+  install.install()
+  try:
+    got = _full_run(mode, workers, extra)
+  finally:
+    install.uninstall()
+  assert got.shape == want.shape and np.array_equal(got, want)
