@@ -276,3 +276,28 @@ def test_reference_full_runs_with_parallel_workers(mode, workers, extra, monkeyp
   finally:
     install.uninstall()
   assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_top_level_maximise_function_with_default_options(monkeypatch):
+  """ dragonfly.maximise_function with nothing but defaults: default kernel, acquisition mix,
+      'direct' maximisers and the ml / post_sampling tuning mix. """
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  from dragonfly import maximise_function
+  f = lambda x: -float((x[0] - 0.3) ** 2 + (x[1] + 0.2) ** 2) + 0.05 * float(np.cos(7 * x[0]))
+  def run():
+    np.random.seed(77)
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      val, pt, history = maximise_function(f, [[-1, 1], [-1, 1]], 9)
+    return val, np.array(pt), np.array(history.query_points)
+  want = run()
+  patch_engine(monkeypatch)
+  install.install()
+  try:
+    got = run()
+  finally:
+    install.uninstall()
+  assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
