@@ -43,15 +43,14 @@ class SpeculativeSlice(object):
   def _step_out(self, y, ql, qr, w):
     """ slice.py:52-63: move each edge outwards by w until the density there is below the level. """
     need_l, need_r = True, True
-    first = True
     while need_l or need_r:
       lefts, rights = [], []
       edge = ql
-      for k in range(self.ahead_step if need_l else 0):
+      for _ in range(self.ahead_step if need_l else 0):
         lefts.append(edge)
         edge = edge - w               # the reference's repeated `ql[i] -= w[i]`
       edge = qr
-      for k in range(self.ahead_step if need_r else 0):
+      for _ in range(self.ahead_step if need_r else 0):
         rights.append(edge)
         edge = edge + w
       vals = self._logp(lefts + rights)
@@ -72,7 +71,6 @@ class SpeculativeSlice(object):
           qr, need_r = rights[stop], False
         else:
           qr = rights[-1] + w
-      first = False
     return ql, qr
 
   def _shrink(self, y, q0, ql, qr):
