@@ -251,6 +251,28 @@ def main():
       },
       'device': eng.name(),
     }
+    # untimed extra: drawing this rank's candidates (oper_utils.py:62 -- np.random.random((m, d))) on
+    # the device instead of on the host + PCIe; inputs of the timed step are resident either way
+    import time as _time
+    gen = {}
+    buf = eng.empty((CANDS_PER_GPU, DIM))
+    for label, rng in (('mt19937_continuing_numpy_state', np.random.RandomState(11)),
+                       ('philox4x64', np.random.Generator(np.random.Philox(key=11)))):
+      eng.random_candidates(64, DIM, rng=rng, out=buf)
+      eng.sync()
+      t0 = _time.perf_counter()
+      eng.random_candidates(CANDS_PER_GPU, DIM, rng=rng, out=buf)
+      eng.sync()
+      gen[label + '_ms'] = round((_time.perf_counter() - t0) * 1e3, 3)
+    t0 = _time.perf_counter()
+    host_draw = np.random.RandomState(11).random_sample((CANDS_PER_GPU, DIM))
+    t1 = _time.perf_counter()
+    buf.upload(host_draw)
+    eng.sync()
+    gen['host_numpy_draw_ms'] = round((t1 - t0) * 1e3, 3)
+    gen['host_upload_ms'] = round((_time.perf_counter() - t1) * 1e3, 3)
+    buf.free()
+    out['candidate_generation_untimed_rank0'] = gen
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(X, Y, bw, mean_c, noise)
     elif not args.no_cpu_baseline:
