@@ -158,7 +158,7 @@ def _tiny_specs(rs, d, y_var):
   return pairs
 
 
-@pytest.mark.parametrize('n,d', [(1, 1), (2, 3), (17, 2), (64, 5), (100, 32), (128, 6)])
+@pytest.mark.parametrize('n,d', [(1, 1), (2, 3), (17, 2), (64, 5), (100, 32), (128, 6), (128, 64)])
 def test_small_problems_take_the_one_launch_path_and_match(engine, n, d):
   """ n <= 128: pack, Gram matrix, stable_cholesky and solve of every candidate are one kernel
       (k_lml_tiny); same numbers as the oracle and as one dfh_gp_fit per candidate """

@@ -259,10 +259,13 @@ FULL_RUNS = [
   ('syn', 2, dict(acq='ucb-add_ucb')),
   ('asy', 2, dict(acq='ucb', use_additive_gp=True, kernel_type='se')),
   ('asy', 1, dict(acq='pi', acq_opt_method='pdoo', acq_opt_max_evals=60)),
+  ('asy', 1, dict(acq='ei', use_additive_gp=True, kernel_type='matern', gpb_ml_hp_tune_opt='pdoo')),
+  ('asy', 2, dict(acq='add_ucb-ucb', gpb_ml_hp_tune_opt='direct', gpb_hp_tune_criterion='ml-post_sampling',
+                  gpb_post_hp_tune_burn=8)),
 ]
 
 
-@pytest.mark.parametrize('mode,workers,extra', FULL_RUNS, ids=['%s%d-%s' % (m, w, e['acq']) for m, w, e in FULL_RUNS])
+@pytest.mark.parametrize('mode,workers,extra', FULL_RUNS, ids=['%s%d-%s-%d' % (m, w, e['acq'], i) for i, (m, w, e) in enumerate(FULL_RUNS)])
 def test_reference_full_runs_with_parallel_workers(mode, workers, extra, monkeypatch):
   from oracle.make_golden import import_reference
   import_reference()
