@@ -70,7 +70,7 @@ def install(multi_fidelity=False, batched_tuning=True):
     our_ns = getattr(gpb_acquisitions, ns_name)
     for acq in ('ucb', 'ei', 'pi', 'ttei', 'ts', 'add_ucb'):
       _saved.append((ref_ns, acq, getattr(ref_ns, acq)))
-      setattr(ref_ns, acq, getattr(our_ns, acq))
+      setattr(ref_ns, acq, _euclidean_dispatch(getattr(our_ns, acq), getattr(ref_ns, acq)))
       patched.append('dragonfly.opt.gpb_acquisitions.%s.%s' % (ns_name, acq))
   gpb_acquisitions.external_maximise_with_method = maximise_with_method
   # the multi-objective acquisitions (opt/multiobjective_gpb_acquisitions.py:19-107) are closures
@@ -90,6 +90,23 @@ def install(multi_fidelity=False, batched_tuning=True):
     _set(ref_gp_bandit, 'EuclideanGPFitter', batched)
     _set(ref_moo_bandit, 'EuclideanGPFitter', batched)
   return patched
+
+
+def _euclidean_dispatch(ours, theirs):
+  """ The acquisition entry installed in the reference's namespaces: ours on Euclidean domains,
+      the reference's own callable on every other domain (Cartesian-product, neural-network, ...
+      domains keep running exactly as before).  Works for asy (gp, anc_data) and syn
+      (num_workers, gps, anc_datas) signatures: the ancillary data is the last argument. """
+  def acquisition(*args, **kwargs):
+    anc_data = args[-1]
+    if isinstance(anc_data, (list, tuple)):
+      anc_data = anc_data[0]
+    if anc_data.domain.get_type() == 'euclidean':
+      return ours(*args, **kwargs)
+    return theirs(*args, **kwargs)
+  acquisition.__wrapped__ = ours
+  acquisition.reference_callable = theirs
+  return acquisition
 
 
 def make_batched_fitter(ref_fitter_cls):

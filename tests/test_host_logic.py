@@ -171,7 +171,8 @@ def test_install_rebinds_reference_names():
     assert ref_egp.EuclideanMFGP is orig_mfgp              # multi-fidelity rebinding is opt-in
     assert ref_kernel.SEKernel is K.SEKernel and ref_kernel.AdditiveKernel is K.AdditiveKernel
     assert ref_egp.EuclideanGP is euclidean_gp.EuclideanGP
-    assert ref_acq.asy.ucb is gpb_acquisitions.asy_ucb and ref_acq.syn.ts is gpb_acquisitions.syn_ts
+    assert ref_acq.asy.ucb.__wrapped__ is gpb_acquisitions.asy_ucb and ref_acq.syn.ts.__wrapped__ is gpb_acquisitions.syn_ts
+    assert ref_acq.asy.ucb.reference_callable is orig_ucb      # non-Euclidean domains keep the reference's
     assert gpb_acquisitions.external_maximise_with_method is not None and len(patched) >= 20
     # the reference's kernel factory now builds device kernels
     kern, _, _ = ref_egp.get_euclidean_integral_gp_kernel_with_scale(

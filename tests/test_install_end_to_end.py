@@ -304,3 +304,35 @@ def test_top_level_maximise_function_with_default_options(monkeypatch):
   finally:
     install.uninstall()
   assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
+def test_cartesian_product_domain_runs_keep_working(monkeypatch):
+  """ install() must not break what it does not accelerate: on a Cartesian-product domain (float +
+      int + discrete variables) the acquisition entries dispatch to the reference's own callables
+      and the CP GP evaluates its Euclidean factor kernels through the mirror kernel classes. """
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  from dragonfly import maximise_function, load_config
+  config = load_config({'domain': [{'name': 'x', 'type': 'float', 'min': 0, 'max': 1, 'dim': 2},
+                                   {'name': 'k', 'type': 'int', 'min': 1, 'max': 5},
+                                   {'name': 'c', 'type': 'discrete', 'items': ['a', 'b', 'c']}]})
+  def f(p):
+    x, k, c = p
+    return -float(np.sum((np.asarray(x) - 0.4) ** 2)) - 0.1 * (k - 3) ** 2 + {'a': 0.0, 'b': 0.3, 'c': -0.2}[c]
+  def run():
+    np.random.seed(5)
+    from dragonfly.utils.reporters import get_reporter
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      val, pt, hist = maximise_function(f, config.domain, 12, config=config, reporter=get_reporter('silent'))
+    return val, str(pt), str(hist.query_points)
+  want = run()
+  patch_engine(monkeypatch)
+  install.install()
+  try:
+    got = run()
+  finally:
+    install.uninstall()
+  assert got == want
