@@ -58,6 +58,19 @@ class OracleFittedGP(object):
       return self.oracle.eval_with_hallucinated_observations(Xs, X_halluc, 'covar')
     return self.oracle.eval(np.asarray(Xs, dtype=np.float64), 'covar')
 
+  def predict_gram(self, K_cross, k_ss=None, mean_const=0.0, mean_vals=None):
+    K_cross = np.asarray(K_cross, dtype=np.float64)
+    mu = K_cross.dot(self.oracle.alpha) + (mean_const if mean_vals is None else np.asarray(mean_vals))
+    if k_ss is None:
+      return mu, None
+    V = O.solve_lower_triangular(self.oracle.L, K_cross.T)
+    return mu, np.sqrt(np.asarray(k_ss) - np.diag(V.T.dot(V)))       # gp_core.py:180-187
+
+  def predict_covar_gram(self, K_cross, K_tete):
+    K_cross = np.asarray(K_cross, dtype=np.float64)
+    V = O.solve_lower_triangular(self.oracle.L, K_cross.T)
+    return K_cross.dot(self.oracle.alpha), np.asarray(K_tete) - V.T.dot(V)
+
   def acq_argmax(self, acq, Xs, params=(0.0, 0.0), mean_const=0.0, mean_vals=None, X_halluc=None,
                  return_vals=False):
     mu, sd = self.predict(Xs, True, X_halluc)

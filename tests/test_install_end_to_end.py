@@ -336,3 +336,54 @@ def test_cartesian_product_domain_runs_keep_working(monkeypatch):
   finally:
     install.uninstall()
   assert got == want
+
+
+def _api_mf():
+  from dragonfly import maximise_multifidelity_function
+  from dragonfly.utils.reporters import get_reporter
+  f = lambda z, x: -float(np.sum((np.asarray(x) - 0.3) ** 2)) - 0.3 * (1 - float(z[0])) * float(np.sin(5 * np.sum(x)))
+  np.random.seed(3)
+  val, pt, hist = maximise_multifidelity_function(f, [[0, 1]], [[0, 1]] * 2, [1.0], lambda z: 0.2 + 0.8 * float(z[0]),
+                                                  6, reporter=get_reporter('silent'))
+  return val, str(pt), str(hist.query_points), str(hist.query_fidels)
+
+
+def _api_moo():
+  from dragonfly import multiobjective_maximise_functions
+  from dragonfly.utils.reporters import get_reporter
+  f1 = lambda x: -float(np.sum((np.asarray(x) - 0.2) ** 2))
+  f2 = lambda x: -float(np.sum((np.asarray(x) - 0.8) ** 2))
+  np.random.seed(4)
+  vals, pts, hist = multiobjective_maximise_functions([f1, f2], [[0, 1]] * 2, 9, reporter=get_reporter('silent'))
+  return str(vals), str(pts), str(hist.query_points)
+
+
+def _api_min():
+  from dragonfly import minimise_function
+  from dragonfly.utils.reporters import get_reporter
+  np.random.seed(6)
+  val, pt, hist = minimise_function(lambda x: float((x[0] - 0.3) ** 2 + np.abs(x[1])), [[-1, 1], [-1, 1]], 9,
+                                    reporter=get_reporter('silent'))
+  return val, str(pt), str(hist.query_points)
+
+
+@pytest.mark.parametrize('name,install_kwargs', [('mf', {}), ('mf', dict(multi_fidelity=True)), ('moo', {}), ('min', {})],
+                         ids=['mf', 'mf-mfgp', 'moo', 'min'])
+def test_top_level_apis_with_default_options(name, install_kwargs, monkeypatch):
+  """ dragonfly.maximise_multifidelity_function (BOCA; with and without the mirror MF GP),
+      multiobjective_maximise_functions and minimise_function, all options at their defaults. """
+  from oracle.make_golden import import_reference
+  import_reference()
+  from oracle_engine import patch_engine
+  from dragonfly_amd import install
+  run = {'mf': _api_mf, 'moo': _api_moo, 'min': _api_min}[name]
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    want = run()
+    patch_engine(monkeypatch)
+    install.install(**install_kwargs)
+    try:
+      got = run()
+    finally:
+      install.uninstall()
+  assert got == want
