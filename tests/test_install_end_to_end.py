@@ -242,13 +242,14 @@ def _full_run(mode, num_workers, extra):
   opts.acq_opt_method = 'rand'
   opts.mode = mode
   for k, v in extra.items():
-    setattr(opts, k, v)
+    if k != 'capital':
+      setattr(opts, k, v)
   np.random.seed(31)
   with warnings.catch_warnings():
     warnings.simplefilter('ignore')
     opt = gp_bandit.EuclideanGPBandit(caller, SyntheticWorkerManager(num_workers, time_distro='const'),
                                       options=opts, reporter='silent')
-    _, _, history = opt.optimise(18)
+    _, _, history = opt.optimise(extra.get('capital', 18))
   return np.array(history.query_points)
 
 
@@ -261,7 +262,7 @@ FULL_RUNS = [
   ('asy', 1, dict(acq='pi', acq_opt_method='pdoo', acq_opt_max_evals=60)),
   ('asy', 1, dict(acq='ei', use_additive_gp=True, kernel_type='matern', gpb_ml_hp_tune_opt='pdoo')),
   ('asy', 2, dict(acq='add_ucb-ucb', gpb_ml_hp_tune_opt='direct', gpb_hp_tune_criterion='ml-post_sampling',
-                  gpb_post_hp_tune_burn=8)),
+                  gpb_post_hp_tune_burn=6, capital=8)),
 ]
 
 
@@ -294,7 +295,7 @@ def test_top_level_maximise_function_with_default_options(monkeypatch):
     np.random.seed(77)
     with warnings.catch_warnings():
       warnings.simplefilter('ignore')
-      val, pt, history = maximise_function(f, [[-1, 1], [-1, 1]], 9)
+      val, pt, history = maximise_function(f, [[-1, 1], [-1, 1]], 7)
     return val, np.array(pt), np.array(history.query_points)
   want = run()
   patch_engine(monkeypatch)
@@ -326,7 +327,7 @@ def test_cartesian_product_domain_runs_keep_working(monkeypatch):
     from dragonfly.utils.reporters import get_reporter
     with warnings.catch_warnings():
       warnings.simplefilter('ignore')
-      val, pt, hist = maximise_function(f, config.domain, 12, config=config, reporter=get_reporter('silent'))
+      val, pt, hist = maximise_function(f, config.domain, 9, config=config, reporter=get_reporter('silent'))
     return val, str(pt), str(hist.query_points)
   want = run()
   patch_engine(monkeypatch)
@@ -354,7 +355,7 @@ def _api_moo():
   f1 = lambda x: -float(np.sum((np.asarray(x) - 0.2) ** 2))
   f2 = lambda x: -float(np.sum((np.asarray(x) - 0.8) ** 2))
   np.random.seed(4)
-  vals, pts, hist = multiobjective_maximise_functions([f1, f2], [[0, 1]] * 2, 9, reporter=get_reporter('silent'))
+  vals, pts, hist = multiobjective_maximise_functions([f1, f2], [[0, 1]] * 2, 6, reporter=get_reporter('silent'))
   return str(vals), str(pts), str(hist.query_points)
 
 
@@ -362,7 +363,7 @@ def _api_min():
   from dragonfly import minimise_function
   from dragonfly.utils.reporters import get_reporter
   np.random.seed(6)
-  val, pt, hist = minimise_function(lambda x: float((x[0] - 0.3) ** 2 + np.abs(x[1])), [[-1, 1], [-1, 1]], 9,
+  val, pt, hist = minimise_function(lambda x: float((x[0] - 0.3) ** 2 + np.abs(x[1])), [[-1, 1], [-1, 1]], 7,
                                     reporter=get_reporter('silent'))
   return val, str(pt), str(hist.query_points)
 
