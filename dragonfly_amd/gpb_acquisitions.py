@@ -75,7 +75,7 @@ def _is_device_gp(gp):
 def _can_fuse(gp, anc_data):
   """ The fused candidates -> posterior -> acquisition -> arg-max call needs a device kernel; GPs
       whose kernel the host evaluates take the reference's closure route (batched gp.eval). """
-  return _is_rand_euclidean(anc_data) and _is_device_gp(gp)
+  return _is_rand_euclidean(anc_data) and _is_device_gp(gp) and not getattr(anc_data, 'is_mf', False)
 
 
 def _fortran_direct_available():
@@ -133,29 +133,41 @@ class _BoxDomain(object):
     return len(self.bounds)
 
 
+def _in_progress(anc_data):
+  """ What the acquisitions hallucinate (gpb_acquisitions.py:56-64): the evaluations in progress
+      when handle_parallel == 'halluc' -- (fidelity, point) pairs in multi-fidelity runs, where the
+      GP handed in is BOCA's view at the target fidelity -- or None. """
+  if getattr(anc_data, 'handle_parallel', None) != 'halluc' or \
+     len(getattr(anc_data, 'eval_points_in_progress', [])) == 0:
+    return None
+  if getattr(anc_data, 'is_mf', False):
+    return anc_data.eval_fidel_points_in_progress
+  return anc_data.eval_points_in_progress
+
+
 def _halluc_points(anc_data):
-  """ gpb_acquisitions.py:56-64: the in-progress points when handle_parallel == 'halluc'. """
-  if getattr(anc_data, 'handle_parallel', None) == 'halluc' and \
-     len(getattr(anc_data, 'eval_points_in_progress', [])) > 0:
-    if getattr(anc_data, 'is_mf', False):
-      raise NotImplementedError('Multi-fidelity acquisitions are out of scope.')
-    return _as_2d_array(anc_data.eval_points_in_progress)
-  return None
+  """ The in-progress points as an array for the device calls (single-fidelity GPs only). """
+  pts = _in_progress(anc_data)
+  if pts is None or getattr(anc_data, 'is_mf', False):
+    return None
+  return _as_2d_array(pts)
 
 
 def _get_gp_eval_for_parallel_strategy(gp, anc_data, uncert_form='std'):
   """ gpb_acquisitions.py:43-64 """
-  Xh = _halluc_points(anc_data)
-  if Xh is not None:
-    return lambda x: gp.eval_with_hallucinated_observations(x, Xh, uncert_form=uncert_form)
+  pts = _in_progress(anc_data)
+  if pts is not None:
+    pts = pts if getattr(anc_data, 'is_mf', False) else _as_2d_array(pts)
+    return lambda x: gp.eval_with_hallucinated_observations(x, pts, uncert_form=uncert_form)
   return lambda x: gp.eval(x, uncert_form=uncert_form)
 
 
 def get_gp_sampler_for_parallel_strategy(gp, anc_data):
   """ gpb_acquisitions.py:67-87 """
-  Xh = _halluc_points(anc_data)
-  if Xh is not None:
-    return lambda x: gp.draw_samples_with_hallucinated_observations(1, x, Xh).ravel()
+  pts = _in_progress(anc_data)
+  if pts is not None:
+    pts = pts if getattr(anc_data, 'is_mf', False) else _as_2d_array(pts)
+    return lambda x: gp.draw_samples_with_hallucinated_observations(1, x, pts).ravel()
   return lambda x: gp.draw_samples(1, x).ravel()
 
 

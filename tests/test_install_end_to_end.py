@@ -177,7 +177,7 @@ def test_install_without_batched_tuning_leaves_the_fitter_alone(monkeypatch):
   assert ref_gp_bandit.EuclideanGPFitter is ref_egp.EuclideanGPFitter
 
 
-def _mf_run():
+def _mf_run(num_workers=1, acq=None):
   """ A short multi-fidelity (BOCA) run of the reference: 1-D fidelity space, 2-D domain. """
   from dragonfly.opt import gp_bandit
   from dragonfly.exd.domains import EuclideanDomain
@@ -196,31 +196,34 @@ def _mf_run():
   opts.hp_tune_max_evals = 30
   opts.acq_opt_max_evals = 100
   opts.acq_opt_method = 'rand'
+  if acq is not None:
+    opts.acq = acq
   np.random.seed(9)
   with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    opt = gp_bandit.EuclideanGPBandit(caller, SyntheticWorkerManager(1, time_distro='const'), is_mf=True,
+    opt = gp_bandit.EuclideanGPBandit(caller, SyntheticWorkerManager(num_workers, time_distro='const'), is_mf=True,
                                       options=opts, reporter='silent')
     _, _, history = opt.optimise(8)
   return np.array(history.query_points), np.array(history.query_fidels), type(opt.gp).__module__
 
 
-def test_reference_multifidelity_bandit_with_the_mf_gp_installed(monkeypatch):
+@pytest.mark.parametrize('num_workers,acq,mf_gp', [(1, None, True), (3, 'ucb-ts', True), (2, 'ei', False)])
+def test_reference_multifidelity_bandit_with_the_mf_gp_installed(num_workers, acq, mf_gp, monkeypatch):
   """ install(multi_fidelity=True): BOCA's GP (gp/euclidean_gp.py:347-412, built at :707) is the
       mirror EuclideanMFGP -- coordinate-product kernel on the engine -- and the run is unchanged. """
   from oracle.make_golden import import_reference
   import_reference()
   from oracle_engine import patch_engine
   from dragonfly_amd import install
-  want_pts, want_fidels, want_mod = _mf_run()
+  want_pts, want_fidels, want_mod = _mf_run(num_workers, acq)
   assert want_mod.startswith('dragonfly.')
   patch_engine(monkeypatch)
-  install.install(multi_fidelity=True)
+  install.install(multi_fidelity=mf_gp)
   try:
-    got_pts, got_fidels, got_mod = _mf_run()
+    got_pts, got_fidels, got_mod = _mf_run(num_workers, acq)
   finally:
     install.uninstall()
-  assert got_mod.startswith('dragonfly_amd.')
+  assert got_mod.startswith('dragonfly_amd.' if mf_gp else 'dragonfly.')
   assert np.array_equal(got_pts, want_pts) and np.array_equal(got_fidels, want_fidels)
 
 
