@@ -793,12 +793,26 @@ int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const doubl
     for (int64_t c0 = 0; c0 < n; c0 += NB) {
       const int64_t w = (n - c0 < NB) ? n - c0 : NB;
       const int64_t rest = n - c0 - w;
-      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, inv + (c0 / NB) * NB * NB, NB, 0.0,
-                       nullptr, 0, T, NB));
-      DFH_TRY(copy_matrix(ctx, T, NB, Kct + c0, ldk, m, w));
-      if (rest > 0)
-        DFH_TRY(gemm_f64(ctx, 0, m, rest, w, -1.0, T, NB, L + (c0 + w) * ldl + c0, ldl, 1.0,
-                         Kct + c0 + w, ldk, Kct + c0 + w, ldk));
+      const double* Linv = inv + (c0 / NB) * NB * NB;
+      const double* Lpanel = L + (c0 + w) * ldl + c0;
+      // (the inverse block has an exactly zero upper part, so the full K range gives the same sum)
+      // the solved block goes to T (a GEMM may not overwrite what other workgroups still read) and
+      // has to end up in place as well: the few-row update below stages T anyway and writes the
+      // copy on the side; only the last block, which has nothing to update, needs a copy launch
+      const bool skinny_update = rest > 0 && gemm_skinny_applies(m, rest, w, T, NB, Lpanel, ldl) && (ldk % 2) == 0;
+      if (gemm_skinny_applies(m, w, w, Kct + c0, ldk, Linv, NB))
+        DFH_TRY(gemm_skinny_nt(ctx, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 0.0, nullptr, 0, T, NB));
+      else
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 0.0, nullptr, 0, T, NB));
+      if (skinny_update) {
+        DFH_TRY(gemm_skinny_nt(ctx, m, rest, w, -1.0, T, NB, Lpanel, ldl, 1.0, Kct + c0 + w, ldk,
+                               Kct + c0 + w, ldk, Kct + c0, ldk));
+      } else {
+        DFH_TRY(copy_matrix(ctx, T, NB, Kct + c0, ldk, m, w));
+        if (rest > 0)
+          DFH_TRY(gemm_f64(ctx, 0, m, rest, w, -1.0, T, NB, Lpanel, ldl, 1.0, Kct + c0 + w, ldk,
+                           Kct + c0 + w, ldk));
+      }
     }
     return DFH_OK;
   }

@@ -166,6 +166,15 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
              const double* Cin, int64_t ldcin, double* Cout, int64_t ldc,
              const GemmBatch* batch = nullptr);
 
+// Few-row variant (m <= 256, K a multiple of 64, NT only): streams B once, see gemm_f64.hip.
+// Acopy (optional, 16-byte aligned rows, even ld): A is also copied there -- it must not overlap
+// anything the call reads or writes.
+bool gemm_skinny_applies(int64_t m, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                         int64_t ldb);
+int gemm_skinny_nt(dfh_ctx* ctx, int64_t m, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, const double* Cin, int64_t ldcin, double* Cout,
+                   int64_t ldc, double* Acopy = nullptr, int64_t ldacopy = 0);
+
 // Flattened kernel description.  A "part" is one SE / Matern kernel over a subset of the input
 // columns: SE and Matern kernels have one part, an additive kernel one part per group
 // (dragonfly/gp/kernel.py:484-494).  Inputs are pre-scaled once into a packed layout

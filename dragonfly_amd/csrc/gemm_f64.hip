@@ -343,7 +343,142 @@ int dispatch(dfh_ctx* ctx, GemmArgs& p, int count, bool edge) {
   return edge ? launch<false, true, WT>(ctx, p, grid) : launch<false, false, WT>(ctx, p, grid);
 }
 
+// ---------------------------------------------------------------------------------------
+// Few-row NT GEMM:  C[m x N] = beta * Cin + alpha * A[m x K] * B[N x K]^T  for m <= 256 rows.
+//
+// The posterior solve of a handful of points (single GP.eval calls, tree-search frontiers,
+// block-row appends) is a chain of such products in which B is a 512-column panel of the factor L
+// with up to n rows: the work is reading B once.  The square-tile kernel above is the wrong shape
+// for it -- a 64x64 tile per workgroup whose K loop waits for HBM every 16 columns, with 63 of 64
+// accumulator rows computing padding: 32 us per launch.  Here a wave owns 16 columns of C (16 rows
+// of B) and ALL m rows: B streams from HBM through registers exactly once, 128 contiguous bytes per
+// row and load, two K slabs in flight; A (tiny) is staged per 64-column K slab in LDS in the
+// operand order of v_mfma_f64_16x16x4; the m/16 accumulator tiles stay in registers.
+// K order inside a slab is permuted (lane group g takes columns 16t+4g..16t+4g+3) -- the same
+// permutation for A and B, so the sum is over the same products -- to make both operand loads
+// 32 contiguous bytes per lane.  A row's result depends on K and on nothing else: a point gets the
+// same value alone or inside any batch.
+// ---------------------------------------------------------------------------------------
+constexpr int SK_SLAB = 64;                 // K columns per LDS slab
+constexpr int SK_LDA = SK_SLAB + 4;         // slab row stride in LDS (doubles)
+constexpr int SK_MAX_ROWS = 256;
+
+struct SkinnyArgs {
+  const double* A; long lda;
+  const double* B; long ldb;
+  const double* Cin; long ldcin;
+  double* Cout; long ldc;
+  double* Acopy; long ldacopy;       // optional: workgroup 0 also copies A there (A is staged anyway)
+  int m, N, K;
+  double alpha, beta;
+};
+
+template <int MT>      // MT 16-row tiles of C per wave: m <= 16 * MT
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
+  extern __shared__ __attribute__((aligned(32))) double slab[];     // [16 * MT][SK_LDA]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const long j = (long)blockIdx.x * 64 + wave * 16 + l15;           // this lane's row of B / column of C
+  const long jc = j < p.N ? j : p.N - 1;                            // clamp: loads stay in bounds
+  const double* brow = p.B + jc * p.ldb + 4 * g;
+  double4_t acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  double4_t bnext[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) bnext[t] = *reinterpret_cast<const double4_t*>(brow + 16 * t);
+  const int rows = 16 * MT;
+  for (int k0 = 0; k0 < p.K; k0 += SK_SLAB) {
+    double4_t bcur[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bcur[t] = bnext[t];
+    if (k0 + SK_SLAB < p.K) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        bnext[t] = *reinterpret_cast<const double4_t*>(brow + k0 + SK_SLAB + 16 * t);
+    }
+    __syncthreads();                        // the previous slab has been consumed
+    for (int idx = tid; idx < rows * (SK_SLAB / 2); idx += 256) {
+      const int r = idx / (SK_SLAB / 2), c2 = idx - r * (SK_SLAB / 2);
+      double2_t v = (double2_t){0.0, 0.0};
+      if (r < p.m) {
+        v = *reinterpret_cast<const double2_t*>(p.A + (long)r * p.lda + k0 + 2 * c2);
+        if (p.Acopy && blockIdx.x == 0)
+          *reinterpret_cast<double2_t*>(p.Acopy + (long)r * p.ldacopy + k0 + 2 * c2) = v;
+      }
+      *reinterpret_cast<double2_t*>(slab + r * SK_LDA + 2 * c2) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int it = 0; it < MT; ++it) {
+        const double4_t a = *reinterpret_cast<const double4_t*>(slab + (it * 16 + l15) * SK_LDA + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bcur[t][r], acc[it], 0, 0, 0);
+      }
+    }
+  }
+  if (j < p.N) {
+#pragma unroll
+    for (int it = 0; it < MT; ++it) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + g + 4 * r;
+        if (i < p.m) {
+          double v = p.alpha * acc[it][r];
+          if (p.Cin) v += p.beta * p.Cin[(long)i * p.ldcin + j];
+          p.Cout[(long)i * p.ldc + j] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MT>
+int launch_skinny(dfh_ctx* ctx, const SkinnyArgs& p) {
+  hipLaunchKernelGGL(gemm_skinny_kernel<MT>, dim3((unsigned)((p.N + 63) / 64)), dim3(256),
+                     sizeof(double) * 16 * MT * SK_LDA, ctx->stream, p);
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
+
 }  // namespace
+
+bool gemm_skinny_applies(int64_t m, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                         int64_t ldb) {
+  auto aligned32 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 31) == 0; };
+  return m >= 1 && m <= SK_MAX_ROWS && N >= 1 && K >= SK_SLAB && K % SK_SLAB == 0 && (lda % 2) == 0 &&
+         (ldb % 4) == 0 && aligned32(B) && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+}
+
+int gemm_skinny_nt(dfh_ctx* ctx, int64_t m, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, const double* Cin, int64_t ldcin, double* Cout,
+                   int64_t ldc, double* Acopy, int64_t ldacopy) {
+  DFH_ARG(gemm_skinny_applies(m, N, K, A, lda, B, ldb));
+  DFH_ARG(beta == 0.0 || Cin != nullptr);
+  SkinnyArgs p;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
+  p.Cin = beta == 0.0 ? nullptr : Cin; p.ldcin = ldcin; p.Cout = Cout; p.ldc = ldc;
+  p.Acopy = Acopy; p.ldacopy = ldacopy;
+  p.m = (int)m; p.N = (int)N; p.K = (int)K; p.alpha = alpha; p.beta = beta;
+  const int tiles = (int)((m + 15) / 16);
+  static bool attr_set[DFH_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device]) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 256 * SK_LDA)));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 128 * SK_LDA)));
+    attr_set[ctx->device] = true;
+  }
+  if (tiles <= 1) return launch_skinny<1>(ctx, p);
+  if (tiles <= 2) return launch_skinny<2>(ctx, p);
+  if (tiles <= 4) return launch_skinny<4>(ctx, p);
+  if (tiles <= 8) return launch_skinny<8>(ctx, p);
+  return launch_skinny<16>(ctx, p);
+}
 
 int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double alpha,
              const double* A, int64_t lda, const double* B, int64_t ldb, double beta,

@@ -166,3 +166,31 @@ def test_no_device_memory_growth_over_repeated_calls(engine):
   engine.sync()
   free1 = engine.mem_info()[0]
   assert free0 - free1 < 8 * 2 ** 20, (free0, free1)
+
+
+@pytest.mark.parametrize('n', [1024, 1536, 1600])
+def test_few_row_posterior_is_batch_invariant_and_matches_the_wide_path(engine, n):
+  """ m <= 256 rows take the right-looking solve with the few-row GEMM (B streamed once through
+      registers); more rows the left-looking square-tile form.  Same posterior to rounding, and a
+      point gets exactly the same value alone or inside any small batch (the tree search's frontier
+      evaluation relies on it). """
+  from dragonfly_amd.engine import KernelSpec
+  from oracle import ref_numpy as O
+  rs = np.random.RandomState(n)
+  d = 5
+  X = rs.random_sample((n, d))
+  Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+  bw = 0.3 * np.sqrt(d) * np.ones(d)
+  gp = engine.gp_fit(KernelSpec('se', d, float(Y.var()), bw), X, Y - np.median(Y), float(Y.var() / 20))
+  og = O.GPOracle(X, Y, O.KernelSpec('se', d, float(Y.var()), bw), float(np.median(Y)), float(Y.var() / 20))
+  Xs = rs.random_sample((300, d))
+  mu_wide, sd_wide = gp.predict(Xs)                       # 300 rows: the wide path
+  mu_ref, sd_ref = og.eval(Xs, 'std')
+  assert relerr(mu_wide + np.median(Y), mu_ref) < 1e-10 and relerr(sd_wide, sd_ref) < 1e-10
+  for m in (1, 5, 16, 17, 100, 256):
+    mu, sd = gp.predict(Xs[:m])
+    assert relerr(mu, mu_wide[:m]) < 1e-12 and relerr(sd, sd_wide[:m]) < 1e-11
+    assert relerr(sd, sd_ref[:m]) < 1e-10
+    mu1, sd1 = gp.predict(Xs[m - 1:m])                    # the last point of the batch, alone
+    assert mu1[0] == mu[m - 1] and sd1[0] == sd[m - 1]
+  gp.free()
