@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
   double* Xp = A + (n + 1) * (n + 2) / 2;            // [n][P]
   double* Np = Xp + n * P;                           // [n][n_parts]
   __shared__ int s_fail;
+  __shared__ double s_pivot;
 
   // get_scaled_repr (kernel.py:179-181) and the squared row norms (general_utils.py:66-67)
   for (int idx = tid; idx < n * P; idx += 256) {
@@ -644,22 +645,43 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
       for (int i = 0; i < n; ++i) { const double v = A[tri(i, i)]; any_nan |= (v != v); m = v > m ? v : m; }
       max_diag = any_nan ? NAN : m;
     }
-    // right-looking Cholesky; the extra row turns into z = L^-1 (y - m) along the way
+    // Left-looking Cholesky, column by column; the extra row turns into z = L^-1 (y - m) along the
+    // way.  Column k of rows k..n is A[i][k] - sum_{j<k} L[i][j] L[k][j]: two threads per row split
+    // the dot product (rows are contiguous in the packed triangle, row k is a broadcast), nothing
+    // is stored inside the loop, and a step costs two barriers.
+    const int half = tid & 1, slot = tid >> 1;
     for (int k = 0; k < n; ++k) {
-      const double pivot = A[tri(k, k)];
-      if (!(pivot > 0.0)) {                          // not positive definite (or NaN)
+      double v[2] = {0.0, 0.0};
+      const double* rowk = A + tri(k, 0);
+      const int j0 = half ? (k + 1) / 2 : 0, j1 = half ? k : (k + 1) / 2;
+      int cnt = 0;
+      for (int i = k + slot; i <= n; i += 128, ++cnt) {
+        const double* rowi = A + tri(i, 0);
+        // four independent partial sums: the LDS loads of a whole group are in flight together
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+          s0 = fma(rowi[j], rowk[j], s0); s1 = fma(rowi[j + 1], rowk[j + 1], s1);
+          s2 = fma(rowi[j + 2], rowk[j + 2], s2); s3 = fma(rowi[j + 3], rowk[j + 3], s3);
+          s0 = fma(rowi[j + 4], rowk[j + 4], s0); s1 = fma(rowi[j + 5], rowk[j + 5], s1);
+          s2 = fma(rowi[j + 6], rowk[j + 6], s2); s3 = fma(rowi[j + 7], rowk[j + 7], s3);
+        }
+        for (; j < j1; ++j) s0 = fma(rowi[j], rowk[j], s0);
+        double sum = (s0 + s1) + (s2 + s3);
+        sum += __shfl_xor(sum, 1, 64);
+        v[cnt] = rowi[k] - sum;
+      }
+      if (slot == 0 && half == 0) s_pivot = v[0];      // row k itself
+      __syncthreads();                                 // every dot product has read row k
+      const double pivot = s_pivot;
+      if (!(pivot > 0.0)) {                            // not positive definite (or NaN): uniform
         if (tid == 0) s_fail = 1;
-        break;                                       // uniform: every thread reads the same pivot
+        break;
       }
       const double lkk = sqrt(pivot);
-      __syncthreads();                               // everyone has read the pivot
-      for (int i = k + tid; i <= n; i += 256) A[tri(i, k)] = (i == k) ? lkk : A[tri(i, k)] / lkk;
-      __syncthreads();
-      for (int i = k + 1 + ty; i <= n; i += 16) {
-        const double lik = A[tri(i, k)];
-        const int jmax = i < n ? i : n - 1;          // row n has no diagonal entry
-        for (int j = k + 1 + tx; j <= jmax; j += 16) A[tri(i, j)] -= lik * A[tri(j, k)];
-      }
+      cnt = 0;
+      for (int i = k + slot; i <= n; i += 128, ++cnt)
+        if (half == 0) A[tri(i, k)] = (i == k) ? lkk : v[cnt] / lkk;
       __syncthreads();
     }
     __syncthreads();
