@@ -645,44 +645,83 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
       for (int i = 0; i < n; ++i) { const double v = A[tri(i, i)]; any_nan |= (v != v); m = v > m ? v : m; }
       max_diag = any_nan ? NAN : m;
     }
-    // Left-looking Cholesky, column by column; the extra row turns into z = L^-1 (y - m) along the
-    // way.  Column k of rows k..n is A[i][k] - sum_{j<k} L[i][j] L[k][j]: two threads per row split
-    // the dot product (rows are contiguous in the packed triangle, row k is a broadcast), nothing
-    // is stored inside the loop, and a step costs two barriers.
+    // Left-looking Cholesky in panels of four columns; the extra row turns into z = L^-1 (y - m)
+    // along the way.  Two threads per row.  For a panel starting at k0 the bulk of the work --
+    // b[c] = sum_{j<k0} L[i][j] L[k0+c][j], c = 0..3 -- is one pass over the row: each L[i][j]
+    // (a per-lane LDS load) feeds four FMAs, the four panel rows are broadcasts; nothing is stored
+    // inside the pass.  The four columns are then finished one after the other from registers:
+    // v = A[i][k] - b[c] - sum_{c'<c} L[i][k0+c'] L[k][k0+c'], pivot, scale -- two barriers each.
     const int half = tid & 1, slot = tid >> 1;
-    for (int k = 0; k < n; ++k) {
-      double v[2] = {0.0, 0.0};
-      const double* rowk = A + tri(k, 0);
-      const int j0 = half ? (k + 1) / 2 : 0, j1 = half ? k : (k + 1) / 2;
-      int cnt = 0;
-      for (int i = k + slot; i <= n; i += 128, ++cnt) {
+    bool failed = false;
+    for (int k0 = 0; k0 < n && !failed; k0 += 4) {
+      const int width = n - k0 < 4 ? n - k0 : 4;
+      const int j0 = half ? (k0 + 1) / 2 : 0, j1 = half ? k0 : (k0 + 1) / 2;
+      const double* prow[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) prow[c] = A + tri(k0 + (c < width ? c : 0), 0);
+      // this thread's rows: i0 = k0 + slot and, only while more than 128 rows are left, i0 + 128
+      double bulk[2][4], mine[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = k0 + slot + 128 * r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bulk[r][c] = 0.0; mine[r][c] = 0.0; }
+        if (i > n) continue;
         const double* rowi = A + tri(i, 0);
-        // four independent partial sums: the LDS loads of a whole group are in flight together
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
         int j = j0;
-        for (; j + 8 <= j1; j += 8) {
-          s0 = fma(rowi[j], rowk[j], s0); s1 = fma(rowi[j + 1], rowk[j + 1], s1);
-          s2 = fma(rowi[j + 2], rowk[j + 2], s2); s3 = fma(rowi[j + 3], rowk[j + 3], s3);
-          s0 = fma(rowi[j + 4], rowk[j + 4], s0); s1 = fma(rowi[j + 5], rowk[j + 5], s1);
-          s2 = fma(rowi[j + 6], rowk[j + 6], s2); s3 = fma(rowi[j + 7], rowk[j + 7], s3);
+        for (; j + 2 <= j1; j += 2) {
+          const double x = rowi[j], y2 = rowi[j + 1];
+          s0 = fma(x, prow[0][j], s0); s1 = fma(x, prow[1][j], s1);
+          s2 = fma(x, prow[2][j], s2); s3 = fma(x, prow[3][j], s3);
+          t0 = fma(y2, prow[0][j + 1], t0); t1 = fma(y2, prow[1][j + 1], t1);
+          t2 = fma(y2, prow[2][j + 1], t2); t3 = fma(y2, prow[3][j + 1], t3);
         }
-        for (; j < j1; ++j) s0 = fma(rowi[j], rowk[j], s0);
-        double sum = (s0 + s1) + (s2 + s3);
-        sum += __shfl_xor(sum, 1, 64);
-        v[cnt] = rowi[k] - sum;
+        if (j < j1) {
+          const double x = rowi[j];
+          s0 = fma(x, prow[0][j], s0); s1 = fma(x, prow[1][j], s1);
+          s2 = fma(x, prow[2][j], s2); s3 = fma(x, prow[3][j], s3);
+        }
+        s0 += t0; s1 += t1; s2 += t2; s3 += t3;
+        bulk[r][0] = s0 + __shfl_xor(s0, 1, 64); bulk[r][1] = s1 + __shfl_xor(s1, 1, 64);
+        bulk[r][2] = s2 + __shfl_xor(s2, 1, 64); bulk[r][3] = s3 + __shfl_xor(s3, 1, 64);
       }
-      if (slot == 0 && half == 0) s_pivot = v[0];      // row k itself
-      __syncthreads();                                 // every dot product has read row k
-      const double pivot = s_pivot;
-      if (!(pivot > 0.0)) {                            // not positive definite (or NaN): uniform
-        if (tid == 0) s_fail = 1;
-        break;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c >= width || failed) continue;            // uniform
+        const int k = k0 + c;
+        const double* rowk = A + tri(k, 0);
+        double v[2] = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int i = k0 + slot + 128 * r;
+          if (i < k || i > n) continue;                // rows above this column's diagonal are done
+          double acc = A[tri(i, k)] - bulk[r][c];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+            if (cc < c) acc -= mine[r][cc] * rowk[k0 + cc];
+          v[r] = acc;
+          if (i == k && half == 0) s_pivot = acc;
+        }
+        __syncthreads();                               // the pivot is published; row k has been read
+        const double pivot = s_pivot;
+        if (!(pivot > 0.0)) {                          // not positive definite (or NaN): uniform
+          if (tid == 0) s_fail = 1;
+          failed = true;
+          continue;
+        }
+        const double lkk = sqrt(pivot);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int i = k0 + slot + 128 * r;
+          if (i < k || i > n) continue;
+          const double lik = (i == k) ? lkk : v[r] / lkk;
+          mine[r][c] = lik;
+          if (half == 0) A[tri(i, k)] = lik;
+        }
+        __syncthreads();
       }
-      const double lkk = sqrt(pivot);
-      cnt = 0;
-      for (int i = k + slot; i <= n; i += 128, ++cnt)
-        if (half == 0) A[tri(i, k)] = (i == k) ? lkk : v[cnt] / lkk;
-      __syncthreads();
     }
     __syncthreads();
     if (!s_fail) break;
