@@ -905,7 +905,8 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   std::vector<KernDev> kds((size_t)G);       // device images live in one scratch blob: nothing to free
   const double *dX = nullptr, *dy = nullptr;
   DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
-  if (n <= TINY_MAX_N) {
+  static const bool tiny_enabled = []() { const char* e = getenv("DFH_LML_TINY"); return e ? atoi(e) != 0 : true; }();
+  if (tiny_enabled && n <= TINY_MAX_N) {
     // small problems: pack, Gram matrix, stable_cholesky and the solve of every candidate in ONE
     // launch (kernmat.hip: k_lml_tiny)
     std::vector<KernDev> all((size_t)nb);
