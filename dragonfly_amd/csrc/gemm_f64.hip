@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
   extern __shared__ __attribute__((aligned(32))) double slab[];     // [16 * MT][SK_LDA]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
+  const int m = p.m;
   const long j = (long)blockIdx.x * 64 + wave * 16 + l15;           // this lane's row of B / column of C
   const long jc = j < p.N ? j : p.N - 1;                            // clamp: loads stay in bounds
   const double* brow = p.B + jc * p.ldb + 4 * g;
@@ -388,26 +389,46 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
   double4_t bnext[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) bnext[t] = *reinterpret_cast<const double4_t*>(brow + 16 * t);
-  const int rows = 16 * MT;
+  // A slab: 16 * MT rows x 64 columns = 2 * MT double2 per thread, prefetched like B so that no
+  // iteration waits for a global load it has just issued
+  // (the 256-row variant has no registers left for it and stages A straight from global memory)
+  constexpr bool PREFETCH_A = MT <= 8;
+  constexpr int AREGS = 2 * MT;
+  double2_t anext[PREFETCH_A ? AREGS : 1];
+  auto load_a = [&](int k0) {
+    if (!PREFETCH_A) return;
+#pragma unroll
+    for (int q = 0; q < AREGS; ++q) {
+      const int idx = tid + 256 * q, r = idx / (SK_SLAB / 2), c2 = idx - r * (SK_SLAB / 2);
+      anext[PREFETCH_A ? q : 0] = (double2_t){0.0, 0.0};
+      if (r < m) anext[PREFETCH_A ? q : 0] = *reinterpret_cast<const double2_t*>(p.A + (long)r * p.lda + k0 + 2 * c2);
+    }
+  };
+  load_a(0);
   for (int k0 = 0; k0 < p.K; k0 += SK_SLAB) {
     double4_t bcur[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bcur[t] = bnext[t];
+    __syncthreads();                        // the previous slab has been consumed
+#pragma unroll
+    for (int q = 0; q < AREGS; ++q) {
+      const int idx = tid + 256 * q, r = idx / (SK_SLAB / 2), c2 = idx - r * (SK_SLAB / 2);
+      double2_t v;
+      if (PREFETCH_A) {
+        v = anext[PREFETCH_A ? q : 0];
+      } else {
+        v = (double2_t){0.0, 0.0};
+        if (r < m) v = *reinterpret_cast<const double2_t*>(p.A + (long)r * p.lda + k0 + 2 * c2);
+      }
+      *reinterpret_cast<double2_t*>(slab + r * SK_LDA + 2 * c2) = v;
+      if (p.Acopy && blockIdx.x == 0 && r < m)
+        *reinterpret_cast<double2_t*>(p.Acopy + (long)r * p.ldacopy + k0 + 2 * c2) = v;
+    }
     if (k0 + SK_SLAB < p.K) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         bnext[t] = *reinterpret_cast<const double4_t*>(brow + k0 + SK_SLAB + 16 * t);
-    }
-    __syncthreads();                        // the previous slab has been consumed
-    for (int idx = tid; idx < rows * (SK_SLAB / 2); idx += 256) {
-      const int r = idx / (SK_SLAB / 2), c2 = idx - r * (SK_SLAB / 2);
-      double2_t v = (double2_t){0.0, 0.0};
-      if (r < p.m) {
-        v = *reinterpret_cast<const double2_t*>(p.A + (long)r * p.lda + k0 + 2 * c2);
-        if (p.Acopy && blockIdx.x == 0)
-          *reinterpret_cast<double2_t*>(p.Acopy + (long)r * p.ldacopy + k0 + 2 * c2) = v;
-      }
-      *reinterpret_cast<double2_t*>(slab + r * SK_LDA + 2 * c2) = v;
+      load_a(k0 + SK_SLAB);
     }
     __syncthreads();
 #pragma unroll
@@ -427,7 +448,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = it * 16 + g + 4 * r;
-        if (i < p.m) {
+        if (i < m) {
           double v = p.alpha * acc[it][r];
           if (p.Cin) v += p.beta * p.Cin[(long)i * p.ldcin + j];
           p.Cout[(long)i * p.ldc + j] = v;
