@@ -575,7 +575,10 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
   // kernel image sections (blob_layout): parts | bw | cols | lcols
   const size_t off_bw = (sizeof(PartDev) * n_parts + 15) & ~size_t(15);
   const size_t off_cols = off_bw + ((sizeof(double) * (P ? P : 1) + 15) & ~size_t(15));
-  const PartDev* parts = reinterpret_cast<const PartDev*>(image);
+  const PartDev* parts_g = reinterpret_cast<const PartDev*>(image);
+  __shared__ PartDev parts[TINY_MAX_PARTS];          // the Gram loop reads them per entry: keep them off the global-load path
+  for (int q = tid; q < n_parts * (int)(sizeof(PartDev) / sizeof(int)); q += 256)
+    reinterpret_cast<int*>(parts)[q] = reinterpret_cast<const int*>(parts_g)[q];
   const double* bw = reinterpret_cast<const double*>(image + off_bw);
   const int* cols = reinterpret_cast<const int*>(image + off_cols);
   const double* y = reinterpret_cast<const double*>(a.blob + a.y_off);
@@ -810,7 +813,7 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   static bool attr_set[DFH_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device]) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lml_tiny), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 256));
+                                160 * 1024 - 4096));      // static LDS (kernel parts, flags) takes ~2 KB
     attr_set[ctx->device] = true;
   }
   hipLaunchKernelGGL(k_lml_tiny, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
