@@ -62,6 +62,7 @@ struct dfh_ctx {
   std::vector<DevBuf> scratch;
   int64_t* d_info = nullptr;                         // device int64[CHOL_MAX_BATCH + 8]: pivot flag per batch matrix, then debug words
   int64_t* h_info = nullptr;                         // pinned mirror
+  void* h_stage = nullptr; size_t h_stage_bytes = 0; // pinned, grow-only: small per-call blobs and results
   // section timing
   bool timing = false;
   double t_ms[DFH_T_COUNT] = {0};
@@ -121,6 +122,9 @@ enum ScratchSlot {
 // reused block is never still being written by an earlier launch.
 int dev_alloc(dfh_ctx* ctx, size_t bytes, void** out);
 void dev_release(dfh_ctx* ctx, void* p);      // ctx may be null / already destroyed: plain hipFree
+
+// pinned host staging memory of at least `bytes` (contents undefined; valid until the next call)
+int pinned_get(dfh_ctx* ctx, size_t bytes, void** out);
 
 // returns a device pointer with at least `bytes` capacity (contents undefined)
 int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out);

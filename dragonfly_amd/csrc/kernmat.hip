@@ -783,8 +783,15 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   at += sizeof(double) * (size_t)n;
   const size_t pow_off = at;
   at += sizeof(double) * 16;
-  std::vector<char> host(at, 0);
-  TinyCand* cands = reinterpret_cast<TinyCand*>(host.data());
+  // blob and results go through pinned staging memory: two asynchronous copies and one
+  // synchronisation per call instead of two staged, blocking ones
+  const size_t res_off = (at + 63) & ~size_t(63);
+  void* pinned = nullptr;
+  DFH_TRY(pinned_get(ctx, res_off + sizeof(double) * 4 * (size_t)count, &pinned));
+  char* host_blob = static_cast<char*>(pinned);
+  std::memset(host_blob, 0, at);
+  double* res = reinterpret_cast<double*>(host_blob + res_off);
+  TinyCand* cands = reinterpret_cast<TinyCand*>(host_blob);
   for (int c = 0; c < count; ++c) {
     cands[c].image = (long)image_off[c];
     cands[c].P = kds[c].P; cands[c].n_parts = kds[c].n_parts;
@@ -792,16 +799,16 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
     cands[c].outer = kds[c].outer_scale;
     cands[c].noise = noise_vars[c];
     cands[c].mean = mean_consts ? mean_consts[c] : 0.0;
-    blob_fill(kds[c], host.data() + image_off[c]);
+    blob_fill(kds[c], host_blob + image_off[c]);
   }
-  std::memcpy(host.data() + y_off, y_host, sizeof(double) * (size_t)n);
-  double* pw = reinterpret_cast<double*>(host.data() + pow_off);
+  std::memcpy(host_blob + y_off, y_host, sizeof(double) * (size_t)n);
+  double* pw = reinterpret_cast<double*>(host_blob + pow_off);
   for (int p = -11; p < 5; ++p) pw[p + 11] = pow(10.0, (double)p);      // 10 ** diag_noise_power
   void* d_blob = nullptr;
   double* d_out = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_AUG2, at, &d_blob));
   DFH_TRY(scratch_get(ctx, SCR_OUT2, sizeof(double) * 4 * (size_t)count, (void**)&d_out));
-  DFH_HIP(hipMemcpyAsync(d_blob, host.data(), at, hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(d_blob, host_blob, at, hipMemcpyHostToDevice, ctx->stream));
   TinyArgs a;
   a.ec = kExpConsts;
   a.X = dX; a.ldx = ldx;
@@ -818,8 +825,7 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   }
   hipLaunchKernelGGL(k_lml_tiny, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
   DFH_LAUNCH_CHECK();
-  std::vector<double> res((size_t)count * 4);
-  DFH_HIP(hipMemcpyAsync(res.data(), d_out, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream));
+  DFH_HIP(hipMemcpyAsync(res, d_out, sizeof(double) * 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
   DFH_HIP(hipStreamSynchronize(ctx->stream));
   for (int c = 0; c < count; ++c) {
     const int status = (int)res[4 * c + 3];

@@ -104,6 +104,7 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   for (auto& b : ctx->pool_idle) (void)hipFree(b.p);     // blocks still held by live GPs stay theirs
   if (ctx->d_info) (void)hipFree(ctx->d_info);
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   for (int i = 0; i < DFH_T_COUNT; ++i) {
@@ -141,6 +142,18 @@ extern "C" int dfh_sync(dfh_ctx* ctx) {
 extern "C" int dfh_device_name(dfh_ctx* ctx, char* buf, size_t buflen) {
   DFH_ARG(ctx && buf && buflen > 0);
   snprintf(buf, buflen, "%s", ctx->name);
+  return DFH_OK;
+}
+
+int pinned_get(dfh_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->h_stage_bytes) {
+    if (ctx->h_stage) { DFH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+    size_t cap = 1 << 16;
+    while (cap < bytes) cap <<= 1;
+    DFH_HIP(hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+    ctx->h_stage_bytes = cap;
+  }
+  *out = ctx->h_stage;
   return DFH_OK;
 }
 
