@@ -373,18 +373,24 @@ struct SkinnyArgs {
   double alpha, beta;
 };
 
-template <int MT>      // MT 16-row tiles of C per wave: m <= 16 * MT
+// SPLIT: narrow C (the 512-column block solve: only eight 64-column workgroups' worth of work) --
+// a workgroup then owns 16 columns and its four waves split the row tiles, four times as many
+// workgroups each a quarter as long.
+template <int MT, bool SPLIT>      // MT 16-row tiles of C per workgroup: m <= 16 * MT
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
   extern __shared__ __attribute__((aligned(32))) double slab[];     // [16 * MT][SK_LDA]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int m = p.m;
-  const long j = (long)blockIdx.x * 64 + wave * 16 + l15;           // this lane's row of B / column of C
+  constexpr int MTW = SPLIT ? MT / 4 : MT;                          // row tiles of this wave
+  const int tile0 = SPLIT ? wave * MTW : 0;
+  const long j = SPLIT ? (long)blockIdx.x * 16 + l15                 // this lane's row of B / column of C
+                       : (long)blockIdx.x * 64 + wave * 16 + l15;
   const long jc = j < p.N ? j : p.N - 1;                            // clamp: loads stay in bounds
   const double* brow = p.B + jc * p.ldb + 4 * g;
-  double4_t acc[MT];
+  double4_t acc[MTW];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < MTW; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   double4_t bnext[4];
 #pragma unroll
@@ -434,8 +440,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int it = 0; it < MT; ++it) {
-        const double4_t a = *reinterpret_cast<const double4_t*>(slab + (it * 16 + l15) * SK_LDA + 16 * t + 4 * g);
+      for (int it = 0; it < MTW; ++it) {
+        const double4_t a = *reinterpret_cast<const double4_t*>(slab + ((tile0 + it) * 16 + l15) * SK_LDA + 16 * t + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bcur[t][r], acc[it], 0, 0, 0);
@@ -444,10 +450,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
   }
   if (j < p.N) {
 #pragma unroll
-    for (int it = 0; it < MT; ++it) {
+    for (int it = 0; it < MTW; ++it) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = it * 16 + g + 4 * r;
+        const int i = (tile0 + it) * 16 + g + 4 * r;
         if (i < m) {
           double v = p.alpha * acc[it][r];
           if (p.Cin) v += p.beta * p.Cin[(long)i * p.ldcin + j];
@@ -458,9 +464,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
   }
 }
 
-template <int MT>
+template <int MT, bool SPLIT>
 int launch_skinny(dfh_ctx* ctx, const SkinnyArgs& p) {
-  hipLaunchKernelGGL(gemm_skinny_kernel<MT>, dim3((unsigned)((p.N + 63) / 64)), dim3(256),
+  const int cols = SPLIT ? 16 : 64;
+  hipLaunchKernelGGL((gemm_skinny_kernel<MT, SPLIT>), dim3((unsigned)((p.N + cols - 1) / cols)), dim3(256),
                      sizeof(double) * 16 * MT * SK_LDA, ctx->stream, p);
   DFH_LAUNCH_CHECK();
   return DFH_OK;
@@ -488,17 +495,24 @@ int gemm_skinny_nt(dfh_ctx* ctx, int64_t m, int64_t N, int64_t K, double alpha, 
   const int tiles = (int)((m + 15) / 16);
   static bool attr_set[DFH_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device]) {
-    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 256 * SK_LDA)));
-    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 128 * SK_LDA)));
+    const int big = (int)(sizeof(double) * 256 * SK_LDA), mid = (int)(sizeof(double) * 128 * SK_LDA);
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<16, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<16, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, mid));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, mid));
     attr_set[ctx->device] = true;
   }
-  if (tiles <= 1) return launch_skinny<1>(ctx, p);
-  if (tiles <= 2) return launch_skinny<2>(ctx, p);
-  if (tiles <= 4) return launch_skinny<4>(ctx, p);
-  if (tiles <= 8) return launch_skinny<8>(ctx, p);
-  return launch_skinny<16>(ctx, p);
+  // few columns and several row tiles: split the rows over the waves instead of the columns
+  const bool split = tiles > 2 && (N + 63) / 64 <= ctx->n_cu / 8;
+  if (tiles <= 1) return launch_skinny<1, false>(ctx, p);
+  if (tiles <= 2) return launch_skinny<2, false>(ctx, p);
+  if (tiles <= 4) return split ? launch_skinny<4, true>(ctx, p) : launch_skinny<4, false>(ctx, p);
+  if (tiles <= 8) return split ? launch_skinny<8, true>(ctx, p) : launch_skinny<8, false>(ctx, p);
+  return split ? launch_skinny<16, true>(ctx, p) : launch_skinny<16, false>(ctx, p);
 }
 
 int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double alpha,
