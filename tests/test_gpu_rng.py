@@ -145,3 +145,21 @@ def test_row_shards_tile_the_full_draw_and_leave_the_same_state(engine, kind):
     assert np.array_equal(np.concatenate(parts), full)
   with pytest.raises(ValueError):
     engine.random_candidates(10, 2, rows=(5, 6))
+
+
+def test_c_abi_argument_checks(engine):
+  """ bad generator positions / row windows / dimensions are DFH_ERR_BAD_ARG (-> ValueError), not
+      memory errors """
+  import ctypes as C
+  from dragonfly_amd._lib import check
+  key = np.zeros(624, dtype=np.uint32)
+  out = np.empty(8)
+  ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+  for pos, m, d, r0, rc in ((625, 4, 2, 0, 4), (-1, 4, 2, 0, 4), (0, 4, 0, 0, 4), (0, 4, 2, 3, 2), (0, 4, 2, -1, 1)):
+    p = C.c_int32(pos)
+    with pytest.raises(ValueError):
+      check(engine.lib.dfh_rand_mt19937_uniform(engine.ctx, ptr(key), C.byref(p), m, d, r0, rc, None, ptr(out)))
+  pk = np.zeros(2, dtype=np.uint64); ctr = np.zeros(4, dtype=np.uint64); held = np.zeros(4, dtype=np.uint64)
+  bp = C.c_int32(5)
+  with pytest.raises(ValueError):
+    check(engine.lib.dfh_rand_philox_uniform(engine.ctx, ptr(pk), ptr(ctr), ptr(held), C.byref(bp), 4, 2, 0, 4, None, ptr(out)))
