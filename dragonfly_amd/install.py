@@ -21,9 +21,10 @@ edited):
                constructs its GP through this module global (dragonfly/gp/euclidean_gp.py:707).
                Opt-in because the reference class cannot be reached once the name is rebound (its
                __init__ calls super(EuclideanMFGP, self)).
-  S4 acquisitions  the fused callables are written into the namespaces
+  S4 acquisitions  dispatchers are written into the namespaces
                dragonfly.opt.gpb_acquisitions.asy / syn / seq (looked up with getattr at
-               dragonfly/opt/gp_bandit.py:490,510,651,681)
+               dragonfly/opt/gp_bandit.py:490,510,651,681): the fused callables on Euclidean
+               domains, the reference's own callables on every other domain
   S3 fitter    dragonfly.opt.gp_bandit.EuclideanGPFitter and
                dragonfly.opt.multiobjective_gp_bandit.EuclideanGPFitter (the names the bandits
                construct their fitters by, gp_bandit.py:22,584; multiobjective_gp_bandit.py:27,481)
@@ -32,8 +33,10 @@ edited):
                out, one dfh_gp_lml_batch call) instead of one fit per callback.  'rand' and
                'rand_exp_sampling' evaluate their whole sample in one call, 'pdoo' -- and 'direct'
                without the Fortran library, the reference's own fall-back and its default -- run
-               the tree search of dragonfly_amd.doo a frontier per call.  Everything else of the
-               fitter (options, bounds, posterior sampling, the bandit bookkeeping) is the
+               the tree search of dragonfly_amd.doo a frontier per call, and the slice sampler of
+               the posterior-sampling criterion evaluates its loops' next candidates a batch at
+               a time (dragonfly_amd.slice_sampler: the same chain, draw for draw).  Everything
+               else of the fitter (options, bounds, priors, the bandit bookkeeping) is the
                reference's code.  install(batched_tuning=False) leaves the fitter alone.
   S4' MOO      dragonfly.opt.multiobjective_gpb_acquisitions.maximise_acquisition -> ours for
                Euclidean domains: the multi-objective closures are maximised by the batched tree
