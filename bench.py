@@ -1,22 +1,30 @@
 """bench.py -- GP-fit + acquisition-batch time at n = 16384, d = 32 on N MI355X GPUs.
 
-    python bench.py [--gpus N --steps K --warmup W]                      (N = 1)
+    python bench.py [--gpus N --steps K --warmup W]
+        ONE process drives N devices through libdfhip.so's in-library fan-out (dfh_mgpu_*: a
+        context + host thread per device, RCCL communicator clique) -- no launcher, no PyTorch.
+        Fails loudly if fewer than N GPUs are visible.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        one process per GPU (the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE); the ranks
+        form an RCCL communicator through dfh_comm_* (unique id passed through a file), again
+        without PyTorch in the processes.  WORLD_SIZE must equal --gpus.
 
 One "step" = one pass of Dragonfly's GP hot path over one batch of synthetic input, everything
 already resident in HBM when the timed region starts:
     fit   : kernel matrix K(X,X) (SE-ARD) -> K + noise I -> blocked Cholesky -> alpha -> lml
             (GP.build_posterior + compute_log_marginal_likelihood, BASELINE config 3)
     batch : blocked-joint Thompson sampling (block 4096) over this rank's 262144 candidates and the
-            arg-max of the draw (asy_ts, BASELINE config 4: 2 097 152 candidates over 8 GPUs)
+            arg-max of the draw (asy_ts, BASELINE config 4: 2 097 152 candidates over 8 GPUs);
+            rank r holds rows [r*262144, (r+1)*262144) of the ONE seed-204 candidate set
 Weak scaling: per-GPU candidates are fixed; every rank fits the (replicated) GP -- the n = 16384
-fit does not shard profitably -- and the only exchange is the all-gather of
-one (value, index) pair per rank over RCCL.  `value` is the step time in ms (max over ranks).
+fit does not shard profitably -- and the only exchange is the RCCL
+all-gather of one (value, index) pair per rank.  `value` is the step time in ms (max over ranks).
 
-Also reported: `roofline` for the dominant kernel (the fp64 MFMA GEMM behind Cholesky SYRK/TRSM,
-posterior TRSM and TS SYRK) from per-launch HIP events recorded on the launch streams, and
-`cpu_baseline`: the NumPy oracle (a port of the reference's CPU path) timed on this host's cores
-on a bounded sample of the same workload and scaled by algorithmic work.
+Also on the JSON line: `roofline` for the dominant kernel (the fp64 MFMA GEMM behind Cholesky
+SYRK/TRSM, posterior TRSM and TS SYRK) from per-launch HIP events recorded on the launch streams;
+`cpu_baseline`: the NumPy oracle (a port of the reference's CPU path) timed on this host's cores --
+the full n = 16384 fit and three full Thompson blocks; `parity_vs_oracle`: the device results of
+the same inputs against that oracle run; `configs`: BASELINE configs 2 and 5, untimed extras.
 """
 import argparse
 import json
@@ -30,98 +38,307 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-N_TRAIN, DIM, TS_BLOCK = 16384, 32, 4096
-CANDS_PER_GPU = 262144
+import bench_configs as BC      # noqa: E402  pylint: disable=wrong-import-position
+
+N_TRAIN, DIM, TS_BLOCK, CANDS_PER_GPU = BC.N_TRAIN, BC.DIM, BC.TS_BLOCK, BC.CANDS_PER_GPU
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak: 256 CU x 128 flop/clk x 2.4 GHz
+HBM_PEAK_TBS = 8.0
+PMC_TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
-def make_problem(rank):
-  """ X ~ U[0,1)^32 (seed 103), Y = sum_j j/d x_j^2 + noise,
-      SE-ARD bandwidths 0.2 sqrt(32) (0.5 + j/32), mean = median(Y), noise = Var(Y)/20; candidates
-      seed 204 (+rank: each rank owns its contiguous shard), normals seed 304 (+rank). """
-  rs = np.random.RandomState(103)
-  X = rs.random_sample((N_TRAIN, DIM))
-  w = (np.arange(DIM) + 1.0) / DIM
-  Y = (X ** 2).dot(w) + 0.01 * rs.randn(N_TRAIN)
-  bw = 0.2 * np.sqrt(DIM) * (0.5 + np.arange(DIM) / 32.0)
-  mean_c = float(np.median(Y))
-  noise = float(Y.var() / 20)
-  cands = np.random.RandomState(204 + rank).random_sample((CANDS_PER_GPU, DIM))
-  U = np.random.RandomState(304 + rank).standard_normal(CANDS_PER_GPU)
-  return X, Y, bw, mean_c, noise, cands, U
+def rel(a, b):
+  a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+  den = float(np.max(np.abs(b))) if b.size else 1.0
+  return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
 
 
-def cpu_baseline(X, Y, bw, mean_c, noise, budget_note=True):
-  """ The oracle (NumPy/SciPy restatement of the reference path) on a bounded sample, all host
-      cores through OpenBLAS: fit at n_s = 12288 and one full Thompson block of 4096 candidates
-      (about 10-20 s of CPU work), each
-      stage scaled to the full step by its algorithmic work (SURVEY.md section 8d formulas). """
-  from oracle import ref_numpy as O
-  n_s, b_s = 12288, 4096
-  Xs, Ys = X[:n_s], Y[:n_s]
-  kern = O.KernelSpec('se', DIM, float(Y.var()), bw)
-  t = {}
-  t0 = time.perf_counter()
-  K = kern(Xs, Xs)
-  t['kernel'] = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  L = O.stable_cholesky(K + noise * np.eye(n_s))
-  t['chol'] = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  yc = Ys - mean_c
-  alpha = O.solve_upper_triangular(L.T, O.solve_lower_triangular(L, yc))
-  _ = -0.5 * yc.dot(alpha) - np.log(np.diag(L)).sum()
-  t['solve'] = time.perf_counter() - t0
-  Xc = np.random.RandomState(1).random_sample((b_s, DIM))
-  t0 = time.perf_counter()
-  K_tetr = kern(Xc, Xs)
-  mu = mean_c + K_tetr.dot(alpha)
-  K_tete = kern(Xc, Xc)
-  t['cross'] = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  V = O.solve_lower_triangular(L, K_tetr.T)
-  t['trsm'] = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  cov = K_tete - V.T.dot(V)
-  t['syrk'] = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  Lc = O.stable_cholesky(cov)
-  s = Lc.dot(np.random.RandomState(2).standard_normal((b_s, 1))).T + mu
-  _ = s.argmax()
-  t['blockchol'] = time.perf_counter() - t0
-  r_n = N_TRAIN / float(n_s)
-  r_b = TS_BLOCK / float(b_s)
-  fit_full = t['kernel'] * r_n ** 2 + t['chol'] * r_n ** 3 + t['solve'] * r_n ** 2
-  block_full = (t['cross'] * r_n * r_b + t['trsm'] * r_n ** 2 * r_b + t['syrk'] * r_n * r_b ** 2 +
-                t['blockchol'] * r_b ** 3)
-  n_blocks = CANDS_PER_GPU // TS_BLOCK
-  full_ms = (fit_full + n_blocks * block_full) * 1e3
+# ---- the two ways to run N GPUs --------------------------------------------------------------
+class InProcess(object):
+  """ one process, N devices: parallel.MultiEngine (dfh_mgpu_*) """
+  mode = 'one process, in-library fan-out (dfh_mgpu_*: host thread + context per device, ncclCommInitAll)'
+
+  def __init__(self, n_gpus, prob, spec):
+    from dragonfly_amd import parallel
+    self.world, self.rank = n_gpus, 0
+    self.mg = parallel.MultiEngine(n_gpus)        # raises if fewer GPUs are visible
+    self.eng0 = self.mg.engines[0]
+    self.spec, self.prob = spec, prob
+    self.Xd = [e.to_device(prob['X']) for e in self.mg.engines]
+    self.yd = [e.to_device(prob['Y'] - prob['mean_c']) for e in self.mg.engines]
+    self.cd, self.ud = [], []
+    for r, e in enumerate(self.mg.engines):
+      cands, U = BC.config4_shard(r)
+      if r == 0:
+        self.cands0, self.U0 = cands, U
+      self.cd.append(e.to_device(cands))
+      self.ud.append(e.to_device(U))
+    self.result = {}
+
+  def step(self):
+    lml = self.mg.fit(self.spec, self.Xd, self.yd, self.prob['noise'])
+    v, i = self.mg.thompson(self.cd, self.ud, block=TS_BLOCK, mean_const=self.prob['mean_c'])
+    self.result.update(lml=lml[0], best=v, idx=i)
+
+  def sync(self):
+    self.mg.sync()
+
+  def max_over_ranks(self, x):
+    return x
+
+  def close(self):
+    self.mg.free_fit()
+    self.mg.close()
+
+
+class PerProcess(object):
+  """ one process per GPU (launcher): Engine + parallel.RcclComm (dfh_comm_*) """
+  mode = 'one process per GPU (launcher env), dfh_comm_*: ncclGetUniqueId by file rendezvous, ncclCommInitRank'
+
+  def __init__(self, n_gpus, prob, spec):
+    from dragonfly_amd import parallel
+    from dragonfly_amd.engine import Engine
+    self.world = n_gpus
+    self.rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
+    self.eng0 = Engine(local_rank)
+    self.comm = parallel.RcclComm.from_env(self.eng0)
+    self.spec, self.prob = spec, prob
+    self.Xd = self.eng0.to_device(prob['X'])
+    self.yd = self.eng0.to_device(prob['Y'] - prob['mean_c'])
+    self.cands0, self.U0 = BC.config4_shard(self.rank)
+    self.cd, self.ud = self.eng0.to_device(self.cands0), self.eng0.to_device(self.U0)
+    self.result = {}
+
+  def step(self):
+    gp = self.eng0.gp_fit(self.spec, self.Xd, self.yd, self.prob['noise'])
+    v, i = gp.thompson(self.cd, self.ud, block=TS_BLOCK, mean_const=self.prob['mean_c'])
+    v, i = self.comm.allgather_argmax(v, i + self.rank * CANDS_PER_GPU)
+    self.result.update(lml=gp.lml, best=v, idx=i)
+    gp.free()
+
+  def sync(self):
+    self.eng0.sync()
+    self.comm.barrier()
+
+  def max_over_ranks(self, x):
+    return float(self.comm.allreduce_max([x])[0])
+
+  def close(self):
+    self.comm.barrier()
+    self.comm.close()
+
+
+# ---- CPU baseline + parity ---------------------------------------------------------------------
+def _blas_threads():
   try:
     import threadpoolctl
-    threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] + [1])
+    return max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] + [1])
   except Exception:    # pylint: disable=broad-except
-    threads = os.cpu_count()
-  return {
-    'value': round(full_ms, 1), 'unit': 'ms', 'cores': int(threads), 'kind': 'port',
-    'sample': ('oracle/ref_numpy.py (NumPy %s) fit at n=%d + one TS block of %d candidates, '
-               'measured %.1f s; each stage scaled to n=%d, block=%d, %d blocks by its algorithmic '
-               'work (n^2 kernel, n^3 chol, n^2 b trsm, n b^2 syrk, b^3 block chol)'
-               % (np.__version__, n_s, b_s, sum(t.values()), N_TRAIN, TS_BLOCK, n_blocks)),
-    'measured_sample_s': {k: round(v, 3) for k, v in t.items()},
-    'host_cpus': os.cpu_count(),
+    return os.cpu_count()
+
+
+def oracle_stages(O, kern, X, Y, mean_c, noise, cand_blocks, U_blocks):
+  """ The oracle (oracle/ref_numpy.py: the reference's NumPy/SciPy path restated) stage by stage:
+      the fit, then per Thompson block cross matrices / triangular solve / covariance / block
+      factorisation + draw.  Returns (timings, results). """
+  t, out = {}, {}
+  n = len(X)
+  t0 = time.perf_counter()
+  K = kern(X, X)                                                   # gp_core.py:157
+  t['kernel'] = time.perf_counter() - t0
+  t0 = time.perf_counter()
+  L, power = O.stable_cholesky(K + noise * np.eye(n), return_power=True)     # gp_core.py:843
+  del K
+  t['chol'] = time.perf_counter() - t0
+  t0 = time.perf_counter()
+  yc = Y - mean_c
+  alpha = O.solve_upper_triangular(L.T, O.solve_lower_triangular(L, yc))     # gp_core.py:161-163
+  lml = -0.5 * yc.T.dot(alpha) - (np.log(np.diag(L))).sum() - 0.5 * n * np.log(2 * np.pi)   # :224-226
+  t['solve'] = time.perf_counter() - t0
+  out.update(alpha=alpha, lml=float(lml), jitter_power=power, blocks=[])
+  per_block = []
+  for Xc, U in zip(cand_blocks, U_blocks):
+    tb = {}
+    t0 = time.perf_counter()
+    K_tetr = kern(Xc, X)                                            # gp_core.py:172-174
+    mu = mean_c + K_tetr.dot(alpha)
+    K_tete = kern(Xc, Xc)
+    tb['cross'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    V = O.solve_lower_triangular(L, K_tetr.T)                       # gp_core.py:180
+    tb['trsm'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cov = K_tete - V.T.dot(V)                                       # gp_core.py:181
+    tb['syrk'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Lc, pw = O.stable_cholesky(cov, return_power=True)              # general_utils.py:229
+    s = (Lc.dot(U.reshape(-1, 1)).T + mu).ravel()                   # general_utils.py:231
+    arg = int(s.argmax())
+    tb['blockchol'] = time.perf_counter() - t0
+    per_block.append(tb)
+    out['blocks'].append(dict(mu=mu, sd=np.sqrt(np.diag(cov)), draw=s, argmax=arg, jitter_power=pw))
+  t['blocks'] = per_block
+  return t, out
+
+
+def cpu_baseline_and_parity(prob, cands0, U0, eng, spec):
+  """ cpu_baseline: the oracle on this host's cores -- the FULL n = 16384 fit once and three full
+      Thompson blocks of 4096 candidates (median block time x 64 blocks; the blocks are
+      independent and identical in work).  parity_vs_oracle: the device on the same inputs. """
+  from oracle import ref_numpy as O
+  X, Y, mean_c, noise = prob['X'], prob['Y'], prob['mean_c'], prob['noise']
+  kern = O.KernelSpec('se', DIM, prob['scale'], prob['bw'])
+  nb = 3
+  cb = [cands0[b * TS_BLOCK:(b + 1) * TS_BLOCK] for b in range(nb)]
+  ub = [U0[b * TS_BLOCK:(b + 1) * TS_BLOCK] for b in range(nb)]
+  kern(X[:256], X[:256]); np.linalg.cholesky(np.eye(64))          # warm-up (first BLAS call)
+  t_all0 = time.perf_counter()
+  t, ref = oracle_stages(O, kern, X, Y, mean_c, noise, cb, ub)
+  measured_s = time.perf_counter() - t_all0
+  fit_s = t['kernel'] + t['chol'] + t['solve']
+  block_s = sorted(sum(tb.values()) for tb in t['blocks'])
+  n_blocks = CANDS_PER_GPU // TS_BLOCK
+  full_ms = (fit_s + n_blocks * block_s[len(block_s) // 2]) * 1e3
+  # one BLAS thread: a smaller sample (the full step would take ~an hour), scaled by algorithmic work
+  single = None
+  try:
+    import threadpoolctl
+    n1, b1 = 4096, 1024
+    with threadpoolctl.threadpool_limits(limits=1):
+      t1, _ = oracle_stages(O, kern, X[:n1], Y[:n1], mean_c, noise, [cands0[:b1]], [U0[:b1]])
+    rn, rb = N_TRAIN / float(n1), TS_BLOCK / float(b1)
+    tb = t1['blocks'][0]
+    fit1 = t1['kernel'] * rn ** 2 + t1['chol'] * rn ** 3 + t1['solve'] * rn ** 2
+    blk1 = tb['cross'] * rn * rb + tb['trsm'] * rn ** 2 * rb + tb['syrk'] * rn * rb ** 2 + tb['blockchol'] * rb ** 3
+    single = {'value': round((fit1 + n_blocks * blk1) * 1e3, 1), 'unit': 'ms', 'cores': 1,
+              'sample': 'fit at n=%d + one TS block of %d with one BLAS thread (threadpoolctl), each stage '
+                        'scaled to n=%d, block=%d by its algorithmic work (n^2 kernel, n^3 chol, n^2 b trsm, '
+                        'n b^2 syrk, b^3 block chol)' % (n1, b1, N_TRAIN, TS_BLOCK),
+              'measured_sample_s': round(t1['kernel'] + t1['chol'] + t1['solve'] + sum(tb.values()), 3)}
+  except Exception as e:    # pylint: disable=broad-except
+    single = {'error': repr(e)}
+  cpu = {
+    'value': round(full_ms, 1), 'unit': 'ms', 'cores': int(_blas_threads()), 'kind': 'port',
+    'sample': ('oracle/ref_numpy.py (NumPy %s): the full fit at n=%d (kernel matrix, Cholesky, alpha, lml) '
+               'measured once + %d full Thompson blocks of %d candidates at n=%d; value = fit + %d x median '
+               'block time (blocks are independent, equal work); %.1f s of CPU work measured'
+               % (np.__version__, N_TRAIN, nb, TS_BLOCK, N_TRAIN, n_blocks, measured_s)),
+    'measured_s': {'kernel': round(t['kernel'], 3), 'chol': round(t['chol'], 3), 'solve': round(t['solve'], 3),
+                   'blocks': [{k: round(v, 3) for k, v in tb.items()} for tb in t['blocks']]},
+    'host_cpus': os.cpu_count(), 'single_thread': single,
   }
+  # ---- the device on the same inputs ----
+  gp = eng.gp_fit(spec, X, Y - mean_c, noise)
+  m3 = nb * TS_BLOCK
+  mu, sd = gp.predict(cands0[:m3])
+  mu = mu + mean_c
+  _, _, samp, jps = gp.thompson(cands0[:m3], U0[:m3], block=TS_BLOCK, mean_const=mean_c, return_samples=True)
+  par = {
+    'what': 'device vs oracle on the bench inputs: n=%d fit; mu / sd / joint TS draw on the first %d candidates '
+            '(blocks of %d); max|a-b|/max|b|' % (N_TRAIN, m3, TS_BLOCK),
+    'lml_rel': abs(gp.lml - ref['lml']) / abs(ref['lml']),
+    'alpha_rel': rel(gp.get_alpha(), ref['alpha']),
+    'mu_rel': rel(mu, np.concatenate([b['mu'] for b in ref['blocks']])),
+    'sd_rel': rel(sd, np.concatenate([b['sd'] for b in ref['blocks']])),
+    'ts_draw_rel': rel(samp, np.concatenate([b['draw'] for b in ref['blocks']])),
+    'ts_argmax_equal': [int(np.argmax(samp[b * TS_BLOCK:(b + 1) * TS_BLOCK])) == ref['blocks'][b]['argmax']
+                        for b in range(nb)],
+    'jitter_power_fit': [gp.jitter_power, ref['jitter_power']],
+    'jitter_power_blocks': [list(jps), [b['jitter_power'] for b in ref['blocks']]],
+  }
+  gp.free()
+  return cpu, par
+
+
+# ---- other BASELINE configs (untimed extras) ---------------------------------------------------
+def other_configs(eng):
+  """ BASELINE configs 2 and 5 on one GPU: fit + candidate stage, inputs resident in HBM, median of
+      three; the posterior TRSM's share of the fp64 MFMA peak and the kernel-matrix build's share of
+      the HBM peak from the section timers (HIP events) of one extra pass. """
+  from dragonfly_amd.engine import KernelSpec
+  out = {}
+
+  def timed(fn, reps=3):
+    fn()
+    eng.sync()
+    ts = []
+    for _ in range(reps):
+      t0 = time.perf_counter()
+      fn()
+      eng.sync()
+      ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+  def sections(fn):
+    eng.timings(True)
+    fn()
+    eng.sync()
+    return eng.timings(False)
+
+  c = BC.config2()
+  spec = KernelSpec('matern', c['d'], c['scale'], c['bw'], nu=c['nu'])
+  Xd, yd, cd = eng.to_device(c['X']), eng.to_device(c['Y'] - c['mean_c']), eng.to_device(c['cands'])
+  box = {}
+
+  def c2():
+    gp = eng.gp_fit(spec, Xd, yd, c['noise'])
+    box['r'] = gp.acq_argmax('ei', cd, params=(c['best'], 0.0), mean_const=c['mean_c'])
+    gp.free()
+  ms = timed(c2)
+  s = sections(c2)
+  n, m = c['n'], c['m']
+  out['C2'] = {
+    'workload': 'Hartmann6 n=4096 d=6 Matern-2.5: fit + EI arg-max over 65536 candidates',
+    'ms': round(ms, 3), 'sections_ms': {k: round(v, 3) for k, v in s.items() if v > 0},
+    'trsm_frac_of_fp64_mfma_peak': round(float(n) * n * m / (s['trsm'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+    'kernel_matrix_frac_of_hbm_peak': round(8.0 * (n * n + 2 * n * c['d']) / (s['kernmat'] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
+    'cross_matrix_frac_of_hbm_peak': round(8.0 * (float(m) * n + (m + n) * c['d']) / (s['cross'] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
+    'chol_frac_of_fp64_mfma_peak': round(float(n) ** 3 / 3 / (s['chol'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+    'argmax': int(box['r'][1]),
+  }
+  for a in (Xd, yd, cd):
+    a.free()
+
+  c = BC.config5()
+  G = c['G']
+  spec = KernelSpec('additive', c['d'], c['scale'], groups=c['groups'], sub_kinds=['se'] * G,
+                    sub_scales=[1.0] * G, sub_nus=[0.0] * G, sub_bandwidths=c['bws'])
+  Xd, yd = eng.to_device(c['X']), eng.to_device(c['Y'] - c['mean_c'])
+  flat = eng.to_device(np.concatenate([x.ravel() for x in c['cands']]))
+  sizes = [c['m_j']] * G
+  beta = float(np.sqrt(0.2 * 5 * np.log(2 * 5 * c['n'] + 1)))      # gpb_acquisitions.py:135-137, t = n
+
+  def c5():
+    gp = eng.gp_fit(spec, Xd, yd, c['noise'])
+    box['r'] = gp.add_ucb_all([beta] * G, flat, sizes=sizes)
+    gp.free()
+  ms = timed(c5)
+  s = sections(c5)
+  n, M = c['n'], c['m_j'] * G
+  out['C5'] = {
+    'workload': 'additive GP d=100, 20 groups x 5, n=4096: fit + add-UCB over 20 x 3276 candidates (one call)',
+    'ms': round(ms, 3), 'sections_ms': {k: round(v, 3) for k, v in s.items() if v > 0},
+    'trsm_frac_of_fp64_mfma_peak': round(float(n) * n * M / (s['trsm'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+    'kernel_matrix_frac_of_hbm_peak': round(8.0 * n * n / (s['kernmat'] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
+    'chol_frac_of_fp64_mfma_peak': round(float(n) ** 3 / 3 / (s['chol'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+  }
+  for a in (Xd, yd, flat):
+    a.free()
+  return out
 
 
 def pmc_traffic():
   """ HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over
-      this same command (profiles/r01_pmc_traffic.json, written by tools/rocpd_pmc_traffic.py); None when
-      that file is absent.  Counters cannot be collected inside the timed run itself. """
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-  try:
-    with open(path) as f:
-      return json.load(f)['hbm_bytes_per_launch']
-  except (OSError, KeyError, ValueError):
-    return None
+      this same command (profiles/rNN_pmc_traffic.json, written by tools/rocpd_pmc_traffic.py).
+      Counters cannot be collected inside the timed run itself; the source file is named. """
+  for name in PMC_TRAFFIC_FILES:
+    path = os.path.join(ROOT, 'profiles', name)
+    try:
+      with open(path) as f:
+        return json.load(f)['hbm_bytes_per_launch'], 'profiles/' + name
+    except (OSError, KeyError, ValueError):
+      continue
+  return None, None
 
 
 def main():
@@ -130,88 +347,38 @@ def main():
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extras', action='store_true')
   args = ap.parse_args()
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  dist = None
-  torch = None
-  force_dist = os.environ.get('DFH_BENCH_FORCE_DIST', '0') == '1'   # exercise the RCCL path on one GPU
-  if world > 1 or force_dist:
-    # torch is plumbing only: process group (RCCL) for the barrier and the 16-byte all-gather
-    import torch                      # pylint: disable=import-outside-toplevel
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    torch.cuda.set_device(local_rank)
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if force_dist and 'RANK' not in os.environ:
-      os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'))
-    dist.init_process_group('nccl')
-  os.environ['DFH_DEVICE'] = str(local_rank)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes)
+  world_env = int(os.environ.get('WORLD_SIZE', '1'))
+  if world_env > 1 and world_env != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d processes' % (args.gpus, world_env))
 
-  from dragonfly_amd.engine import KernelSpec, get_engine
-  from dragonfly_amd import parallel
-  eng = get_engine()
-  X, Y, bw, mean_c, noise, cands, U = make_problem(rank)
-  spec = KernelSpec('se', DIM, float(Y.var()), bw)
-  Xd = eng.to_device(X)
-  yd = eng.to_device(Y - mean_c)
-  cd = eng.to_device(cands)
-  ud = eng.to_device(U)
-
-  def sync_all():
-    eng.sync()
-    if dist is not None:
-      torch.cuda.synchronize()
-      dist.barrier()
-
-  results = {}
-
-  def step():
-    gp = eng.gp_fit(spec, Xd, yd, noise)
-    v, i = gp.thompson(cd, ud, block=TS_BLOCK, mean_const=mean_c)
-    i += rank * CANDS_PER_GPU
-    if dist is not None:
-      v, i = parallel.allgather_argmax(v, i, device='cuda:%d' % local_rank)
-    results['lml'], results['best'], results['idx'] = gp.lml, v, i
-    gp.free()
+  from dragonfly_amd.engine import KernelSpec
+  prob = BC.config3()
+  spec = KernelSpec('se', DIM, prob['scale'], prob['bw'])
+  runner = (PerProcess if world_env > 1 else InProcess)(args.gpus, prob, spec)
+  rank, world, eng = runner.rank, runner.world, runner.eng0
 
   for _ in range(args.warmup):
-    step()
-  sync_all()
+    runner.step()
+  runner.sync()
   eng.gemm_profile(enable=True, fetch=False)      # event pairs only, no host synchronisation
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    step()
-  sync_all()
+    runner.step()
+  runner.sync()
   elapsed = time.perf_counter() - t0
   gstats = eng.gemm_profile(enable=False, fetch=True)
+  elapsed = runner.max_over_ranks(elapsed)
+  ms_per_step = elapsed * 1e3 / args.steps
   # section breakdown from one extra, untimed step (section timers synchronise the host)
   eng.timings(True)
-  step()
-  sync_all()
+  runner.step()
+  runner.sync()
   sections = eng.timings(False)
-  cond_est = None
-  if rank == 0:
-    # conditioning of the matrix that was factored (quoted next to the parity numbers):
-    # lambda_max(K) by power iteration on the host, lambda_min(K + noise I) >= noise
-    gp = eng.gp_fit(spec, Xd, yd, noise)
-    Kh = gp.get_K()
-    gp.free()
-    v = np.ones(N_TRAIN) / np.sqrt(N_TRAIN)
-    lam = 0.0
-    for _ in range(12):
-      w = Kh.dot(v)
-      lam = float(np.linalg.norm(w))
-      v = w / lam
-    cond_est = {'lambda_max_K': round(lam, 3), 'noise_var': noise,
-                'cond_upper_bound': round((lam + noise) / noise, 1)}
-    del Kh
-  if dist is not None:
-    tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
-  ms_per_step = elapsed * 1e3 / args.steps
+  result = dict(runner.result)
 
   out = None
   if rank == 0:
@@ -222,6 +389,7 @@ def main():
     # wall-clock is the union of its launch intervals (busy_ms), not the sum of their durations
     achieved = g0['flop'] / (g0['busy_ms'] * 1e-3) / 1e12 if g0['busy_ms'] > 0 else 0.0
     achieved_sum = g0['flop'] / (g0['ms'] * 1e-3) / 1e12 if g0['ms'] > 0 else 0.0
+    traffic, traffic_src = pmc_traffic()
     out = {
       'metric': 'GP-fit+acq-batch ms at n=16384,d=32',
       'value': round(ms_per_step, 3), 'unit': 'ms', 'n_gpus': world, 'steps': args.steps,
@@ -232,15 +400,17 @@ def main():
                               'candidates per GPU with arg-max'),
                  'n': N_TRAIN, 'd': DIM, 'candidates_per_gpu': CANDS_PER_GPU,
                  'candidates_total': CANDS_PER_GPU * world, 'ts_block': TS_BLOCK,
-                 'parallelism': 'candidate shards x%d, replicated fit, all-gather of (val,idx)' % world},
+                 'candidate_rows': 'rank r: rows [r*262144, (r+1)*262144) of RandomState(204).random_sample((2097152, 32)), '
+                                   'normals RandomState(304).standard_normal(2097152)',
+                 'parallelism': 'candidate shards x%d, replicated fit, RCCL all-gather of (val,idx)' % world,
+                 'launch': runner.mode},
       'candidates_per_s': round(CANDS_PER_GPU * world / (ms_per_step * 1e-3), 1),
       'sections_ms_extra_untimed_step_rank0': {k: round(v, 3) for k, v in sections.items() if v > 0},
-      'result': {'lml': results['lml'], 'ts_best': results['best'], 'ts_argmax': int(results['idx'])},
-      'conditioning': cond_est,
+      'result': {'lml': result['lml'], 'ts_best': result['best'], 'ts_argmax': int(result['idx'])},
       'roofline': {
         'bound': 'mfma', 'kernel': 'gemm_f64_kernel<NT,128x128> (v_mfma_f64_16x16x4_f64)',
         'achieved': round(achieved, 2), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(),
+        'frac': round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'launches_per_step': g0['launches'] / args.steps,
         'avg_launch_us': round(g0['busy_ms'] * 1e3 / max(1, g0['launches']), 2),
         'avg_launch_us_incl_overlap': round(g0['ms'] * 1e3 / max(1, g0['launches']), 2),
@@ -248,38 +418,57 @@ def main():
         'algorithmic_gflop_per_launch': round(g0['flop'] / max(1, g0['launches']) / 1e9, 3),
         'all_gemm_variants': {'ms_per_step': round(all_ms / args.steps, 3),
                               'tflops': round(all_flop / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0},
+        'side_targets': {
+          'cholesky_frac_of_fp64_mfma_peak': round(N_TRAIN ** 3 / 3.0 / (sections['chol'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
+                                             if sections.get('chol', 0) > 0 else None,
+          'kernel_matrix_frac_of_hbm_peak': round(8.0 * (N_TRAIN ** 2 + 2 * N_TRAIN * DIM) / (sections['kernmat'] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4)
+                                            if sections.get('kernmat', 0) > 0 else None,
+        },
       },
       'device': eng.name(),
     }
-    # untimed extra: drawing this rank's candidates (oper_utils.py:62 -- np.random.random((m, d))) on
-    # the device instead of on the host + PCIe; inputs of the timed step are resident either way
-    import time as _time
-    gen = {}
-    buf = eng.empty((CANDS_PER_GPU, DIM))
-    for label, rng in (('mt19937_continuing_numpy_state', np.random.RandomState(11)),
-                       ('philox4x64', np.random.Generator(np.random.Philox(key=11)))):
-      eng.random_candidates(64, DIM, rng=rng, out=buf)
+    if not args.no_extras:
+      # conditioning of the matrix that was factored (quoted next to the parity numbers):
+      # lambda_max(K) by power iteration on the host, lambda_min(K + noise I) >= noise
+      gp = eng.gp_fit(spec, prob['X'], prob['Y'] - prob['mean_c'], prob['noise'])
+      Kh = gp.get_K()
+      gp.free()
+      v = np.ones(N_TRAIN) / np.sqrt(N_TRAIN)
+      lam = 0.0
+      for _ in range(12):
+        w = Kh.dot(v)
+        lam = float(np.linalg.norm(w))
+        v = w / lam
+      del Kh
+      out['conditioning'] = {'lambda_max_K': round(lam, 3), 'noise_var': prob['noise'],
+                             'cond_upper_bound': round((lam + prob['noise']) / prob['noise'], 1)}
+      # untimed extra: drawing this rank's candidates (oper_utils.py:62 -- np.random.random((m, d))) on
+      # the device instead of on the host + PCIe; inputs of the timed step are resident either way
+      gen = {}
+      buf = eng.empty((CANDS_PER_GPU, DIM))
+      for label, rng in (('mt19937_continuing_numpy_state', np.random.RandomState(11)),
+                         ('philox4x64', np.random.Generator(np.random.Philox(key=11)))):
+        eng.random_candidates(64, DIM, rng=rng, out=buf)
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.random_candidates(CANDS_PER_GPU, DIM, rng=rng, out=buf)
+        eng.sync()
+        gen[label + '_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+      t0 = time.perf_counter()
+      host_draw = np.random.RandomState(11).random_sample((CANDS_PER_GPU, DIM))
+      t1 = time.perf_counter()
+      buf.upload(host_draw)
       eng.sync()
-      t0 = _time.perf_counter()
-      eng.random_candidates(CANDS_PER_GPU, DIM, rng=rng, out=buf)
-      eng.sync()
-      gen[label + '_ms'] = round((_time.perf_counter() - t0) * 1e3, 3)
-    t0 = _time.perf_counter()
-    host_draw = np.random.RandomState(11).random_sample((CANDS_PER_GPU, DIM))
-    t1 = _time.perf_counter()
-    buf.upload(host_draw)
-    eng.sync()
-    gen['host_numpy_draw_ms'] = round((t1 - t0) * 1e3, 3)
-    gen['host_upload_ms'] = round((_time.perf_counter() - t1) * 1e3, 3)
-    buf.free()
-    out['candidate_generation_untimed_rank0'] = gen
+      gen['host_numpy_draw_ms'] = round((t1 - t0) * 1e3, 3)
+      gen['host_upload_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
+      buf.free()
+      out['candidate_generation_untimed_rank0'] = gen
+      out['configs'] = other_configs(eng)
     if not args.no_cpu_baseline and world == 1:
-      out['cpu_baseline'] = cpu_baseline(X, Y, bw, mean_c, noise)
+      out['cpu_baseline'], out['parity_vs_oracle'] = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec)
     elif not args.no_cpu_baseline:
       out['cpu_baseline'] = None
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  runner.close()
   if rank == 0:
     sys.stdout.flush()
     print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout

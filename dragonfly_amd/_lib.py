@@ -18,6 +18,7 @@ GET_L, GET_ALPHA, GET_K = 0, 1, 2
 FIT_NO_JITTER = 1
 T_NAMES = ['kernmat', 'chol', 'solve', 'cross', 'trsm', 'acq', 'ts', 'spare']
 INT32_MIN = -2**31
+UNIQUE_ID_BYTES = 128
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -93,6 +94,33 @@ SIGNATURES = {
                           C.c_void_p, C.c_void_p, c_double_p, c_int64_p, c_int32_p]),
   'dfh_gp_add_ucb_group': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int64,
                                      C.c_void_p, c_double_p, c_int64_p]),
+  # multi-GPU: host-only contract, one-process-per-GPU communicator, in-process fan-out
+  'dfh_shard_bounds': (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int64, c_int64_p, c_int64_p]),
+  'dfh_reduce_argmax': (C.c_int, [c_double_p, c_int64_p, C.c_int, c_double_p, c_int64_p]),
+  'dfh_comm_unique_id': (C.c_int, [C.c_void_p]),
+  'dfh_comm_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+  'dfh_comm_destroy': (None, [C.c_void_p]),
+  'dfh_comm_rank': (C.c_int, [C.c_void_p]),
+  'dfh_comm_size': (C.c_int, [C.c_void_p]),
+  'dfh_comm_allgather_argmax': (C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_double_p, c_int64_p]),
+  'dfh_comm_allgather_f64': (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
+  'dfh_comm_allreduce_max': (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
+  'dfh_comm_barrier': (C.c_int, [C.c_void_p]),
+  'dfh_mgpu_create': (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+  'dfh_mgpu_destroy': (None, [C.c_void_p]),
+  'dfh_mgpu_size': (C.c_int, [C.c_void_p]),
+  'dfh_mgpu_ctx': (C.c_void_p, [C.c_void_p, C.c_int]),
+  'dfh_mgpu_gp': (C.c_void_p, [C.c_void_p, C.c_int]),
+  'dfh_mgpu_comm': (C.c_void_p, [C.c_void_p, C.c_int]),
+  'dfh_mgpu_sync': (C.c_int, [C.c_void_p]),
+  'dfh_mgpu_fit': (C.c_int, [C.c_void_p, C.POINTER(KernelDesc), C.POINTER(C.c_void_p), C.c_int64, C.c_int64,
+                             C.POINTER(C.c_void_p), C.c_double, C.c_int, c_double_p, c_int32_p]),
+  'dfh_mgpu_free_fit': (C.c_int, [C.c_void_p]),
+  'dfh_mgpu_ts': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_int64_p, C.c_int64, C.POINTER(C.c_void_p),
+                            C.c_double, c_double_p, c_int64_p, c_double_p, c_int64_p]),
+  'dfh_mgpu_acq_argmax': (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.POINTER(C.c_void_p), c_int64_p,
+                                    C.c_double, c_double_p, c_int64_p, c_double_p, c_int64_p]),
+  'dfh_mgpu_allgather_argmax': (C.c_int, [C.c_void_p, c_double_p, c_int64_p, c_double_p, c_int64_p]),
   'dfh_ctx_timings': (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
   'dfh_ctx_gemm_profile': (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
 }

@@ -174,11 +174,19 @@ class Engine(object):
     check(self.lib.dfh_ctx_create(int(device), C.byref(ctx)))
     self.ctx = ctx
     self.device = int(device)
+    self._owns_ctx = True
+
+  @classmethod
+  def from_ctx(cls, ctx, device):
+    """ A view of a context somebody else owns (parallel.MultiEngine's per-device contexts). """
+    new = cls.__new__(cls)
+    new.lib, new.ctx, new.device, new._owns_ctx = _lib.load(), ctx, int(device), False
+    return new
 
   def close(self):
-    if self.ctx is not None:
+    if self.ctx is not None and getattr(self, '_owns_ctx', True):
       self.lib.dfh_ctx_destroy(self.ctx)
-      self.ctx = None
+    self.ctx = None
 
   def __del__(self):
     try:

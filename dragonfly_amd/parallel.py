@@ -1,102 +1,320 @@
-"""Multi-GPU acquisition: candidates shard across the GPUs of a node, one process per GPU.
+"""Multi-GPU acquisition: candidates shard across the GPUs of a node.
 
-The reference evaluates every candidate in one NumPy array in one process (SURVEY.md section 8e:
-no collective exists in Dragonfly).  Candidates are independent given the fitted GP, so each rank
-fits the (replicated) GP on its own GPU, evaluates a contiguous shard of the candidate set with
-the fused device call, and the ranks exchange only their local (value, global index) pairs: an
-all-gather of 16 bytes per rank over RCCL/xGMI (torch.distributed backend "nccl"; "gloo" in the
-CPU tests), followed by the same deterministic reduction on every rank -- first NaN wins, else the
-largest value, ties to the lowest global index, i.e. exactly np.argmax over the whole set
-(dragonfly/utils/oper_utils.py:73).  RCCL has no MAXLOC and an all-reduce(max) alone would lose
-the index, hence gather-then-reduce.
+The reference evaluates every candidate in one NumPy array in one process and takes
+`obj_vals.argmax()` (dragonfly/utils/oper_utils.py:59-80; no collective exists in Dragonfly).
+Candidates are independent given the fitted GP, so each GPU fits the (replicated) GP, evaluates a
+contiguous shard of the candidate set with the fused device call, and the ranks exchange only
+their local (value, global index) pairs: an RCCL all-gather of 16 bytes per rank over xGMI, then
+the same deterministic reduction on every rank -- first NaN wins, else the largest value, ties to
+the lowest global index, i.e. exactly np.argmax over the whole set.  RCCL has no MAXLOC and an
+all-reduce(max) alone would lose the index, hence gather-then-reduce.
+
+Everything here goes through libdfhip.so (csrc/mgpu.hip: RCCL by dlopen); there is no PyTorch:
+
+  * `MultiEngine`  -- ONE process, N devices (dfh_mgpu_*: a context and a host thread per device,
+                      ncclCommInitAll).  `python bench.py --gpus N` without a launcher.
+  * `RcclComm`     -- one process PER GPU (dfh_comm_*: ncclGetUniqueId / ncclCommInitRank), the
+                      128-byte unique id passed through a file keyed by the launcher's rendezvous
+                      (MASTER_PORT, run id, parent pid).  What a `torch.distributed.run` launch
+                      of bench.py uses -- the launcher only provides RANK / WORLD_SIZE.
+  * `sharded_*`    -- the shard / evaluate / exchange helpers, written against a communicator
+                      object (rank, size, allgather_argmax, allgather_rows) so that the CPU tests
+                      can drive them with a stand-in transport.
 """
+import ctypes as C
+import os
+import time
+
 import numpy as np
 
+from . import _lib
+from ._lib import check
 
+
+# ---- the host-only contract (C-ABI: dfh_shard_bounds, dfh_reduce_argmax) ---------------------
 def shard_bounds(m, rank, world_size, align=1):
   """ [lo, hi) of rank's contiguous shard of m candidates; shard edges fall on multiples of
       `align` (the TS block size, so blocked-joint sampling is rank-count invariant). """
-  nblk = (m + align - 1) // align
-  per = (nblk + world_size - 1) // world_size
-  lo = min(m, rank * per * align)
-  hi = min(m, (rank + 1) * per * align)
-  return lo, hi
-
-
-def better(va, ia, vb, ib):
-  """ np.argmax ordering between two (value, index) pairs. """
-  na, nb = va != va, vb != vb
-  if na or nb:
-    if na and nb:
-      return ia < ib
-    return na
-  if va > vb:
-    return True
-  if va < vb:
-    return False
-  return ia < ib
+  lo, hi = C.c_int64(0), C.c_int64(0)
+  check(_lib.load().dfh_shard_bounds(int(m), int(rank), int(world_size), int(align), C.byref(lo), C.byref(hi)))
+  return int(lo.value), int(hi.value)
 
 
 def reduce_argmax(vals, idxs):
-  """ The winner among per-rank (value, global index) pairs; ranks with an empty shard pass
-      idx < 0 and are skipped. """
-  best_v, best_i = None, -1
-  for v, i in zip(vals, idxs):
-    i = int(i)
-    if i < 0:
-      continue
-    if best_i < 0 or better(float(v), i, best_v, best_i):
-      best_v, best_i = float(v), i
-  return best_v, best_i
+  """ The winner among per-rank (value, global index) pairs -- np.argmax ordering: first NaN, else
+      the largest value, ties to the lowest index; ranks with an empty shard pass idx < 0 and are
+      skipped.  Returns (None, -1) when every shard was empty. """
+  v = np.ascontiguousarray(vals, dtype=np.float64).reshape(-1)
+  i = np.ascontiguousarray(idxs, dtype=np.int64).reshape(-1)
+  bv, bi = C.c_double(0), C.c_int64(-1)
+  check(_lib.load().dfh_reduce_argmax(v.ctypes.data_as(_lib.c_double_p), i.ctypes.data_as(_lib.c_int64_p),
+                                      len(v), C.byref(bv), C.byref(bi)))
+  if bi.value < 0:
+    return None, -1
+  return float(bv.value), int(bi.value)
 
 
-def allgather_argmax(local_val, local_idx, group=None, device=None):
-  """ All-gather (value, global index) over the process group and reduce. Works with any
-      torch.distributed backend; `device` is the tensor device ('cuda:<n>' for nccl/RCCL). """
-  import torch
-  import torch.distributed as dist
-  if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-    return float(local_val), int(local_idx)
-  world = dist.get_world_size(group)
-  if device is None:
-    device = 'cuda:%d' % torch.cuda.current_device() if dist.get_backend(group) == 'nccl' else 'cpu'
-  # value and index travel as two float64 / int64 tensors (bit-exact; NaNs preserved)
-  v = torch.tensor([float(local_val)], dtype=torch.float64, device=device)
-  i = torch.tensor([int(local_idx)], dtype=torch.int64, device=device)
-  vs = [torch.empty_like(v) for _ in range(world)]
-  is_ = [torch.empty_like(i) for _ in range(world)]
-  dist.all_gather(vs, v, group=group)
-  dist.all_gather(is_, i, group=group)
-  return reduce_argmax([float(t.item()) for t in vs], [int(t.item()) for t in is_])
+# ---- passing the RCCL unique id between the processes of one node ---------------------------
+def _rendezvous_path(key=None):
+  if key is None:
+    key = '%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+                        os.getppid())
+  base = os.environ.get('DFH_RDZV_DIR', '/tmp')
+  return os.path.join(base, 'dfhip_rccl_id_%s.bin' % ''.join(ch if ch.isalnum() or ch in '-_' else '_' for ch in str(key)))
 
 
-def sharded_acq_argmax(fitted_gp, acq, cands, params=(0.0, 0.0), mean_const=0.0, rank=0,
-                       world_size=1, group=None, device=None):
+def exchange_unique_id(rank, make_id, key=None, timeout=600.0, nbytes=_lib.UNIQUE_ID_BYTES):
+  """ Rank 0 creates the id (make_id() -> bytes) and publishes it atomically in a file every rank
+      of this node can see; the others wait for the file.  Returns (id bytes, path). """
+  path = _rendezvous_path(key)
+  if rank == 0:
+    blob = bytes(make_id())
+    assert len(blob) == nbytes
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    with open(tmp, 'wb') as f:
+      f.write(blob)
+    os.replace(tmp, path)
+    return blob, path
+  deadline = time.time() + timeout
+  while True:
+    try:
+      with open(path, 'rb') as f:
+        blob = f.read()
+      if len(blob) == nbytes:
+        return blob, path
+    except OSError:
+      pass
+    if time.time() > deadline:
+      raise RuntimeError('Timed out waiting for the RCCL unique id at %s.' % path)
+    time.sleep(0.01)
+
+
+class RcclComm(object):
+  """ This process's rank of an RCCL communicator bound to its Engine (one process per GPU). """
+
+  def __init__(self, engine, rank, world_size, unique_id):
+    self.engine, self.rank, self.size = engine, int(rank), int(world_size)
+    self.lib = engine.lib
+    self.handle = None
+    h = C.c_void_p()
+    buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+    check(self.lib.dfh_comm_create(engine.ctx, self.size, self.rank, buf, C.byref(h)))
+    self.handle = h
+
+  @classmethod
+  def from_env(cls, engine, key=None):
+    """ RANK / WORLD_SIZE from the launcher's environment; the unique id through the file
+        rendezvous.  The file is removed once every rank has joined. """
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    lib = engine.lib
+
+    def make_id():
+      buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+      check(lib.dfh_comm_unique_id(buf))
+      return buf.raw
+    uid, path = exchange_unique_id(rank, make_id, key=key)
+    comm = cls(engine, rank, world, uid)      # returns when all ranks have arrived
+    if rank == 0:
+      try:
+        os.remove(path)
+      except OSError:
+        pass
+    return comm
+
+  def allgather_argmax(self, local_val, local_idx):
+    bv, bi = C.c_double(0), C.c_int64(-1)
+    check(self.lib.dfh_comm_allgather_argmax(self.handle, float(local_val), int(local_idx), C.byref(bv), C.byref(bi)))
+    return float(bv.value), int(bi.value)
+
+  def allgather_rows(self, row, is_owner):
+    """ The row held by the one rank with is_owner set, on every rank. """
+    row = np.ascontiguousarray(row, dtype=np.float64).reshape(-1)
+    send = np.concatenate([[1.0 if is_owner else 0.0], row])
+    recv = np.empty((self.size, len(send)), dtype=np.float64)
+    check(self.lib.dfh_comm_allgather_f64(self.handle, send.ctypes.data_as(_lib.c_double_p), len(send),
+                                          recv.ctypes.data_as(_lib.c_double_p)))
+    for r in range(self.size):
+      if recv[r, 0] == 1.0:
+        return recv[r, 1:].copy()
+    raise RuntimeError('allgather_rows: no rank owns the row.')
+
+  def allreduce_max(self, values):
+    a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+    check(self.lib.dfh_comm_allreduce_max(self.handle, a.ctypes.data_as(_lib.c_double_p), len(a)))
+    return a
+
+  def barrier(self):
+    check(self.lib.dfh_comm_barrier(self.handle))
+
+  def close(self):
+    if self.handle is not None:
+      self.lib.dfh_comm_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:     # pylint: disable=broad-except
+      pass
+
+
+# ---- one process, N devices -----------------------------------------------------------------
+def _ptr_array(items):
+  arr = (C.c_void_p * len(items))()
+  for r, it in enumerate(items):
+    p = _engine_ptr(it)
+    arr[r] = p.value if isinstance(p, C.c_void_p) else p
+  return arr
+
+
+def _engine_ptr(a):
+  from .engine import _ptr      # pylint: disable=import-outside-toplevel
+  return _ptr(a)
+
+
+class MultiEngine(object):
+  """ N MI355X in one process (dfh_mgpu): engines[r] is rank r's Engine view (uploads, buffers);
+      fit() replicates the GP; thompson() / acq_argmax() run the shards and the RCCL exchange. """
+
+  def __init__(self, n_devices, device_ids=None):
+    from .engine import Engine      # pylint: disable=import-outside-toplevel
+    self.lib = _lib.load()
+    self.handle = None
+    n_devices = int(n_devices)
+    visible = _lib.device_count()
+    if n_devices > visible:
+      raise _lib.DfhipError('%d GPUs requested, %d visible.' % (n_devices, visible))
+    ids = None if device_ids is None else (C.c_int * n_devices)(*[int(i) for i in device_ids])
+    h = C.c_void_p()
+    check(self.lib.dfh_mgpu_create(n_devices, ids, C.byref(h)))
+    self.handle = h
+    self.size = n_devices
+    self.engines = [Engine.from_ctx(C.c_void_p(self.lib.dfh_mgpu_ctx(h, r)),
+                                    r if device_ids is None else int(device_ids[r]))
+                    for r in range(n_devices)]
+    self.lml = None
+    self.jitter_power = None
+    self._keep = None
+
+  def _per_rank(self, a):
+    """ One entry per rank: a list is taken as is, anything else is shared by all ranks. """
+    if isinstance(a, (list, tuple)):
+      if len(a) != self.size:
+        raise ValueError('Need one entry per device (%d), got %d.' % (self.size, len(a)))
+      return list(a)
+    return [a] * self.size
+
+  def fit(self, spec, X, y_centred, noise_var, allow_jitter=True):
+    """ dfh_gp_fit on every device.  X / y_centred: a host array (shared) or a list with one
+        host array / DeviceArray per rank.  Returns the per-rank lml list (all equal). """
+    from .engine import DeviceArray, _f64      # pylint: disable=import-outside-toplevel
+    Xs = [x if isinstance(x, DeviceArray) else _f64(x) for x in self._per_rank(X)]
+    ys = [y if isinstance(y, DeviceArray) else _f64(y) for y in self._per_rank(y_centred)]
+    n, d = Xs[0].shape
+    desc = spec.to_desc()
+    lml = (C.c_double * self.size)()
+    jp = (C.c_int32 * self.size)()
+    check(self.lib.dfh_mgpu_fit(self.handle, C.byref(desc), _ptr_array(Xs), n, d, _ptr_array(ys),
+                                float(noise_var), 0 if allow_jitter else _lib.FIT_NO_JITTER, lml, jp))
+    self.lml = list(lml)
+    self.jitter_power = [None if p == _lib.INT32_MIN else int(p) for p in jp]
+    return self.lml
+
+  def free_fit(self):
+    check(self.lib.dfh_mgpu_free_fit(self.handle))
+
+  def gp_handle(self, rank):
+    return C.c_void_p(self.lib.dfh_mgpu_gp(self.handle, int(rank)))
+
+  @staticmethod
+  def _shards(shards):
+    from .engine import DeviceArray, _f64      # pylint: disable=import-outside-toplevel
+    out = [s if isinstance(s, DeviceArray) or s is None else _f64(s) for s in shards]
+    sizes = np.ascontiguousarray([0 if s is None else s.shape[0] for s in out], dtype=np.int64)
+    return out, sizes
+
+  def thompson(self, cand_shards, U_shards, block=4096, mean_const=0.0, return_local=False):
+    """ Blocked-joint Thompson sampling over the concatenation of the shards (cut them with
+        shard_bounds(..., align=block)); returns (best value, GLOBAL index[, per-rank winners]). """
+    Xs, ms = self._shards(cand_shards)
+    Us, _ = self._shards([None if u is None else np.ravel(u) if not hasattr(u, 'ptr') else u for u in U_shards])
+    bv, bi = C.c_double(0), C.c_int64(-1)
+    lv = (C.c_double * self.size)()
+    li = (C.c_int64 * self.size)()
+    check(self.lib.dfh_mgpu_ts(self.handle, _ptr_array(Xs), ms.ctypes.data_as(_lib.c_int64_p), int(block),
+                               _ptr_array(Us), float(mean_const), C.byref(bv), C.byref(bi), lv, li))
+    if return_local:
+      return float(bv.value), int(bi.value), list(zip(list(lv), list(li)))
+    return float(bv.value), int(bi.value)
+
+  def acq_argmax(self, acq, cand_shards, params=(0.0, 0.0), mean_const=0.0, return_local=False):
+    from .engine import ACQ_IDS      # pylint: disable=import-outside-toplevel
+    Xs, ms = self._shards(cand_shards)
+    p = (C.c_double * 2)(float(params[0]), float(params[1]) if len(params) > 1 else 0.0)
+    bv, bi = C.c_double(0), C.c_int64(-1)
+    lv = (C.c_double * self.size)()
+    li = (C.c_int64 * self.size)()
+    check(self.lib.dfh_mgpu_acq_argmax(self.handle, ACQ_IDS[acq], p, _ptr_array(Xs),
+                                       ms.ctypes.data_as(_lib.c_int64_p), float(mean_const), C.byref(bv),
+                                       C.byref(bi), lv, li))
+    if return_local:
+      return float(bv.value), int(bi.value), list(zip(list(lv), list(li)))
+    return float(bv.value), int(bi.value)
+
+  def allgather_argmax(self, vals, idxs):
+    """ The exchange alone (RCCL all-gather + reduce) for per-rank pairs given by the caller. """
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    i = np.ascontiguousarray(idxs, dtype=np.int64)
+    bv, bi = C.c_double(0), C.c_int64(-1)
+    check(self.lib.dfh_mgpu_allgather_argmax(self.handle, v.ctypes.data_as(_lib.c_double_p),
+                                             i.ctypes.data_as(_lib.c_int64_p), C.byref(bv), C.byref(bi)))
+    return float(bv.value), int(bi.value)
+
+  def sync(self):
+    check(self.lib.dfh_mgpu_sync(self.handle))
+
+  def close(self):
+    if self.handle is not None:
+      for e in self.engines:
+        e.ctx = None
+      self.lib.dfh_mgpu_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:     # pylint: disable=broad-except
+      pass
+
+
+# ---- shard / evaluate / exchange against a communicator ---------------------------------------
+def sharded_acq_argmax(fitted_gp, acq, cands, params=(0.0, 0.0), mean_const=0.0, comm=None):
   """ Fused acquisition arg-max of this rank's shard + the cross-rank exchange.
       Returns (best_val, best_global_idx); identical on every rank. """
-  lo, hi = shard_bounds(len(cands), rank, world_size)
+  rank, world = (0, 1) if comm is None else (comm.rank, comm.size)
+  lo, hi = shard_bounds(len(cands), rank, world)
   if hi > lo:
     v, i = fitted_gp.acq_argmax(acq, cands[lo:hi], params=params, mean_const=mean_const)
     i += lo
   else:
     v, i = float('nan'), -1
-  if world_size == 1:
+  if world == 1:
     return v, i
-  return allgather_argmax(v, i, group=group, device=device)
+  return comm.allgather_argmax(v, i)
 
 
-def sharded_thompson(fitted_gp, cands, U, block, mean_const=0.0, rank=0, world_size=1, group=None,
-                     device=None):
+def sharded_thompson(fitted_gp, cands, U, block, mean_const=0.0, comm=None):
   """ Blocked-joint Thompson sampling over the candidate set, sharded on block boundaries. """
-  lo, hi = shard_bounds(len(cands), rank, world_size, align=block)
+  rank, world = (0, 1) if comm is None else (comm.rank, comm.size)
+  lo, hi = shard_bounds(len(cands), rank, world, align=block)
   if hi > lo:
     v, i = fitted_gp.thompson(cands[lo:hi], np.asarray(U)[lo:hi], block=block, mean_const=mean_const)
     i += lo
   else:
     v, i = float('nan'), -1
-  if world_size == 1:
+  if world == 1:
     return v, i
-  return allgather_argmax(v, i, group=group, device=device)
+  return comm.allgather_argmax(v, i)
 
 
 def sharded_random_candidates(engine, m, bounds, rank=0, world_size=1, align=1, rng=None):
@@ -111,39 +329,22 @@ def sharded_random_candidates(engine, m, bounds, rank=0, world_size=1, align=1, 
   return shard, lo, hi
 
 
-def sharded_rand_acq_argmax(fitted_gp, acq, m, bounds, params=(0.0, 0.0), mean_const=0.0, rank=0,
-                            world_size=1, group=None, device=None, rng=None):
+def sharded_rand_acq_argmax(fitted_gp, acq, m, bounds, params=(0.0, 0.0), mean_const=0.0, comm=None, rng=None):
   """ random_maximise of an acquisition over m candidates (oper_utils.py:70-80), candidates
       generated and evaluated shard by shard on the GPUs.  Returns (best value, global index, the
       winning point); identical on every rank: the point travels from its owner in a second tiny
       all-gather. """
-  shard, lo, hi = sharded_random_candidates(fitted_gp.engine, m, bounds, rank, world_size, rng=rng)
+  rank, world = (0, 1) if comm is None else (comm.rank, comm.size)
+  shard, lo, hi = sharded_random_candidates(fitted_gp.engine, m, bounds, rank, world, rng=rng)
   if hi > lo:
     v, i = fitted_gp.acq_argmax(acq, shard, params=params, mean_const=mean_const)
     i += lo
   else:
     v, i = float('nan'), -1
-  if world_size > 1:
-    v, i = allgather_argmax(v, i, group=group, device=device)
+  if world > 1:
+    v, i = comm.allgather_argmax(v, i)
   mine = lo <= i < hi
   point = shard.row(i - lo) if mine else np.zeros(len(bounds))
-  if world_size > 1:
-    point = allgather_rows(point, mine, group=group, device=device)
+  if world > 1:
+    point = comm.allgather_rows(point, mine)
   return v, i, point
-
-
-def allgather_rows(row, is_owner, group=None, device=None):
-  """ The row held by the one rank with is_owner set, on every rank. """
-  import torch
-  import torch.distributed as dist
-  world = dist.get_world_size(group)
-  if device is None:
-    device = 'cuda:%d' % torch.cuda.current_device() if dist.get_backend(group) == 'nccl' else 'cpu'
-  payload = torch.tensor(np.concatenate([[1.0 if is_owner else 0.0], np.asarray(row, dtype=np.float64)]),
-                         dtype=torch.float64, device=device)
-  gathered = [torch.empty_like(payload) for _ in range(world)]
-  dist.all_gather(gathered, payload, group=group)
-  for t in gathered:
-    if float(t[0].item()) == 1.0:
-      return t[1:].cpu().numpy()
-  raise RuntimeError('allgather_rows: no rank owns the row.')

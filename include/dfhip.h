@@ -273,6 +273,82 @@ int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64_t* counter
                             int32_t* buffer_pos, int64_t m, int64_t d, int64_t row_begin,
                             int64_t row_count, const double* bounds, double* out);
 
+/* ---- multi-GPU: candidate shards across the GPUs of a node ------------
+ * The reference has no collective: every candidate of a random-search acquisition sits in ONE
+ * array in ONE process and the winner is obj_vals.argmax() (dragonfly/utils/oper_utils.py:59-80,
+ * line 73).  Candidates are independent given the fitted GP, so they shard contiguously over the
+ * devices; the fit is replicated (identical on every device; one n = 16384 factorisation does not
+ * shard profitably over xGMI) and the ONLY exchange is an RCCL all-gather of one 16-byte
+ * (value:f64, global row index:i64) pair per rank, followed by the same deterministic reduce on
+ * every rank -- first NaN wins, else the largest value, ties to the lowest global index: exactly
+ * np.argmax over the whole set (RCCL has no MAXLOC; all-reduce(max) alone would lose the index).
+ * RCCL is dlopen'ed on first use; no PyTorch anywhere.                                         */
+
+/* Host-only pieces of the contract (no GPU needed).
+ * dfh_shard_bounds: rows [*lo, *hi) of rank's contiguous shard of m candidates, shard edges on
+ * multiples of `align` (the Thompson block size, so the blocks -- hence the joint draws -- are
+ * those of a single device doing it all).
+ * dfh_reduce_argmax: the reduce above over `count` (value, global index) pairs; pairs with
+ * idx < 0 (empty shards) are skipped; no pair at all gives (NaN, -1).                          */
+int dfh_shard_bounds(int64_t m, int rank, int world, int64_t align, int64_t* lo, int64_t* hi);
+int dfh_reduce_argmax(const double* vals, const int64_t* idxs, int count, double* best_val,
+                      int64_t* best_idx);
+
+/* (1) One process per GPU.  Rank 0 calls dfh_comm_unique_id (ncclGetUniqueId) and hands the
+ * DFH_UNIQUE_ID_BYTES to the other processes by whatever means the host side has; every process
+ * then calls dfh_comm_create on its own context (ncclCommInitRank: blocks until all arrived).  */
+#define DFH_UNIQUE_ID_BYTES 128
+typedef struct dfh_comm dfh_comm;
+int  dfh_comm_unique_id(void* id_out /* [DFH_UNIQUE_ID_BYTES] */);
+int  dfh_comm_create(dfh_ctx* ctx, int nranks, int rank, const void* id, dfh_comm** out);
+void dfh_comm_destroy(dfh_comm* comm);
+int  dfh_comm_rank(dfh_comm* comm);
+int  dfh_comm_size(dfh_comm* comm);
+/* all-gather of (local_val, local_idx) on the context's stream + the reduce; identical result on
+ * every rank.  local_idx is the GLOBAL row index (or < 0 for an empty shard).                   */
+int  dfh_comm_allgather_argmax(dfh_comm* comm, double local_val, int64_t local_idx,
+                               double* best_val, int64_t* best_idx);
+/* recv[r*count + j] = rank r's send[j] (host buffers, count <= 4096): the winning candidate's
+ * coordinates travelling from its owner to every rank.                                          */
+int  dfh_comm_allgather_f64(dfh_comm* comm, const double* send, int count, double* recv);
+/* plumbing for benchmarks: element-wise max of inout[count <= 64] over the ranks; barrier.      */
+int  dfh_comm_allreduce_max(dfh_comm* comm, double* inout, int count);
+int  dfh_comm_barrier(dfh_comm* comm);
+
+/* (2) One process, N devices: a context per device, a host thread per device for the blocking
+ * per-device work, one communicator clique (ncclCommInitAll).  device_ids NULL = devices 0..N-1.
+ * Fails with DFH_ERR_BAD_ARG when fewer than n_devices are visible.                             */
+typedef struct dfh_mgpu dfh_mgpu;
+int      dfh_mgpu_create(int n_devices, const int* device_ids, dfh_mgpu** out);
+void     dfh_mgpu_destroy(dfh_mgpu* mg);
+int      dfh_mgpu_size(dfh_mgpu* mg);
+dfh_ctx* dfh_mgpu_ctx(dfh_mgpu* mg, int rank);    /* rank's context (for dfh_malloc / uploads)  */
+dfh_gp*  dfh_mgpu_gp(dfh_mgpu* mg, int rank);     /* rank's replica of the current fit, or NULL */
+dfh_comm* dfh_mgpu_comm(dfh_mgpu* mg, int rank);
+int      dfh_mgpu_sync(dfh_mgpu* mg);
+/* Replicated dfh_gp_fit on every device (GP.build_posterior, gp/gp_core.py:155-163).  X[r],
+ * y_centred[r]: rank r's copy -- a host pointer (the same one may be given for all ranks) or a
+ * pointer into rank r's HBM.  lml, jitter_power: [n_devices] or NULL.  Replaces the previous fit. */
+int dfh_mgpu_fit(dfh_mgpu* mg, const dfh_kernel_desc* k, const double* const* X, int64_t n, int64_t d,
+                 const double* const* y_centred, double noise_var, int flags, double* lml,
+                 int32_t* jitter_power);
+int dfh_mgpu_free_fit(dfh_mgpu* mg);
+/* dfh_gp_ts / dfh_gp_acq_argmax over contiguous shards: rank r holds rows [off_r, off_r + m[r]) of
+ * the global candidate set, off_r = m[0] + ... + m[r-1]; Xs[r] (and U[r], the shard's standard
+ * normals) are host pointers or pointers into rank r's HBM; m[r] == 0 is an empty shard.
+ * best_idx is the GLOBAL row index, identical to the single-device call on the concatenated set
+ * (for dfh_mgpu_ts when the shards are cut on multiples of `block`).  local_vals / local_idx:
+ * optional [n_devices], each rank's own winner (global index) before the exchange.              */
+int dfh_mgpu_ts(dfh_mgpu* mg, const double* const* Xs, const int64_t* m, int64_t block,
+                const double* const* U, double mean_const, double* best_val, int64_t* best_idx,
+                double* local_vals, int64_t* local_idx);
+int dfh_mgpu_acq_argmax(dfh_mgpu* mg, int acq, const double* params, const double* const* Xs,
+                        const int64_t* m, double mean_const, double* best_val, int64_t* best_idx,
+                        double* local_vals, int64_t* local_idx);
+/* the exchange alone: vals / idxs [n_devices] in, the reduced pair out                          */
+int dfh_mgpu_allgather_argmax(dfh_mgpu* mg, const double* vals, const int64_t* idxs,
+                              double* best_val, int64_t* best_idx);
+
 /* ---- timing of the last call's dominant kernels (HIP events, ms) ------------------------- */
 #define DFH_T_KERNMAT  0   /* training kernel-matrix build                                   */
 #define DFH_T_CHOL     1   /* blocked Cholesky (all launches)                                */

@@ -1,0 +1,112 @@
+"""GPU: the multi-GPU entry points of the C-ABI (dfh_mgpu_*, dfh_comm_*; csrc/mgpu.hip) on the one
+device a test box has.  The N = 1 path goes through the same code as N = 8 -- per-device context,
+replicated fit, shard evaluation, RCCL all-gather of the (value, index) pair, reduce -- and must
+equal the single-device calls bit for bit (reference semantics: one array, obj_vals.argmax(),
+dragonfly/utils/oper_utils.py:73)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dragonfly_amd import _lib, parallel
+from dragonfly_amd.engine import KernelSpec
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n=700, d=5, m=3000, seed=3):
+  rs = np.random.RandomState(seed)
+  X = rs.rand(n, d)
+  Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+  spec = KernelSpec('se', d, float(Y.var()), np.full(d, 0.4))
+  return X, Y - np.median(Y), float(np.median(Y)), float(Y.var() / 20), spec, rs.rand(m, d), rs.randn(m)
+
+
+def test_mgpu_one_device_equals_single_device_calls(engine):
+  X, yc, mean_c, noise, spec, cands, U = _problem()
+  gp = engine.gp_fit(spec, X, yc, noise)
+  want_ts = gp.thompson(cands, U, block=512, mean_const=mean_c)
+  want_ei = gp.acq_argmax('ei', cands, params=(float(yc.max() + mean_c), 0.0), mean_const=mean_c)
+  mg = parallel.MultiEngine(1)
+  try:
+    lml = mg.fit(spec, X, yc, noise)
+    assert lml == [gp.lml]
+    # host shards, then shards resident in the rank's HBM
+    got = mg.thompson([cands], [U], block=512, mean_const=mean_c, return_local=True)
+    assert got[:2] == want_ts and got[2] == [want_ts]
+    cd, ud = mg.engines[0].to_device(cands), mg.engines[0].to_device(U)
+    assert mg.thompson([cd], [ud], block=512, mean_const=mean_c) == want_ts
+    assert mg.acq_argmax('ei', [cd], params=(float(yc.max() + mean_c), 0.0), mean_const=mean_c) == want_ei
+    # the exchange alone: NaN-first / lowest-index rule comes back through RCCL unchanged
+    assert mg.allgather_argmax([2.5], [17]) == (2.5, 17)
+    v, i = mg.allgather_argmax([float('nan')], [4])
+    assert v != v and i == 4
+    # a second fit replaces the first
+    mg.fit(spec, X[:300], yc[:300], noise)
+    g2 = engine.gp_fit(spec, X[:300], yc[:300], noise)
+    assert mg.thompson([cd], [ud], block=512, mean_const=mean_c) == g2.thompson(cands, U, block=512, mean_const=mean_c)
+    cd.free()
+    ud.free()
+  finally:
+    mg.close()
+
+
+def test_mgpu_rank_loop_on_one_device_matches_unsharded(engine):
+  """ what N devices compute, computed rank after rank on one device, pushed through the RCCL
+      exchange: equal to the unsharded call (shards cut on block boundaries) """
+  X, yc, mean_c, noise, spec, cands, U = _problem(m=4096 + 700)
+  gp = engine.gp_fit(spec, X, yc, noise)
+  B = 256
+  want = gp.thompson(cands, U, block=B, mean_const=mean_c)
+  mg = parallel.MultiEngine(1)
+  try:
+    for world in (2, 3, 8):
+      vals, idxs = [], []
+      for r in range(world):
+        lo, hi = parallel.shard_bounds(len(cands), r, world, align=B)
+        if hi > lo:
+          v, i = gp.thompson(cands[lo:hi], U[lo:hi], block=B, mean_const=mean_c)
+          vals.append(v)
+          idxs.append(i + lo)
+        else:
+          vals.append(float('nan'))
+          idxs.append(-1)
+      assert parallel.reduce_argmax(vals, idxs) == want
+      # one pair at a time through the device collective (a 1-rank communicator), then the reduce
+      through = [mg.allgather_argmax([v], [i]) for v, i in zip(vals, idxs)]
+      live = [(v, i) for v, i in through if i >= 0]
+      assert parallel.reduce_argmax([p[0] for p in live], [p[1] for p in live]) == want
+  finally:
+    mg.close()
+
+
+def test_mgpu_more_devices_than_visible_fails_loudly():
+  with pytest.raises(_lib.DfhipError):
+    parallel.MultiEngine(_lib.device_count() + 1)
+  h = C.c_void_p()
+  rc = _lib.load().dfh_mgpu_create(_lib.device_count() + 1, None, C.byref(h))
+  assert rc == _lib.DFH_ERR_BAD_ARG and 'visible' in _lib.last_error()
+
+
+def test_process_per_gpu_communicator_single_rank(engine, monkeypatch, tmp_path):
+  """ dfh_comm_*: ncclGetUniqueId -> file rendezvous -> ncclCommInitRank, world size 1 """
+  monkeypatch.setenv('RANK', '0')
+  monkeypatch.setenv('WORLD_SIZE', '1')
+  monkeypatch.setenv('DFH_RDZV_DIR', str(tmp_path))
+  comm = parallel.RcclComm.from_env(engine, key='gpu_test')
+  try:
+    assert (comm.rank, comm.size) == (0, 1)
+    assert comm.allgather_argmax(1.25, 7) == (1.25, 7)
+    v, i = comm.allgather_argmax(float('nan'), -1)       # every shard empty
+    assert i == -1
+    row = np.arange(5.0)
+    assert np.array_equal(comm.allgather_rows(row, True), row)
+    assert np.array_equal(comm.allreduce_max([3.0, -1.0]), [3.0, -1.0])
+    comm.barrier()
+    X, yc, mean_c, noise, spec, cands, U = _problem(n=200, m=500)
+    gp = engine.gp_fit(spec, X, yc, noise)
+    assert parallel.sharded_thompson(gp, cands, U, 128, mean_const=mean_c, comm=comm) == \
+        gp.thompson(cands, U, block=128, mean_const=mean_c)
+  finally:
+    comm.close()
+  assert not list(tmp_path.iterdir())       # rank 0 removed the rendezvous file
