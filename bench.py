@@ -244,6 +244,7 @@ def cpu_baseline_and_parity(prob, cands0, U0, eng, spec):
     'ts_argmax_equal': [int(np.argmax(samp[b * TS_BLOCK:(b + 1) * TS_BLOCK])) == ref['blocks'][b]['argmax']
                         for b in range(nb)],
     'jitter_power_fit': [gp.jitter_power, ref['jitter_power']],
+    'refine_steps_per_block': gp.refine_steps(),
     'jitter_power_blocks': [list(jps), [b['jitter_power'] for b in ref['blocks']]],
   }
   gp.free()
@@ -358,7 +359,10 @@ def main():
   from dragonfly_amd.engine import KernelSpec
   prob = BC.config3()
   spec = KernelSpec('se', DIM, prob['scale'], prob['bw'])
-  runner = (PerProcess if world_env > 1 else InProcess)(args.gpus, prob, spec)
+  # DFH_BENCH_PER_PROCESS=1: take the process-per-GPU route even with one process (exercises
+  # ncclGetUniqueId / file rendezvous / ncclCommInitRank on a one-GPU box)
+  per_process = world_env > 1 or os.environ.get('DFH_BENCH_PER_PROCESS', '0') == '1'
+  runner = (PerProcess if per_process else InProcess)(args.gpus, prob, spec)
   rank, world, eng = runner.rank, runner.world, runner.eng0
 
   for _ in range(args.warmup):

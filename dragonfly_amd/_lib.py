@@ -83,6 +83,7 @@ SIGNATURES = {
   'dfh_gp_free': (C.c_int, [C.c_void_p]),
   'dfh_gp_get': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
   'dfh_gp_n': (C.c_int64, [C.c_void_p]),
+  'dfh_gp_refine_steps': (C.c_int, [C.c_void_p, c_int32_p]),
   'dfh_gp_predict': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p]),
   'dfh_gp_predict_covar': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

@@ -18,7 +18,8 @@ struct dfh_gp {
   double* Xp = nullptr;          // [n][P] packed scaled training inputs
   double* Np = nullptr;          // [n][n_parts]
   double* L = nullptr;           // [n][n] lower factor (strict upper part unspecified)
-  double* inv = nullptr;         // [nblk][NB][NB] inverses of the diagonal blocks of L
+  double* inv = nullptr;         // [2][nblk][NB][NB]: inverses of the diagonal blocks of L, then clean copies of the blocks
+  std::vector<int> refine;       // [nblk] refinement steps the solves take with each block (chol.hip: refine_steps)
   double* alpha = nullptr;       // [n]
   bool upper_zeroed = false;
   bool gram = false;             // built from a host-evaluated Gram matrix: no kernel, no packed inputs
@@ -235,7 +236,7 @@ int halluc_prepare(dfh_gp* gp, const double* Xh_user, int64_t q, Halluc* h) {
   DFH_TRY(pack_scaled(ctx, kd, 0, kd.n_parts, false, Xh, q, gp->d, h->Xhp, h->Nhp));
   // Wt = K(Xh, X) L^-T
   DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, gp->Xp, gp->Np, gp->n, false, 0.0, h->Wt, gp->n));
-  DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, h->Wt, q, gp->n));
+  DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, h->Wt, q, gp->n, gp->refine.data()));
   // S = K(Xh,Xh) + (noise + jitter) I - Wt Wt^T ; Lh = chol(S)
   DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, h->Xhp, h->Nhp, q, true, gp->noise_var, h->Lh, q));
   if (gp->diag_jitter != 0.0) DFH_TRY(add_diag(ctx, h->Lh, q, q, gp->diag_jitter));
@@ -274,7 +275,7 @@ int posterior_chunk(dfh_gp* gp, const double* Xs_dev, int64_t mc, int64_t ldxs, 
   if (want_var) {
     {
       SectionTimer t(ctx, DFH_T_TRSM);
-      DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, Kct, mc, gp->n));                // gp_core.py:180
+      DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, Kct, mc, gp->n, gp->refine.data()));                // gp_core.py:180
     }
     SectionTimer t(ctx, DFH_T_ACQ);
     if (ss) DFH_TRY(row_sumsq(ctx, Kct, mc, gp->n, gp->n, ss));
@@ -433,12 +434,12 @@ extern "C" int dfh_cholesky(dfh_ctx* ctx, double* A, int64_t n, int64_t* info_pi
 template <typename Rebuild>
 static int stable_cholesky_device(dfh_ctx* ctx, double* dL, int64_t n, double* keep_inv, bool allow_jitter,
                                   Rebuild rebuild, int32_t* jitter_power, double* jitter_added,
-                                  int64_t ld = 0) {
+                                  int64_t ld = 0, int* refine_out = nullptr) {
   if (ld == 0) ld = n;
   if (jitter_power) *jitter_power = INT32_MIN;
   if (jitter_added) *jitter_added = 0.0;
   int64_t piv = 0;
-  int rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv);
+  int rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv, 1, 0, 0, refine_out);
   if (rc != DFH_ERR_NOT_PD || !allow_jitter) return rc;
   // general_utils.py:183-203
   DFH_TRY(rebuild());
@@ -451,7 +452,7 @@ static int stable_cholesky_device(dfh_ctx* ctx, double* dL, int64_t n, double* k
     if (!first) DFH_TRY(rebuild());
     first = false;
     DFH_TRY(add_diag(ctx, dL, n, ld, diag_noise));      // M + diag_noise * np.eye(n)
-    rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv);
+    rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv, 1, 0, 0, refine_out);
     if (rc == DFH_OK) {
       if (jitter_power) *jitter_power = p;
       if (jitter_added) *jitter_added = diag_noise;
@@ -505,22 +506,23 @@ extern "C" int dfh_solve_triangular(dfh_ctx* ctx, const double* L, int64_t n, in
   DFH_TRY(to_device(ctx, b, (size_t)n * nrhs * 8, SCR_STAGE_B, &dB));
   const int64_t nblk = (n + CHOL_NB - 1) / CHOL_NB;
   double* inv = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nblk * CHOL_NB * CHOL_NB * 8, (void**)&inv));
-  DFH_TRY(tri_block_inverses(ctx, dL, n, n, inv));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)inv_buffer_doubles(n) * 8, (void**)&inv));
+  std::vector<int> refine((size_t)nblk, 0);
+  DFH_TRY(tri_block_inverses(ctx, dL, n, n, inv, refine.data()));
   double* dX = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)n * nrhs * 8, (void**)&dX));
   if (nrhs == 1) {
     DFH_HIP(hipMemcpyAsync(dX, dB, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (!upper) DFH_TRY(trsv_forward(ctx, dL, n, n, inv, dX));
-    else DFH_TRY(trsv_backward(ctx, dL, n, n, inv, dX));
+    if (!upper) DFH_TRY(trsv_forward(ctx, dL, n, n, inv, dX, refine.data()));
+    else DFH_TRY(trsv_backward(ctx, dL, n, n, inv, dX, refine.data()));
   } else {
     double* Bt = nullptr;
     DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)n * nrhs * 8, (void**)&Bt));
     DFH_TRY(transpose_matrix(ctx, dB, nrhs, Bt, n, n, nrhs));       // Bt[nrhs][n]
     {
       SectionTimer t(ctx, DFH_T_TRSM);
-      if (!upper) DFH_TRY(trsm_rows(ctx, dL, n, n, inv, Bt, nrhs, n));
-      else DFH_TRY(trsm_rows_backward(ctx, dL, n, n, inv, Bt, nrhs, n));
+      if (!upper) DFH_TRY(trsm_rows(ctx, dL, n, n, inv, Bt, nrhs, n, refine.data()));
+      else DFH_TRY(trsm_rows_backward(ctx, dL, n, n, inv, Bt, nrhs, n, refine.data()));
     }
     DFH_TRY(transpose_matrix(ctx, Bt, n, dX, nrhs, nrhs, n));
   }
@@ -548,14 +550,20 @@ extern "C" int dfh_gp_free(dfh_gp* gp) {
 
 extern "C" int64_t dfh_gp_n(dfh_gp* gp) { return gp ? gp->n : -1; }
 
+extern "C" int dfh_gp_refine_steps(dfh_gp* gp, int32_t* steps_out) {
+  DFH_ARG(gp && steps_out);
+  for (int64_t b = 0; b < gp->nblk; ++b) steps_out[b] = b < (int64_t)gp->refine.size() ? gp->refine[b] : 0;
+  return DFH_OK;
+}
+
 // alpha = L^T \ (L \ y_centred) (gp_core.py:161-163) and the log marginal likelihood (:224-226)
 static int gp_alpha_and_lml(dfh_gp* gp, const double* dy, double* lml) {
   dfh_ctx* ctx = gp->ctx;
   const int64_t n = gp->n;
   SectionTimer t(ctx, DFH_T_SOLVE);
   DFH_HIP(hipMemcpyAsync(gp->alpha, dy, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  DFH_TRY(trsv_forward(ctx, gp->L, n, n, gp->inv, gp->alpha));
-  DFH_TRY(trsv_backward(ctx, gp->L, n, n, gp->inv, gp->alpha));
+  DFH_TRY(trsv_forward(ctx, gp->L, n, n, gp->inv, gp->alpha, gp->refine.data()));
+  DFH_TRY(trsv_backward(ctx, gp->L, n, n, gp->inv, gp->alpha, gp->refine.data()));
   double logdet = 0.0, dot = 0.0;
   DFH_TRY(logdet_and_dot(ctx, gp->L, n, n, dy, gp->alpha, &logdet, &dot));
   if (lml) *lml = -0.5 * dot - logdet - 0.5 * (double)n * log(2.0 * M_PI);
@@ -579,7 +587,8 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
     DFH_TRY(dev_alloc(ctx, (size_t)n * kd.P * 8, (void**)&gp->Xp));
     DFH_TRY(dev_alloc(ctx, (size_t)n * kd.n_parts * 8, (void**)&gp->Np));
     DFH_TRY(dev_alloc(ctx, (size_t)n * n * 8, (void**)&gp->L));
-    DFH_TRY(dev_alloc(ctx, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8, (void**)&gp->inv));
+    DFH_TRY(dev_alloc(ctx, (size_t)inv_buffer_doubles(n) * 8, (void**)&gp->inv));
+    gp->refine.assign((size_t)gp->nblk, 0);
     DFH_TRY(dev_alloc(ctx, (size_t)n * 8, (void**)&gp->alpha));
     const double *dX = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
@@ -596,7 +605,7 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
     {
       SectionTimer t(ctx, DFH_T_CHOL);
       DFH_TRY(stable_cholesky_device(ctx, gp->L, n, gp->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
-                                     jitter_power, &gp->diag_jitter));
+                                     jitter_power, &gp->diag_jitter, 0, gp->refine.data()));
     }
     return gp_alpha_and_lml(gp, dy, lml);
   };
@@ -630,7 +639,8 @@ extern "C" int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const d
   gp->nblk = (n + CHOL_NB - 1) / CHOL_NB;
   auto body = [&]() -> int {
     DFH_TRY(dev_alloc(ctx, (size_t)n * n * 8, (void**)&gp->L));
-    DFH_TRY(dev_alloc(ctx, (size_t)gp->nblk * CHOL_NB * CHOL_NB * 8, (void**)&gp->inv));
+    DFH_TRY(dev_alloc(ctx, (size_t)inv_buffer_doubles(n) * 8, (void**)&gp->inv));
+    gp->refine.assign((size_t)gp->nblk, 0);
     DFH_TRY(dev_alloc(ctx, (size_t)n * 8, (void**)&gp->alpha));
     const double *dK = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, K, (size_t)n * n * 8, SCR_KCT, &dK));
@@ -643,7 +653,7 @@ extern "C" int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const d
     {
       SectionTimer t(ctx, DFH_T_CHOL);
       DFH_TRY(stable_cholesky_device(ctx, gp->L, n, gp->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
-                                     jitter_power, &gp->diag_jitter));
+                                     jitter_power, &gp->diag_jitter, 0, gp->refine.data()));
     }
     return gp_alpha_and_lml(gp, dy, lml);
   };
@@ -691,7 +701,7 @@ extern "C" int dfh_gp_predict_gram(dfh_gp* gp, const double* Kcross, int64_t m, 
     if (sd_out) {
       {
         SectionTimer t(ctx, DFH_T_TRSM);
-        DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, mc, n));                  // gp_core.py:180
+        DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, mc, n, gp->refine.data()));                  // gp_core.py:180
       }
       SectionTimer t(ctx, DFH_T_ACQ);
       DFH_TRY(row_sumsq(ctx, Kct, mc, n, n, ss));
@@ -726,7 +736,7 @@ extern "C" int dfh_gp_predict_covar_gram(dfh_gp* gp, const double* Kcross, int64
                          is_device_ptr(Kcross) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   DFH_TRY(gemv_rows(ctx, Kct, m, n, n, gp->alpha, 1.0, nullptr, 0.0, vec));
   DFH_TRY(from_device(ctx, mu_out, vec, (size_t)m * 8));
-  DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, m, n));
+  DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, m, n, gp->refine.data()));
   const bool dev_out = is_device_ptr(cov_out);
   double* C = cov_out;
   if (!dev_out) DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)m * m * 8, (void**)&C));
@@ -767,7 +777,8 @@ extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const do
     DFH_TRY(dev_alloc(ctx, (size_t)n2 * P * 8, (void**)&g2->Xp));
     DFH_TRY(dev_alloc(ctx, (size_t)n2 * parts * 8, (void**)&g2->Np));
     DFH_TRY(dev_alloc(ctx, (size_t)n2 * n2 * 8, (void**)&g2->L));
-    DFH_TRY(dev_alloc(ctx, (size_t)g2->nblk * NB * NB * 8, (void**)&g2->inv));
+    DFH_TRY(dev_alloc(ctx, (size_t)inv_buffer_doubles(n2) * 8, (void**)&g2->inv));
+    g2->refine.assign((size_t)g2->nblk, 0);
     DFH_TRY(dev_alloc(ctx, (size_t)n2 * 8, (void**)&g2->alpha));
     const double *dXn = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, Xnew, (size_t)q * d * 8, SCR_STAGE_A, &dXn));
@@ -788,7 +799,7 @@ extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const do
       DFH_TRY(build_M());
       SectionTimer t(ctx, DFH_T_CHOL);
       return stable_cholesky_device(ctx, g2->L, n2, g2->inv, !(flags & DFH_FIT_NO_JITTER), build_M,
-                                    jitter_power, &g2->diag_jitter);
+                                    jitter_power, &g2->diag_jitter, 0, g2->refine.data());
     };
     bool appended = false;
     if (gp->diag_jitter == 0.0) {
@@ -801,7 +812,7 @@ extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const do
       }
       {
         SectionTimer t(ctx, DFH_T_TRSM);
-        DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Bm, q, n2));
+        DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Bm, q, n2, gp->refine.data()));
       }
       {
         SectionTimer t(ctx, DFH_T_CHOL);
@@ -812,9 +823,15 @@ extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const do
         if (rc == DFH_OK) {
           // inverses of the 512-blocks: untouched blocks are copied, the rest recomputed from L'
           const int64_t kb0 = n / NB;            // first diagonal block that contains a new row
-          if (kb0 > 0)
+          double* diag2 = g2->inv + g2->nblk * NB * NB;
+          if (kb0 > 0) {
             DFH_HIP(hipMemcpyAsync(g2->inv, gp->inv, (size_t)kb0 * NB * NB * 8, hipMemcpyDeviceToDevice, ctx->stream));
-          DFH_TRY(tri_block_inverses(ctx, g2->L + kb0 * NB * (n2 + 1), n2 - kb0 * NB, n2, g2->inv + kb0 * NB * NB));
+            DFH_HIP(hipMemcpyAsync(diag2, gp->inv + gp->nblk * NB * NB, (size_t)kb0 * NB * NB * 8,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+            std::copy(gp->refine.begin(), gp->refine.begin() + kb0, g2->refine.begin());
+          }
+          DFH_TRY(tri_block_inverses(ctx, g2->L + kb0 * NB * (n2 + 1), n2 - kb0 * NB, n2, g2->inv + kb0 * NB * NB,
+                                     g2->refine.data() + kb0, diag2 + kb0 * NB * NB));
           appended = true;
         } else if (rc != DFH_ERR_NOT_PD) {
           return rc;
@@ -846,34 +863,56 @@ __global__ void k_centre(const double* __restrict__ y, double c, double* __restr
 }
 
 // n <= CHOL_NB (one diagonal block): the whole solve stage of a candidate in one workgroup --
-// yc = y - m, z = L^-1 yc, alpha = L^-T z through the explicit block inverse, then
-// out = {sum log L_ii, yc . alpha}.  blockIdx.x = candidate.
-__global__ __launch_bounds__(256) void k_lml_finish_small(const double* __restrict__ L, long sL, long ldl,
-                                                          const double* __restrict__ inv, long sInv,
+// yc = y - m, z = L^-1 yc, alpha = L^-T z through the explicit block inverse M (each followed by
+// steps[c] steps of iterative refinement against the clean copy Ld of the block, chol.hip:
+// refine_steps), then out = {sum log L_ii, yc . alpha}.  blockIdx.x = candidate.
+__global__ __launch_bounds__(256) void k_lml_finish_small(const double* __restrict__ inv, long sInv,
                                                           const double* __restrict__ y,
                                                           const double* __restrict__ means, int n,
+                                                          const int* __restrict__ steps,
                                                           double* __restrict__ out2) {
-  __shared__ double yc[CHOL_NB], z[CHOL_NB], red[8];
+  __shared__ double yc[CHOL_NB], z[CHOL_NB], r[CHOL_NB], a[CHOL_NB], red[8];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  L += (long)c * sL;
   inv += (long)c * sInv;
+  const double* Ld = inv + CHOL_NB * CHOL_NB;                // clean copy of the factor (one block: nblk = 1)
   const double mean = means[c];
+  const int nsteps = steps[c];
   for (int i = tid; i < n; i += 256) yc[i] = y[i] - mean;
   __syncthreads();
-  for (int i = wave; i < n; i += 4) {                       // z = Linv yc (lower triangle), wave per row
-    const double* row = inv + (long)i * CHOL_NB;
-    double s = 0.0;
-    for (int j = lane; j <= i; j += 64) s = fma(row[j], yc[j], s);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) z[i] = s;
+  // dst_i (+)= sum_{j <= i} A[i][j] src[j], a wave per row
+  auto lower_mv = [&](const double* A, const double* src, double* dst, double sign, const double* base) {
+    for (int i = wave; i < n; i += 4) {
+      const double* row = A + (long)i * CHOL_NB;
+      double s = 0.0;
+      for (int j = lane; j <= i; j += 64) s = fma(row[j], src[j], s);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if (lane == 0) dst[i] = (base ? base[i] : 0.0) + sign * s;
+    }
+    __syncthreads();
+  };
+  // dst_j (+)= sum_{i >= j} A[i][j] src[i], a thread per column
+  auto lower_tmv = [&](const double* A, const double* src, double* dst, double sign, const double* base) {
+    for (int j = tid; j < n; j += 256) {
+      double s = 0.0;
+      for (int i = j; i < n; ++i) s = fma(A[(long)i * CHOL_NB + j], src[i], s);
+      dst[j] = (base ? base[j] : 0.0) + sign * s;
+    }
+    __syncthreads();
+  };
+  lower_mv(inv, yc, z, 1.0, nullptr);                       // z = M yc
+  for (int s = 0; s < nsteps; ++s) {
+    lower_mv(Ld, z, r, -1.0, yc);                           // r = yc - L z
+    lower_mv(inv, r, z, 1.0, z);                            // z += M r
   }
-  __syncthreads();
+  lower_tmv(inv, z, a, 1.0, nullptr);                       // alpha = M^T z
+  for (int s = 0; s < nsteps; ++s) {
+    lower_tmv(Ld, a, r, -1.0, z);                           // r = z - L^T alpha
+    lower_tmv(inv, r, a, 1.0, a);                           // alpha += M^T r
+  }
   double ld = 0.0, dt = 0.0;
-  for (int j = tid; j < n; j += 256) {                      // alpha_j = sum_{i >= j} Linv[i][j] z[i]
-    double s = 0.0;
-    for (int i = j; i < n; ++i) s = fma(inv[(long)i * CHOL_NB + j], z[i], s);
-    dt = fma(yc[j], s, dt);
-    ld += log(L[(long)j * ldl + j]);
+  for (int j = tid; j < n; j += 256) {
+    dt = fma(yc[j], a[j], dt);
+    ld += log(Ld[(long)j * CHOL_NB + j]);
   }
   for (int off = 32; off > 0; off >>= 1) { ld += __shfl_down(ld, off, 64); dt += __shfl_down(dt, off, 64); }
   if (lane == 0) { red[wave] = ld; red[4 + wave] = dt; }
@@ -895,7 +934,7 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   const int64_t NB = CHOL_NB;
   const int64_t nblk = (n + NB - 1) / NB;
   const int64_t ldK = (n + 1) & ~(int64_t)1;                 // even leading dimension: 16-byte row starts
-  const int64_t strideK = n * ldK, strideInv = nblk * NB * NB;
+  const int64_t strideK = n * ldK, strideInv = inv_buffer_doubles(n);
   // group size: up to CHOL_MAX_BATCH matrices and (DFH_LML_GROUP_GIB, default 8) GiB of Gram
   // matrices at a time.  Measured ms per candidate at 2 / 8 GiB: n=4096 1.55 / 1.07, n=16384
   // 42.6 (one at a time) / 30.0 (four in lock-step: the panel chains of the four interleave).
@@ -933,8 +972,9 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)G * strideInv * 8, (void**)&invb));
   DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)G * n * 8 * 2, (void**)&vecs));
   DFH_TRY(scratch_get(ctx, SCR_OUT2, (size_t)std::max(256, G * 16), (void**)&red));   // SCR_RED belongs to the gemv partials
-  DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)std::max(256, G * 16), (void**)&dpar));   // per candidate {noise, mean}
+  DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)std::max(256, G * 24), (void**)&dpar));   // per candidate {noise, mean}, then int steps
   std::vector<double> hred((size_t)G * 2), hpar((size_t)G * 2);
+  std::vector<int> refine((size_t)G * nblk, 0);           // refinement steps per candidate and diagonal block
   for (int c0 = 0; c0 < nb; c0 += G) {
     const int g = std::min(G, nb - c0);
     // packed inputs of the group's candidates (pad-to-4 columns per kernel part)
@@ -984,7 +1024,7 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
     {
       SectionTimer t(ctx, DFH_T_CHOL);
       int64_t piv[CHOL_MAX_BATCH] = {0};
-      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv);
+      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv, refine.data());
       if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
       for (int c = 0; c < g; ++c) {
         if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;
@@ -996,15 +1036,19 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
         auto rebuild = [&]() -> int { return build_M(c); };
         DFH_TRY(rebuild());
         int32_t jp = INT32_MIN;
-        DFH_TRY(stable_cholesky_device(ctx, Kb + c * strideK, n, invb + c * strideInv, true, rebuild, &jp, nullptr, ldK));
+        DFH_TRY(stable_cholesky_device(ctx, Kb + c * strideK, n, invb + c * strideInv, true, rebuild, &jp, nullptr, ldK,
+                                       refine.data() + (size_t)c * nblk));
         if (jitter_powers) jitter_powers[c0 + c] = jp;
       }
     }
     {
       SectionTimer t(ctx, DFH_T_SOLVE);
       if (n <= NB) {
-        hipLaunchKernelGGL(k_lml_finish_small, dim3((unsigned)g), dim3(256), 0, ctx->stream, Kb, (long)strideK,
-                           (long)ldK, invb, (long)strideInv, dy, dpar + g, (int)n, red);
+        // one block per candidate (nblk = 1): its refinement steps ride behind {noise, mean} in dpar
+        int* dsteps = reinterpret_cast<int*>(dpar + 2 * g);
+        DFH_HIP(hipMemcpyAsync(dsteps, refine.data(), (size_t)g * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_lml_finish_small, dim3((unsigned)g), dim3(256), 0, ctx->stream, invb, (long)strideInv,
+                           dy, dpar + g, (int)n, dsteps, red);
         DFH_LAUNCH_CHECK();
       } else {
         for (int c = 0; c < g; ++c) {
@@ -1013,8 +1057,8 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
           hipLaunchKernelGGL(k_centre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dy, hpar[g + c], yc, alpha, (long)n);
           DFH_LAUNCH_CHECK();
           // alpha = L^T \ (L \ (y - m))      (gp_core.py:161-163)
-          DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha));
-          DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha));
+          DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
+          DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
           DFH_TRY(logdet_and_dot_device(ctx, Kb + c * strideK, n, ldK, yc, alpha, red + 2 * c));
         }
       }
@@ -1189,7 +1233,7 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
   }
   {
     SectionTimer t(ctx, DFH_T_TRSM);
-    DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, M, n));
+    DFH_TRY(trsm_rows(ctx, gp->L, n, n, gp->inv, Kct, M, n, gp->refine.data()));
   }
   SectionTimer t(ctx, DFH_T_ACQ);
   DFH_TRY(row_sumsq(ctx, Kct, M, n, n, ss));

@@ -18,6 +18,7 @@
 #include "common.h"
 #include <utility>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -584,6 +585,76 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
   return DFH_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Quality of an explicit block inverse, and what the solves do about it.
+// Multiplying by the explicit inverse M of a 512 x 512 diagonal block L_bb leaves a residual of
+// order eps * cond(L_bb) instead of the order eps of a substitution.  For the matrices a GP with
+// noise >= Var(Y)/20 produces that is invisible; the reference's tuners also pick noise variances
+// of 1e-8 Var(Y), where cond(L_bb) reaches 1e5 and more (tests/test_gpu_conditioning.py).  Per
+// block the factorisation therefore keeps, next to M, a clean copy of L_bb (lower triangle, zero
+// elsewhere, row stride NB) and measures delta = max |I - M L_bb|.  A solve with block b then runs
+// refine_steps(delta) steps of iterative refinement in working precision, x <- x + M (r - L_bb x):
+// each step multiplies the residual by delta, and it bottoms out at the residual of a backward
+// stable solve (the rounding of r - L_bb x itself) -- the same GEMM / GEMV kernels, no
+// substitution chain.  Well-conditioned blocks (delta <= tol) take no step and cost nothing.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_copy_lower_block(const double* __restrict__ D, long lda, int nbk, double* __restrict__ out,
+                                   long strideD, long strideOut) {
+  D += (long)blockIdx.z * strideD;
+  out += (long)blockIdx.z * strideOut;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= (int)CHOL_NB) return;
+  out[(long)i * CHOL_NB + j] = (i < nbk && j <= i) ? D[(long)i * lda + j] : 0.0;
+}
+
+// delta[blockIdx.x * strideDelta] = max_ij |E_ij - [i == j]| over the nbk x nbk block E (ld NB); NaN if any
+__global__ __launch_bounds__(1024) void k_inv_delta(const double* __restrict__ E, int nbk, long strideE,
+                                                     double* __restrict__ delta, long strideDelta) {
+  __shared__ double sm[1024];
+  E += (long)blockIdx.x * strideE;
+  double m = 0.0;
+  bool bad = false;
+  for (long idx = threadIdx.x; idx < (long)nbk * nbk; idx += 1024) {
+    const int i = (int)(idx / nbk), j = (int)(idx % nbk);
+    const double v = fabs(E[(long)i * CHOL_NB + j] - (i == j ? 1.0 : 0.0));
+    if (v != v) bad = true;
+    m = v > m ? v : m;
+  }
+  sm[threadIdx.x] = bad ? INFINITY : m;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) delta[(long)blockIdx.x * strideDelta] = sm[0];
+}
+
+// clean copy of the diagonal block + delta, asynchronous on ctx->stream (T: NB*NB doubles per matrix)
+int block_inverse_quality(dfh_ctx* ctx, const double* D, int64_t lda, int64_t nbk, const double* Linv, double* Ldiag,
+                          double* T, double* d_delta, int nbatch = 1, int64_t strideD = 0, int64_t strideInv = 0,
+                          int64_t strideT = 0, int64_t strideDelta = 0) {
+  const int64_t NB = CHOL_NB;
+  hipLaunchKernelGGL(k_copy_lower_block, dim3((unsigned)(NB / 256), (unsigned)NB, (unsigned)nbatch), dim3(256), 0,
+                     ctx->stream, D, (long)lda, (int)nbk, Ldiag, (long)strideD, (long)strideInv);
+  DFH_LAUNCH_CHECK();
+  GemmBatch b;
+  b.count = nbatch; b.sA = strideInv; b.sB = strideInv; b.sCout = strideT;
+  DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, nbk, nbk, nbk, 1.0, Linv, NB, Ldiag, NB, 0.0, nullptr, 0, T, NB, &b));
+  hipLaunchKernelGGL(k_inv_delta, dim3((unsigned)nbatch), dim3(1024), 0, ctx->stream, T, (int)nbk, (long)strideT,
+                     d_delta, (long)strideDelta);
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
+
+int refine_steps(double delta) {
+  static const double tol = []() { const char* e = getenv("DFH_REFINE_TOL"); double v = e ? atof(e) : 1e-13; return v; }();
+  if (!(delta > tol)) return 0;
+  if (!(delta < 0.25)) return 8;                    // the inverse is barely an inverse: as many steps as we allow
+  const int k = (int)ceil(log(1e-15) / log(delta)) - 1;
+  return k < 1 ? 1 : (k > 8 ? 8 : k);
+}
+
 }  // namespace
 
 // Look-ahead schedule.  Two streams: P (high priority, "panel") and M (the context's main
@@ -595,7 +666,7 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
 // latency-bound diagonal work leaves the critical path while the trailing update is long enough
 // to cover it.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep) {
+                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out) {
   DFH_ARG(nbatch >= 1 && nbatch <= CHOL_MAX_BATCH);
   if (info_pivot) for (int b = 0; b < nbatch; ++b) info_pivot[b] = 0;
   if (n <= 0) return DFH_OK;
@@ -616,6 +687,9 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * strideL * 8, (void**)&Lscr_all));
   double* T = nullptr;
   if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
+  const int64_t nblk_all = (n + NB - 1) / NB;
+  double* d_delta = nullptr;                  // [nbatch][nblk] quality of the kept block inverses
+  if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_DELTA, (size_t)nbatch * nblk_all * 8, (void**)&d_delta));
   GemmBatch bA;                               // every operand inside the batch matrices
   bA.count = nbatch; bA.sA = bA.sB = bA.sCin = bA.sCout = strideA;
 
@@ -690,7 +764,12 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
                          D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
                          (long)strideL);
       DFH_LAUNCH_CHECK();
-      if (Linv) DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
+      if (Linv) {
+        DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
+        // clean copy of the block behind the inverses (keep_inv + nblk*NB*NB + ...) and delta = max|I - M L_bb|
+        DFH_TRY(block_inverse_quality(ctx, D, lda, nbk, Linv, Linv + nblk_all * NB * NB, T, d_delta + kb, nbatch,
+                                      strideA, strideInv, strideT, nblk_all));
+      }
       DFH_HIP(hipEventRecord(e_aux, X));
     }
     if (rem > NB) {
@@ -723,7 +802,13 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   }
 
   DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8 * (size_t)nbatch, hipMemcpyDeviceToHost, M));
+  std::vector<double> deltas;
+  if (keep_inv && refine_out) {
+    deltas.resize((size_t)nbatch * nblk_all);
+    DFH_HIP(hipMemcpyAsync(deltas.data(), d_delta, deltas.size() * 8, hipMemcpyDeviceToHost, M));
+  }
   DFH_HIP(hipStreamSynchronize(M));
+  for (size_t i = 0; i < deltas.size(); ++i) refine_out[i] = refine_steps(deltas[i]);
   int rc = DFH_OK;
   for (int b = 0; b < nbatch; ++b) {
     const int64_t piv = ctx->h_info[b];
@@ -740,14 +825,24 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
 // (wide, short GEMVs -> thousands of independent rows per launch instead of one long dependent
 // chain).  The pass is HBM-bound: the lower triangle of L is read once per solve.
 int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-                 double* x) {
+                 double* x, const int* refine) {
   const int64_t NB = CHOL_NB;
+  const int64_t nblk = (n + NB - 1) / NB;
+  const double* diag = inv + nblk * NB * NB;
   double* tmp = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)NB * 8, (void**)&tmp));
+  DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)NB * 8 * 2, (void**)&tmp));
+  double* res = tmp + NB;
   for (int64_t c0 = 0; c0 < n; c0 += NB) {
     const int64_t w = (n - c0 < NB) ? n - c0 : NB;
+    const double* Mi = inv + (c0 / NB) * NB * NB;
+    const double* Lbb = diag + (c0 / NB) * NB * NB;
     // x_i <- Linv_ii x_i
-    DFH_TRY(gemv_rows(ctx, inv + (c0 / NB) * NB * NB, w, w, NB, x + c0, 1.0, nullptr, 0.0, tmp));
+    DFH_TRY(gemv_rows(ctx, Mi, w, w, NB, x + c0, 1.0, nullptr, 0.0, tmp));
+    for (int s = 0; s < (refine ? refine[c0 / NB] : 0); ++s) {
+      // res = b_i - L_ii x ; x += Linv_ii res
+      DFH_TRY(gemv_rows(ctx, Lbb, w, w, NB, tmp, -1.0, x + c0, 1.0, res, true));
+      DFH_TRY(gemv_rows(ctx, Mi, w, w, NB, res, 1.0, tmp, 1.0, tmp));
+    }
     DFH_HIP(hipMemcpyAsync(x + c0, tmp, (size_t)w * 8, hipMemcpyDeviceToDevice, ctx->stream));
     // x[i+1:] <- x[i+1:] - L[i+1:, i] x_i
     const int64_t below = n - c0 - w;
@@ -758,16 +853,25 @@ int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const do
 }
 
 int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-                  double* x) {
+                  double* x, const int* refine) {
   const int64_t NB = CHOL_NB;
-  double* tmp = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)NB * 8, (void**)&tmp));
   const int64_t nblk = (n + NB - 1) / NB;
+  const double* diag = inv + nblk * NB * NB;
+  double* tmp = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)NB * 8 * 2, (void**)&tmp));
+  double* res = tmp + NB;
   for (int64_t b = nblk - 1; b >= 0; --b) {
     const int64_t c0 = b * NB;
     const int64_t w = (n - c0 < NB) ? n - c0 : NB;
+    const double* Mi = inv + b * NB * NB;
+    const double* Lbb = diag + b * NB * NB;
     // x_i <- Linv_ii^T x_i
-    DFH_TRY(gemv_cols(ctx, inv + b * NB * NB, w, w, NB, x + c0, 1.0, nullptr, 0.0, tmp));
+    DFH_TRY(gemv_cols(ctx, Mi, w, w, NB, x + c0, 1.0, nullptr, 0.0, tmp));
+    for (int s = 0; s < (refine ? refine[b] : 0); ++s) {
+      // res = b_i - L_ii^T x ; x += Linv_ii^T res
+      DFH_TRY(gemv_cols(ctx, Lbb, w, w, NB, tmp, -1.0, x + c0, 1.0, res));
+      DFH_TRY(gemv_cols(ctx, Mi, w, w, NB, res, 1.0, tmp, 1.0, tmp));
+    }
     DFH_HIP(hipMemcpyAsync(x + c0, tmp, (size_t)w * 8, hipMemcpyDeviceToDevice, ctx->stream));
     // x[:i] <- x[:i] - L[i, :i]^T x_i
     if (c0 > 0) DFH_TRY(gemv_cols(ctx, L + c0 * ldl, w, c0, ldl, x + c0, -1.0, x, 1.0, x));
@@ -779,9 +883,10 @@ int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const d
 constexpr int64_t TRSM_FEW_ROWS = 256;
 
 int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-              double* Kct, int64_t m, int64_t ldk) {
+              double* Kct, int64_t m, int64_t ldk, const int* refine) {
   if (m <= 0 || n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
+  const double* diag = inv + ((n + NB - 1) / NB) * NB * NB;      // clean copies of the diagonal blocks
   double* T = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TMP, (size_t)m * NB * 8, (void**)&T));
   if (m <= TRSM_FEW_ROWS) {
@@ -804,6 +909,13 @@ int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const doubl
         DFH_TRY(gemm_skinny_nt(ctx, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 0.0, nullptr, 0, T, NB));
       else
         DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 0.0, nullptr, 0, T, NB));
+      for (int s = 0; s < (refine ? refine[c0 / NB] : 0); ++s) {
+        // residual in place of the right-hand side (it is overwritten by the solution below anyway):
+        // R <- R - X L_bb^T ; X <- X + R Linv^T
+        const double* Lbb = diag + (c0 / NB) * NB * NB;
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, -1.0, T, NB, Lbb, NB, 1.0, Kct + c0, ldk, Kct + c0, ldk));
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 1.0, T, NB, T, NB));
+      }
       if (skinny_update) {
         DFH_TRY(gemm_skinny_nt(ctx, m, rest, w, -1.0, T, NB, Lpanel, ldl, 1.0, Kct + c0 + w, ldk,
                                Kct + c0 + w, ldk, Kct + c0, ldk));
@@ -821,16 +933,27 @@ int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const doubl
     // T = Kct[:, c0:c0+w] - Vt[:, 0:c0] * L[c0:c0+w, 0:c0]^T      (K = 0 degenerates to a copy)
     DFH_TRY(gemm_f64(ctx, 0, m, w, c0, -1.0, Kct, ldk, L + c0 * ldl, ldl, 1.0, Kct + c0, ldk, T, NB));
     // Vt[:, c0:c0+w] = T * Linv_ii^T
-    DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, T, NB, inv + (c0 / NB) * NB * NB, NB, 0.0,
-                     nullptr, 0, Kct + c0, ldk));
+    const double* Linv = inv + (c0 / NB) * NB * NB;
+    DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, T, NB, Linv, NB, 0.0, nullptr, 0, Kct + c0, ldk));
+    for (int s = 0; s < (refine ? refine[c0 / NB] : 0); ++s) {
+      // T <- T - X L_bb^T (the residual) ; X <- X + T Linv^T
+      const double* Lbb = diag + (c0 / NB) * NB * NB;
+      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, -1.0, Kct + c0, ldk, Lbb, NB, 1.0, T, NB, T, NB));
+      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, T, NB, Linv, NB, 1.0, Kct + c0, ldk, Kct + c0, ldk));
+    }
   }
   return DFH_OK;
 }
 
-int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, double* inv) {
+int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, double* inv, int* refine_out,
+                       double* diag) {
   const int64_t NB = CHOL_NB;
+  const int64_t nblk = (n + NB - 1) / NB;
   double* T = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)NB * NB * 8, (void**)&T));
+  double* d_delta = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_DELTA, (size_t)nblk * 8, (void**)&d_delta));
+  if (!diag) diag = inv + nblk * NB * NB;
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int64_t nbk = (n - k0 < NB) ? n - k0 : NB;
     double* Linv = inv + (k0 / NB) * NB * NB;
@@ -840,14 +963,22 @@ int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, do
                        const_cast<double*>(D), (long)ldl, (int)nbk, Linv, (long)NB, (const double*)nullptr, 0L, 0L, 0L);
     DFH_LAUNCH_CHECK();
     DFH_TRY(assemble_block_inverse(ctx, D, ldl, nbk, Linv, T));
+    DFH_TRY(block_inverse_quality(ctx, D, ldl, nbk, Linv, diag + (k0 / NB) * NB * NB, T, d_delta + k0 / NB));
+  }
+  if (refine_out) {
+    std::vector<double> deltas((size_t)nblk);
+    DFH_HIP(hipMemcpyAsync(deltas.data(), d_delta, (size_t)nblk * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t b = 0; b < nblk; ++b) refine_out[b] = refine_steps(deltas[b]);
   }
   return DFH_OK;
 }
 
 int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-                       double* Bt, int64_t m, int64_t ldb) {
+                       double* Bt, int64_t m, int64_t ldb, const int* refine) {
   if (m <= 0 || n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
+  const double* diag = inv + ((n + NB - 1) / NB) * NB * NB;
   double* T = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TMP, (size_t)m * NB * 8, (void**)&T));
   const int64_t nblk = (n + NB - 1) / NB;
@@ -861,6 +992,11 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
     // Xt[:, c0:c0+w] = T * Linv_ii
     DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, T, NB, inv + b * NB * NB, NB, 0.0, nullptr, 0,
                      Bt + c0, ldb));
+    for (int s = 0; s < (refine ? refine[b] : 0); ++s) {
+      // T <- T - X L_bb (the residual) ; X <- X + T Linv
+      DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, -1.0, Bt + c0, ldb, diag + b * NB * NB, NB, 1.0, T, NB, T, NB));
+      DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, T, NB, inv + b * NB * NB, NB, 1.0, Bt + c0, ldb, Bt + c0, ldb));
+    }
   }
   return DFH_OK;
 }

@@ -114,6 +114,7 @@ enum ScratchSlot {
   SCR_AUG2,
   SCR_OUT,          // device result staging for host outputs
   SCR_OUT2,
+  SCR_DELTA,        // quality of the kept block inverses (one double per diagonal block)
   SCR_COUNT
 };
 
@@ -258,25 +259,34 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
 constexpr int64_t CHOL_NB = 512;
 // nbatch > 1: nbatch independent matrices of the same size at A + b*strideA are factored in lock
 // step (one launch sequence, every kernel batched): the latency-bound pivot chain is paid once.
-// keep_inv is only supported for nbatch == 1; info_pivot has nbatch entries (<= 6).
+// info_pivot has nbatch entries.
+// keep_inv buffers hold inv_buffer_doubles(n) doubles per matrix: the block inverses, then clean
+// copies of the diagonal blocks themselves (lower triangle, zero elsewhere, row stride CHOL_NB).
+// refine_out (host, [nbatch][nblk], optional): iterative-refinement steps a solve should take with
+// each block, from the measured quality max|I - inv L_bb| of its inverse (chol.hip: refine_steps).
+inline int64_t inv_buffer_doubles(int64_t n) { return 2 * ((n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0, int64_t strideKeep = 0);
+                    int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0, int64_t strideKeep = 0,
+                    int* refine_out = nullptr);
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x
+// refine (host, one entry per diagonal block, or null): refinement steps per block, see above
 int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-                 double* x);
+                 double* x, const int* refine = nullptr);
 int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-                  double* x);
+                  double* x, const int* refine = nullptr);
 // Rows-as-RHS solve used by the posterior:  Vt[m x n] <- Kct[m x n] * L^{-T}  (in place),
 // i.e. each row v of Vt satisfies L v = k  (solve_lower_triangular(L, K_tetr.T), gp_core.py:180)
 int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-              double* Kct, int64_t m, int64_t ldk);
+              double* Kct, int64_t m, int64_t ldk, const int* refine = nullptr);
 // Xt[m x n] <- Bt[m x n] * L^{-1} (in place): each row x satisfies L^T x = b
 int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-                       double* Bt, int64_t m, int64_t ldb);
+                       double* Bt, int64_t m, int64_t ldb, const int* refine = nullptr);
 // inverses of the CHOL_NB diagonal blocks of an existing lower factor L (layout as keep_inv)
-int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, double* inv);
+// diag (optional): where the clean diagonal-block copies go (default: right behind the inverses)
+int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, double* inv,
+                       int* refine_out = nullptr, double* diag = nullptr);
 
 // small helpers (elementwise / reductions)
 int fill_f64(dfh_ctx* ctx, double* p, int64_t n, double v);

@@ -523,6 +523,14 @@ class FittedGP(object):
     check(self.engine.lib.dfh_gp_get(self.handle, what, _ptr(out)))
     return out
 
+  def refine_steps(self):
+    """ Iterative-refinement steps the triangular solves take per 512-block of the factor
+        (all zero unless a diagonal block is ill-conditioned; dfh_gp_refine_steps). """
+    nblk = (self.n + 511) // 512
+    out = (C.c_int32 * nblk)()
+    check(self.engine.lib.dfh_gp_refine_steps(self.handle, out))
+    return list(out)
+
   def get_L(self):
     return self._get(GET_L, (self.n, self.n))
 

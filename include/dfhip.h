@@ -197,6 +197,13 @@ int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, con
 /* n x n kernel matrix without noise (GP.K_trtr_wo_noise)        */
 int dfh_gp_get(dfh_gp* gp, int what, double* out);
 int64_t dfh_gp_n(dfh_gp* gp);
+/* Triangular solves with the factor (solve_lower/upper_triangular, utils/general_utils.py:208-221,
+ * as used at gp_core.py:162-163,180) multiply by explicit inverses of the 512 x 512 diagonal
+ * blocks of L; where such an inverse M is not good enough -- max|I - M L_bb| above 1e-13
+ * (DFH_REFINE_TOL), i.e. an ill-conditioned block -- the solves add steps of iterative refinement
+ * against L_bb so that their residual is that of a substitution (dtrtrs).  steps_out
+ * [ceil(n/512)] receives the number of steps per block (0 everywhere for well-conditioned fits). */
+int dfh_gp_refine_steps(dfh_gp* gp, int32_t* steps_out);
 
 /* GP.eval(X_test, 'std') without the mean function (gp_core.py:165-190):
  *   mu_out[m]  = K(Xs, X) alpha           (caller adds mean_func(Xs))
