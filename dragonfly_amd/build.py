@@ -1,6 +1,9 @@
 """Build libdfhip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m dragonfly_amd.build [--force]
+    python -m dragonfly_amd.build [--force] [--debug-hooks]
+
+--debug-hooks also compiles the diagnostics entry points of include/dfhip_debug.h (tools/dbg_*.py);
+the default library exports exactly the C-ABI of include/dfhip.h.
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container;
 the resulting dragonfly_amd/libdfhip.so travels with the repository snapshot to the GPU box.
@@ -38,10 +41,16 @@ def _stale(target, deps):
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, debug_hooks=False):
   """Compile every HIP translation unit for gfx950 and link libdfhip.so. Returns its path."""
   hipcc = _hipcc()
   os.makedirs(OBJ_DIR, exist_ok=True)
+  flags = CXXFLAGS + (['-DDFH_DEBUG_HOOKS'] if debug_hooks else [])
+  stamp = os.path.join(OBJ_DIR, 'flags.txt')
+  if not os.path.exists(stamp) or open(stamp).read() != ' '.join(flags):
+    force = True                   # different flags than the objects on disk were built with
+    with open(stamp, 'w') as f:
+      f.write(' '.join(flags))
   jobs = []
   for src in SOURCES:
     src_path = os.path.join(CSRC, src)
@@ -51,7 +60,7 @@ def build(force=False, verbose=True):
 
   def _compile(job):
     src_path, obj = job
-    cmd = [hipcc] + CXXFLAGS + ['-c', src_path, '-o', obj]
+    cmd = [hipcc] + flags + ['-c', src_path, '-o', obj]
     if verbose:
       print(' '.join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,4 +83,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-  print(build(force='--force' in sys.argv))
+  print(build(force='--force' in sys.argv, debug_hooks='--debug-hooks' in sys.argv))

@@ -217,11 +217,17 @@ struct Halluc {
   double* Lh = nullptr;                           // [q][q] chol(K_hh + noise I - Wt Wt^T)
 };
 
+// The reference factors the whole augmented matrix with stable_cholesky (gp_core.py:199-206).  The
+// block form below gives the same factor as long as that factorisation needs no jitter; when the
+// Schur complement is not positive definite, or the base fit itself needed the ladder (its jitter
+// was chosen for the n x n matrix, the reference would re-run the ladder on the (n+q) x (n+q) one),
+// DFH_ERR_NOT_PD is returned and the callers fall back to halluc_augmented_gp.
 int halluc_prepare(dfh_gp* gp, const double* Xh_user, int64_t q, Halluc* h) {
   dfh_ctx* ctx = gp->ctx;
   h->q = q;
   if (q <= 0) return DFH_OK;
   DFH_ARG(q <= 4096);
+  if (gp->diag_jitter != 0.0) return DFH_ERR_NOT_PD;
   const KernDev& kd = gp->kd;
   const double* Xh = nullptr;
   DFH_TRY(to_device(ctx, Xh_user, (size_t)q * gp->d * 8, SCR_STAGE_C, &Xh));
@@ -239,7 +245,6 @@ int halluc_prepare(dfh_gp* gp, const double* Xh_user, int64_t q, Halluc* h) {
   DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, h->Wt, q, gp->n, gp->refine.data()));
   // S = K(Xh,Xh) + (noise + jitter) I - Wt Wt^T ; Lh = chol(S)
   DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, h->Xhp, h->Nhp, q, true, gp->noise_var, h->Lh, q));
-  if (gp->diag_jitter != 0.0) DFH_TRY(add_diag(ctx, h->Lh, q, q, gp->diag_jitter));
   DFH_TRY(gemm_f64(ctx, 0, q, q, gp->n, -1.0, h->Wt, gp->n, h->Wt, gp->n, 1.0, h->Lh, q, h->Lh, q));
   int64_t piv = 0;
   int rc = cholesky_device(ctx, h->Lh, q, q, nullptr, &piv);
@@ -292,6 +297,14 @@ int posterior_chunk(dfh_gp* gp, const double* Xs_dev, int64_t mc, int64_t ldxs, 
   }
   if (Kct_out) *Kct_out = Kct;
   return DFH_OK;
+}
+
+// Fallback of the hallucinated posterior: the GP over (X, Xh) factored from scratch with the
+// stable_cholesky ladder -- literally gp_core.py:196-206; only its variance is used (the labels
+// are irrelevant: zeros).  The caller frees *aug.
+int halluc_augmented_gp(dfh_gp* gp, const double* Xh, int64_t q, dfh_gp** aug) {
+  std::vector<double> y0((size_t)(gp->n + q), 0.0);
+  return dfh_gp_append(gp, Xh, q, y0.data(), 0, aug, nullptr, nullptr);
 }
 
 int ladder_pow(int p, double max_M, double* out) {
@@ -1102,12 +1115,22 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
   dfh_ctx* ctx = gp->ctx;
   DFH_HIP(hipSetDevice(ctx->device));
   Halluc h;
-  if (q > 0 && want_var) DFH_TRY(halluc_prepare(gp, Xh, q, &h));
-  const int64_t mc_max = pick_chunk(gp->n, m);
+  dfh_gp* aug = nullptr;                    // set when the variance comes from the re-factored augmented GP
+  if (q > 0 && want_var) {
+    int rc = halluc_prepare(gp, Xh, q, &h);
+    if (rc == DFH_ERR_NOT_PD) {
+      h.q = 0;
+      rc = halluc_augmented_gp(gp, Xh, q, &aug);
+    }
+    DFH_TRY(rc);
+  }
+  struct AugGuard { dfh_gp* g; ~AugGuard() { if (g) dfh_gp_free(g); } } aug_guard{nullptr};
+  aug_guard.g = aug;
+  const int64_t mc_max = pick_chunk(gp->n + (aug ? q : 0), m);
   const bool xs_dev = is_device_ptr(Xs);
   const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
   double* vec = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 6, (void**)&vec));
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 7, (void**)&vec));
   double* mu_raw = vec; double* ss = vec + mc_max; double* ss2 = vec + 2 * mc_max;
   double* mu_c = vec + 3 * mc_max; double* sd_c = vec + 4 * mc_max; double* val_c = vec + 5 * mc_max;
   bool have = false; double bv = 0.0; int64_t bi = -1;
@@ -1122,7 +1145,13 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
       if (mv_dev) mv_c = mean_vals + i0;
       else DFH_TRY(to_device(ctx, mean_vals + i0, (size_t)mc * 8, SCR_STAGE_D, &mv_c));
     }
-    DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, want_var, &h, nullptr, mu_raw, ss, ss2));
+    if (aug) {
+      // mean from the real data, variance from the augmented factor (gp_core.py:195, 207-213)
+      DFH_TRY(posterior_chunk(aug, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, true, nullptr, nullptr, vec + 6 * mc_max, ss, ss2));
+      DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, false, nullptr, nullptr, mu_raw, nullptr, nullptr));
+    } else {
+      DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, want_var, &h, nullptr, mu_raw, ss, ss2));
+    }
     {
       SectionTimer t(ctx, DFH_T_ACQ);
       const bool need_val = vals_out || best_val || best_idx;
@@ -1266,7 +1295,19 @@ extern "C" int dfh_gp_predict_covar(dfh_gp* gp, const double* Xs, int64_t m, con
   DFH_HIP(hipSetDevice(ctx->device));
   const KernDev& kd = gp->kd;
   Halluc h;
-  if (q > 0) DFH_TRY(halluc_prepare(gp, Xh, q, &h));
+  if (q > 0) {
+    const int rc = halluc_prepare(gp, Xh, q, &h);
+    if (rc == DFH_ERR_NOT_PD) {
+      // covariance from the augmented GP factored from scratch, mean from the real data
+      dfh_gp* aug = nullptr;
+      DFH_TRY(halluc_augmented_gp(gp, Xh, q, &aug));
+      int rc2 = dfh_gp_predict_covar(aug, Xs, m, nullptr, 0, mu_out, cov_out);
+      dfh_gp_free(aug);
+      DFH_TRY(rc2);
+      return dfh_gp_predict(gp, Xs, m, nullptr, 0, mu_out, nullptr);
+    }
+    DFH_TRY(rc);
+  }
   const double* dXs = nullptr;
   DFH_TRY(to_device(ctx, Xs, (size_t)m * gp->d * 8, SCR_STAGE_A, &dXs));
   double* vec = nullptr;
@@ -1453,6 +1494,7 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   return DFH_OK;
 }
 
+#ifdef DFH_DEBUG_HOOKS      // diagnostics: built only with `python -m dragonfly_amd.build --debug-hooks` (include/dfhip_debug.h)
 // Diagnostics hook (not part of the product path): do kernels on the bulk stream and on the main /
 // panel streams actually run concurrently?  Enqueues `n_big` large GEMMs on stream A and `n_small`
 // tiny kernels on stream B and reports the time of each alone and together.
@@ -1542,3 +1584,4 @@ extern "C" int dfh_debug_write_bw(dfh_ctx* ctx, double gbytes, double* out /*[3]
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return DFH_OK;
 }
+#endif  // DFH_DEBUG_HOOKS

@@ -1001,6 +1001,7 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
   return DFH_OK;
 }
 
+#ifdef DFH_DEBUG_HOOKS      // diagnostics: built only with `python -m dragonfly_amd.build --debug-hooks` (include/dfhip_debug.h)
 // Diagnostics hook (not part of the product path): times `reps` back-to-back launches of the
 // 64-wide diagonal step on a synthetic SPD block and returns in-kernel cycle stamps.
 extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, double* ms_per_launch,
@@ -1042,3 +1043,4 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return DFH_OK;
 }
+#endif  // DFH_DEBUG_HOOKS

@@ -297,11 +297,12 @@ int scratch_get(dfh_ctx* ctx, int slot, size_t bytes, void** out) {
       DFH_HIP(hipStreamSynchronize(ctx->side));
       DFH_HIP(hipStreamSynchronize(ctx->bulk));
       DFH_HIP(hipStreamSynchronize(ctx->aux));
-  DFH_HIP(hipStreamSynchronize(ctx->aux));
       DFH_HIP(hipFree(b.p));
       b.p = nullptr; b.bytes = 0;
     }
-    size_t want = bytes < 256 ? 256 : bytes;
+    // growing slots get the pool's capacity classes (powers of two up to 4 MiB, multiples of 2 MiB
+    // beyond): a sequence of slowly growing n / m does not pay a device-wide sync + hipMalloc per call
+    size_t want = pool_capacity(bytes);
     DFH_HIP(hipMalloc(&b.p, want));
     b.bytes = want;
   }

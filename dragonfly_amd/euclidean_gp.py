@@ -238,6 +238,17 @@ class EuclideanGPFitter(object):
         raise NotImplementedError(
             'hp_tune_criterion=%s is a serial host-side MCMC in the reference and is not part of '
             'the device engine; use dragonfly_amd.install under Dragonfly for it.' % (method))
+    # probabilities of the tuning methods (gp_core.py:365-378); stand-alone only 'ml' exists, so the
+    # 'adaptive' weights never move -- but the draw in get_next_gp still consumes one uniform
+    probs = self.options.hp_tune_probs
+    n_methods = len(self.methods_to_use)
+    if probs in ('uniform', 'adaptive'):
+      self.hp_tune_probs = np.ones(n_methods) / float(n_methods)
+    else:
+      self.hp_tune_probs = np.array([float(x) for x in probs.split('-')])
+      if len(self.hp_tune_probs) != n_methods:
+        self.hp_tune_probs = np.ones(n_methods) / float(n_methods)
+    self.hp_tune_probs = self.hp_tune_probs / self.hp_tune_probs.sum()
     self.cts_hp_bounds = np.array(self.cts_hp_bounds)
     self.num_hps = len(self.cts_hp_bounds) + len(self.dscr_hp_vals)
     self._set_up_ml_hp_tune()
@@ -507,7 +518,8 @@ class EuclideanGPFitter(object):
 
   def get_next_gp(self):
     """ gp_core.py:728-741 """
-    method = np.random.choice(self.methods_to_use)
+    # p= as in the reference: it draws one uniform even for a single method (the no-p form does not)
+    method = np.random.choice(self.methods_to_use, p=self.hp_tune_probs)
     fit_type = self.hp_tune_results[method][0]
     if fit_type == 'fitted_gp':
       gp = self.hp_tune_results[method][1]

@@ -375,8 +375,12 @@ def asy_ttei(gp, anc_data):
 
 # Random ---------------------------------------------------------------------------------------
 def asy_rand(_, anc_data):
-  """ gpb_acquisitions.py:301-306: maximise a random acquisition. """
-  return maximise_acquisition(lambda _x: np.random.random((1,)), anc_data)
+  """ gpb_acquisitions.py:301-306: maximise a random acquisition.  The reference's objective
+      returns ONE random number per call and is called point by point by its tree searches; the
+      batched searches here hand over k points per call and get k numbers back (the 'rand'
+      maximiser's single call with all candidates still draws one, as in the reference). """
+  vectorised = anc_data.acq_opt_method == 'rand'
+  return maximise_acquisition(lambda x: np.random.random((1,) if vectorised else (len(x),)), anc_data)
 
 
 # Synchronous versions (gpb_acquisitions.py:129, 191, 225, 241, 263, 296, 308) -------------------

@@ -1,0 +1,25 @@
+/*
+ * dfhip_debug.h -- diagnostics hooks of libdfhip.so.  NOT part of the product C-ABI (include/dfhip.h):
+ * they exist only in a library built with -DDFH_DEBUG_HOOKS (`python -m dragonfly_amd.build
+ * --debug-hooks`), are used by tools/dbg_*.py during kernel work, and replace nothing in the
+ * reference.
+ */
+#ifndef DFHIP_DEBUG_H
+#define DFHIP_DEBUG_H
+#include "dfhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Do kernels of two streams of one context run concurrently?  which: 0 = bulk vs main, 1 = main vs
+ * panel, 2 = bulk vs panel.  out_ms[4]: big alone, small alone, small-stream completion when both
+ * run, packed total/priorities.                                                                */
+int dfh_debug_overlap(dfh_ctx* ctx, int which, int n_big, int n_small, double* out_ms);
+/* Achievable HBM bandwidth of plain kernels: out[3] = 16-byte fill, hipMemset, copy (TB/s).      */
+int dfh_debug_write_bw(dfh_ctx* ctx, double gbytes, double* out);
+/* `reps` back-to-back launches of the 64-wide pivot step of the Cholesky factorisation on a
+ * synthetic block: ms per launch and in-kernel cycle stamps.                                    */
+int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, double* ms_per_launch, long long* cycles_out);
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFHIP_DEBUG_H */

@@ -23,6 +23,8 @@ import numpy as np
 REF = os.environ.get('DRAGONFLY_REFERENCE', '/root/reference')
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+if os.path.dirname(HERE) not in sys.path:       # `python oracle/make_golden.py` from anywhere: oracle.* importable
+  sys.path.insert(0, os.path.dirname(HERE))
 
 
 def import_reference():
@@ -352,6 +354,131 @@ def gen_slice_cases():
   print('wrote slice_cases')
 
 
+def gen_trajectory_case():
+  """ A multi-step run of the reference's EuclideanGPBandit (opt/gp_bandit.py:551) on Branin in
+      ask/tell mode, with the book-keeping of its main loop (exd/exd_core.py:706-725: set the next
+      GP before every step, a new model every few steps) driven by hand: every call that crosses a
+      seam is recorded IN ORDER with the global RNG state before and after it --
+        fit      EuclideanGPFitter.fit_gp_for_gp_bandit      (S3: data, options)
+        next_gp  EuclideanGPFitter.get_next_gp               (S3: the GP's hyper-parameters)
+        add      GP.add_data_multiple                        (S2)
+        acq      gpb_acquisitions.asy.<ucb|ei|ts|ttei>      (S4: anc_data, the chosen point)
+      tests/test_gpu_trajectory.py replays the events through the mirrors on the MI355X. """
+  import json
+  from dragonfly.opt import gp_bandit
+  from dragonfly.opt import gpb_acquisitions as A
+  from dragonfly.gp import euclidean_gp as EG
+  from dragonfly.gp import gp_core as GC
+  from dragonfly.exd.domains import EuclideanDomain
+  from dragonfly.exd.experiment_caller import EuclideanFunctionCaller
+  from dragonfly.utils.option_handler import load_options
+  from dragonfly.utils.euclidean_synthetic_functions import get_mf_branin_function
+  branin = get_mf_branin_function(1)[1]
+  events = []
+
+  def st():
+    s = np.random.get_state()
+    return [[int(v) for v in s[1]], int(s[2]), int(s[3]), float(s[4])]
+
+  def plain(v):
+    if isinstance(v, (bool, int, float, str)) or v is None:
+      return v
+    if isinstance(v, (np.integer,)):
+      return int(v)
+    if isinstance(v, (np.floating,)):
+      return float(v)
+    return None
+
+  def gp_desc(gp):
+    k = gp.kernel
+    return dict(kernel=type(k).__name__, nu=float(k.hyperparams.get('nu', 0.0) or 0.0),
+                scale=float(k.hyperparams['scale']),
+                bw=[float(b) for b in np.ravel(k.hyperparams['dim_bandwidths'])],
+                noise=float(gp.noise_var), mean=float(gp.mean_func([np.zeros(k.dim)])[0]), n=int(gp.num_tr_data))
+
+  orig_fit, orig_next = EG.EuclideanGPFitter.fit_gp_for_gp_bandit, EG.EuclideanGPFitter.get_next_gp
+  orig_add = GC.GP.add_data_multiple
+  orig_acq = {name: getattr(A.asy, name) for name in ('ucb', 'ei', 'ts', 'ttei')}
+
+  def fit_spy(self, num_samples=1):
+    ev = dict(type='fit', before=st(), X=[[float(v) for v in x] for x in self.X], Y=[float(y) for y in self.Y],
+              num_samples=int(num_samples),
+              options={k: plain(v) for k, v in vars(self.options).items() if plain(v) is not None or v is None})
+    events.append(ev)
+    ret = orig_fit(self, num_samples)
+    ev['after'] = st()
+    return ret
+
+  def next_spy(self):
+    ev = dict(type='next_gp', before=st())
+    events.append(ev)
+    ret = orig_next(self)
+    ev.update(after=st(), fit_type=ret[0], method=ret[1], gp=gp_desc(ret[2]))
+    return ret
+
+  def add_spy(self, X_new, Y_new):
+    events.append(dict(type='add', X=[[float(v) for v in x] for x in X_new], Y=[float(y) for y in Y_new]))
+    return orig_add(self, X_new, Y_new)
+
+  def acq_spy(name):
+    def spy(gp, anc):
+      ev = dict(type='acq', acq=name, before=st(), gp=gp_desc(gp),
+                anc=dict(max_evals=int(anc.max_evals), t=int(anc.t), curr_max_val=float(anc.curr_max_val),
+                         acq_opt_method=str(anc.acq_opt_method), handle_parallel=str(anc.handle_parallel),
+                         bounds=[[float(a), float(b)] for a, b in anc.domain.bounds],
+                         in_progress=[[float(v) for v in x] for x in anc.eval_points_in_progress]))
+      events.append(ev)
+      pt = orig_acq[name](gp, anc)
+      ev.update(after=st(), point=[float(v) for v in pt])
+      return pt
+    return spy
+
+  opts = load_options(gp_bandit.get_all_euc_gp_bandit_args())
+  opts.kernel_type = 'matern'
+  opts.acq = 'ucb-ei-ts-ttei'
+  opts.acq_opt_method = 'rand'
+  opts.acq_opt_max_evals = 400
+  opts.gpb_hp_tune_criterion = 'ml'
+  opts.gpb_ml_hp_tune_opt = 'rand'
+  opts.hp_tune_max_evals = 40
+  opts.build_new_model_every = 4
+  EG.EuclideanGPFitter.fit_gp_for_gp_bandit = fit_spy
+  EG.EuclideanGPFitter.get_next_gp = next_spy
+  GC.GP.add_data_multiple = add_spy
+  for name in orig_acq:
+    setattr(A.asy, name, acq_spy(name))
+  try:
+    np.random.seed(31415)
+    caller = EuclideanFunctionCaller(None, EuclideanDomain([[-5, 10], [0, 15]]))
+    opt = gp_bandit.EuclideanGPBandit(caller, ask_tell_mode=True, options=opts, reporter='silent')
+    opt.initialise()
+    Xraw = np.random.RandomState(7).random_sample((12, 2)) * np.array([15.0, 15.0]) + np.array([-5.0, 0.0])
+    opt.tell([(x, branin(x)) for x in Xraw])
+    opt.first_qinfos = []
+    asked = []
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      for it in range(14):
+        opt.step_idx = 12 + it
+        if it % opts.build_new_model_every == 0:
+          opt._build_new_model()          # pylint: disable=protected-access
+        opt._set_next_gp()                # pylint: disable=protected-access  (exd_core.py: _main_loop_pre)
+        x = np.array(opt.ask())
+        asked.append(x)
+        opt.tell([(x, branin(x))])
+  finally:
+    EG.EuclideanGPFitter.fit_gp_for_gp_bandit, EG.EuclideanGPFitter.get_next_gp = orig_fit, orig_next
+    GC.GP.add_data_multiple = orig_add
+    for name, fn in orig_acq.items():
+      setattr(A.asy, name, fn)
+  blob = np.frombuffer(json.dumps(events).encode('utf-8'), dtype=np.uint8)
+  np.savez_compressed(os.path.join(OUT, 'trajectory_branin.npz'), events_json=blob, asked=np.array(asked))
+  kinds = [e['type'] for e in events]
+  print('wrote trajectory_branin: %d events (%s), acquisitions used: %s'
+        % (len(events), ', '.join('%s x%d' % (k, kinds.count(k)) for k in sorted(set(kinds))),
+           [e['acq'] for e in events if e['type'] == 'acq']))
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   import_reference()
@@ -364,9 +491,13 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'pdoo':
     gen_pdoo_cases()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':
+    gen_trajectory_case()
+    sys.exit(0)
   gen_gp_cases()
   gen_fitter_case()
   gen_c1_case()
   gen_mfgp_case()
   gen_pdoo_cases()
   gen_slice_cases()
+  gen_trajectory_case()

@@ -58,3 +58,14 @@ def test_no_device_fails_loudly():
   import numpy as np
   with pytest.raises(_lib.DfhipError):
     K.SEKernel(2, 1.0, [0.3, 0.3])(np.zeros((3, 2)))
+
+
+def test_library_exports_nothing_beyond_the_header():
+  """ every exported dfh_* symbol is declared in include/dfhip.h (diagnostics hooks live behind
+      -DDFH_DEBUG_HOOKS / include/dfhip_debug.h and are absent from the product build) """
+  import shutil
+  import subprocess
+  nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+  out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+  exported = sorted(set(re.findall(r'\bT (dfh_[a-z0-9_]+)\b', out)))
+  assert exported == declared_functions()

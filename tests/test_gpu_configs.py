@@ -11,22 +11,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-def hartmann6(X):
-  """ Hartmann-6 on the unit cube, the usual constants (the reference defines the same function in
-      exd/../euclidean_synthetic_functions.py:16-49); only used to produce O(1) synthetic targets. """
-  A = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14],
-                [3, 3.5, 1.7, 10, 17, 8], [17, 8, 0.05, 10, 0.1, 14]], dtype=float)
-  P = 1e-4 * np.array([[1312, 1696, 5569, 124, 8283, 5886], [2329, 4135, 8307, 3736, 1004, 9991],
-                       [2348, 1451, 3522, 2883, 3047, 6650], [4047, 8828, 8732, 5743, 1091, 381]], dtype=float)
-  alpha = np.array([1.0, 1.2, 3.0, 3.2])
-  inner = (A[None, :, :] * (X[:, None, :] - P[None, :, :]) ** 2).sum(axis=2)
-  return (alpha[None, :] * np.exp(-inner)).sum(axis=1)
-
-
-def park1(X4):
-  """ Park function 1 on [0,1]^4 (synthetic targets for the additive config). """
-  x1, x2, x3, x4 = [np.maximum(X4[:, i], 1e-6) for i in range(4)]
-  return -((x1 / 2) * (np.sqrt(1 + (x2 + x3 ** 2) * x4 / x1 ** 2) - 1) + (x1 + 3 * x4) * np.exp(1 + np.sin(x3)))
+from bench_configs import hartmann6, park1      # noqa: E402,F401  (one definition of the synthetic inputs)
 
 
 def test_config2_hartmann6_matern_ei_full_size(engine):

@@ -218,3 +218,33 @@ def test_additive_gp_and_add_ucb_groups(engine):
     bv, bi, vals = gp.add_ucb_group(j, beta, Xj, return_vals=True)
     vr = O.add_ucb_group_values(og, j, Xj, n)
     assert relerr(vals, vr) < 1e-9 and bi == int(np.argmax(vr))
+
+
+@pytest.mark.parametrize('noise_frac', [1e-13, 1e-9])
+def test_hallucination_when_the_augmented_matrix_needs_the_ladder(engine, noise_frac):
+  """ gp_core.py:199-206 factors the WHOLE augmented matrix with stable_cholesky.  A tiny fixed
+      noise variance with a pending point that duplicates a training point makes the augmented
+      matrix numerically singular (and at 1e-13 the base fit already needs the ladder): the
+      device re-factors the augmented matrix with the ladder as the reference does instead of
+      giving up (round-1 advisor finding).  Values agree to what such a matrix allows. """
+  from dragonfly_amd.engine import KernelSpec
+  rs = np.random.RandomState(5)
+  n, d, m = 60, 2, 40
+  X = rs.rand(n, d)
+  Y = np.sin(3 * X.sum(axis=1))
+  scale, bw = float(Y.var()), np.full(d, 0.3)
+  noise = noise_frac * scale
+  og = O.GPOracle(X, Y, O.KernelSpec('se', d, scale, bw), 0.0, noise)
+  gp = engine.gp_fit(KernelSpec('se', d, scale, bw), X, Y, noise)
+  assert gp.jitter_power == og.jitter_power
+  Xh = np.vstack([X[7], rs.rand(d)])            # one duplicate of a training point, one fresh point
+  Xs = rs.rand(m, d)
+  mu_o, sd_o = og.eval_with_hallucinated_observations(Xs, Xh)
+  mu_d, sd_d = gp.predict(Xs, X_halluc=Xh)
+  assert relerr(mu_d, mu_o) < 1e-6
+  assert np.all(np.isfinite(sd_d) == np.isfinite(sd_o))
+  ok = np.isfinite(sd_o)
+  assert relerr(sd_d[ok], sd_o[ok]) < 1e-3
+  _, cov_o = og.eval_with_hallucinated_observations(Xs, Xh, 'covar')
+  _, cov_d = gp.predict_covar(Xs, X_halluc=Xh)
+  assert relerr(cov_d, cov_o) < 1e-3

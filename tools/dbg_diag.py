@@ -1,3 +1,4 @@
+# needs a library built with the diagnostics hooks: python -m dragonfly_amd.build --force --debug-hooks (include/dfhip_debug.h)
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dragonfly_amd.engine import Engine
