@@ -18,6 +18,7 @@
 #include <cstring>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -79,15 +80,44 @@ __device__ __forceinline__ double exp_fast(double x, const ExpConsts& ec) {
   return ldexp(p, (int)fmax(fmin(n, 4000.0), -4000.0));
 }
 
+// exp(x) for x <= 0 without the exponent clamp of exp_fast: v_cvt_i32_f64 saturates, and v_ldexp_f64
+// with a hugely negative exponent returns 0 (what exp of such an x rounds to); NaN propagates
+__device__ __forceinline__ double exp_fast_neg(double x, const ExpConsts& ec) {
+  const double n = rint(x * ec.log2e);
+  double r = fma(-n, ec.ln2_hi, x);
+  r = fma(-n, ec.ln2_lo, r);
+  double p = ec.c[0];
+#pragma unroll
+  for (int i = 1; i < 12; ++i) p = fma(p, r, ec.c[i]);
+  return ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double sqrt_fast(double d) {
+  // rsq + two Goldschmidt steps: <= 1 ulp on the range a clipped squared distance has; sqrt(0) = 0
+  const double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  return d > 0.0 ? g : d;               // d == 0 -> 0 ; NaN -> NaN
+}
+
 __device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq, const ExpConsts& ec) {
   if (pd.kind == DFH_KERNEL_SE) {
     return pd.scale_c * exp_fast(-dsq / 2, ec);                // kernel.py:176
   } else if (pd.kind == DFH_KERNEL_MATERN) {
-    const double dist = sqrt(dsq);                         // kernel.py:296
+    const double dist = sqrt_fast(dsq);                    // kernel.py:296 (<= 1 ulp)
     const double mult = pd.s8 * dist;                      // kernel.py:265
-    double u = 0.0;
-    for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * ipow(mult, pd.p - i);   // kernel.py:266
-    u *= (pd.gfac * exp_fast(-pd.s2 * dist, ec));              // kernel.py:268-269
+    double u;                                              // sum_i coeff_i mult^(p-i), kernel.py:266 (Horner)
+    if (pd.p == 0) u = pd.coeff[0];
+    else if (pd.p == 1) u = fma(pd.coeff[0], mult, pd.coeff[1]);
+    else if (pd.p == 2) u = fma(fma(pd.coeff[0], mult, pd.coeff[1]), mult, pd.coeff[2]);
+    else {
+      u = 0.0;
+      for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * ipow(mult, pd.p - i);
+    }
+    u *= (pd.gfac * exp_fast_neg(-pd.s2 * dist, ec));      // kernel.py:268-269
     return pd.scale_c * u;                                 // kernel.py:298
   }
   return dsq;                                              // DFH_KERNEL_DIST
@@ -379,6 +409,181 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Cross matrix K(X1, X2), single-part SE / Matern kernels, packed width 8..32: "strip" kernel.
+//
+// What was measured on gfx950 (tools/km_bench.hip, 32768 x 16384, d = 32): the fp64 MFMA work of
+// the distance expansion alone takes 0.56 ms, the fp64 VALU epilogue (clip, exp) alone 0.43 ms,
+// both together 0.89 ms -- fp64 matrix and fp64 vector instructions share the SIMD's fp64 pipe on
+// this part, they do not overlap -- and the 4.3 GB of output 0.72 ms.  The pass is bound by that
+// pipe, so the kernel is organised to keep it fed: no LDS, no barriers, a wave keeps the operand
+// fragments of its 64 rows in registers and walks along the columns in tiles of 32, loading the
+// next tile's column fragments a whole tile ahead (register double buffer) while the current tile
+// runs its 16 * C MFMAs and its epilogue; stores are fire-and-forget.
+// Operand fragments come straight from L2: lane (l15, l4) of an MFMA holds, for row l15 of a
+// 16-row tile, the packed columns [l4 * C, (l4 + 1) * C) -- which k of the dot product sits in
+// which MFMA slot is free as long as both operands agree -- i.e. contiguous 16-byte loads.
+// Same expansion as the reference ((|a|^2 + |b|^2) - 2 a.b, clipped at 0; general_utils.py:66-69),
+// only the summation order inside a.b differs from the LDS kernel's.
+// The 64 x 64-tile LDS kernel (kernmat_sym_kernel<..., false>) took 1.45 ms on this shape and
+// 1.14 ms for 65536 x 4096 at d = 6, this one 1.2 ms and 0.47 ms.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int C, int MP>
+__global__ __launch_bounds__(256, (C <= 4 ? 2 : 1)) void kernmat_strip_kernel(KmArgs p, int tiles_per_seg) {
+  constexpr int WI = 4, WJ = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long m0 = ((long)blockIdx.y * 4 + wave) * 64;
+  if (m0 >= p.n1) return;
+  const long ntile = ((long)p.n2 + 16 * WJ - 1) / (16 * WJ);
+  const long t0 = (long)blockIdx.x * tiles_per_seg;
+  const long t1 = t0 + tiles_per_seg < ntile ? t0 + tiles_per_seg : ntile;
+  if (t0 >= t1) return;
+  const PartDev& pd = p.parts[p.part_lo];
+  const ExpConsts& ec = p.ec;              // SE: scale_c already folded into the coefficients
+  const int npt = p.n_parts_total, part = p.part_lo;
+  const double* __restrict__ A = p.Xp1 + pd.poff + l4 * C;
+  const double* __restrict__ B = p.Xp2 + pd.poff + l4 * C;
+  double a[WI][C];
+  double nah[WI][4];                       // SE: |a|^2 / 2 ; Matern: |a|^2
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    long row = m0 + i * 16 + l15;
+    row = row < p.n1 ? row : p.n1 - 1;
+    const double* src = A + row * p.P;
+#pragma unroll
+    for (int c = 0; c < C; c += 2) {
+      const double2_t v = *reinterpret_cast<const double2_t*>(src + c);
+      a[i][c] = v.x; a[i][c + 1] = v.y;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      long rr = m0 + i * 16 + l4 + 4 * r;
+      rr = rr < p.n1 ? rr : p.n1 - 1;
+      const double v = p.Np1[rr * npt + part];
+      nah[i][r] = KIND == DFH_KERNEL_SE ? 0.5 * v : v;
+    }
+  }
+  // Matern constants (uniform)
+  constexpr int mp = MP;                   // Matern: int(nu), compile time
+  const double s8 = pd.s8, s2 = pd.s2, gsc = pd.scale_c * pd.gfac;
+  const double c0 = pd.coeff[0], c1 = pd.coeff[1], c2 = pd.coeff[2], c3 = pd.coeff[3];
+  double b[WJ][C], nbh[WJ];
+  auto load_b = [&](long t, double (&bb)[WJ][C], double (&nn)[WJ]) {
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      // MFMA tile j, lane column l15 <-> matrix column n0 + 2 l15 + j: a lane then owns two ADJACENT
+      // columns of every row it holds and stores them with one 16-byte instruction
+      long col = t * (16 * WJ) + 2 * l15 + j;
+      col = col < p.n2 ? col : p.n2 - 1;
+      const double* src = B + col * p.P;
+#pragma unroll
+      for (int c = 0; c < C; c += 2) {
+        const double2_t v = *reinterpret_cast<const double2_t*>(src + c);
+        bb[j][c] = v.x; bb[j][c + 1] = v.y;
+      }
+      const double v = p.Np2[col * npt + part];
+      nn[j] = KIND == DFH_KERNEL_SE ? 0.5 * v : v;
+    }
+  };
+  // per-lane element offset inside a 4-row group: the store address is a wave-uniform row-group base
+  // plus this
+  const unsigned voff = (unsigned)(l4 * p.ldk + 2 * l15);
+  double* __restrict__ Kstrip = p.K + m0 * p.ldk;
+  const bool rows_full = m0 + 64 <= p.n1;
+  load_b(t0, b, nbh);
+  for (long t = t0; t < t1; ++t) {
+    double bn[WJ][C], nbn[WJ];
+    load_b(t + 1 < t1 ? t + 1 : t, bn, nbn);
+    double4_t acc[WI][WJ];
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c], b[j][c], acc[i][j], 0, 0, 0);
+    const long n0 = t * (16 * WJ);
+    double* __restrict__ Kt = Kstrip + n0;
+    auto epilogue = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double kvs[WJ];
+#pragma unroll
+          for (int j = 0; j < WJ; ++j) {
+            double kv;
+            if (KIND == DFH_KERNEL_SE) {
+              // -dsq/2 directly: acc - (|b|^2/2 + |a|^2/2), clipped at 0 (scaling by 2 commutes with
+              // rounding: the same number as ((nb + na) - 2 acc) clipped, halved and negated)
+              double tt = acc[i][j][r] - (nbh[j] + nah[i][r]);
+              tt = tt > 0.0 ? 0.0 : tt;
+              kv = exp_fast_neg(tt, ec);                               // kernel.py:176, scale inside ec
+            } else {
+              double dsq = (nbh[j] + nah[i][r]) - 2.0 * acc[i][j][r];   // general_utils.py:66-68
+              dsq = dsq < 0.0 ? 0.0 : dsq;
+              const double dist = sqrt_fast(dsq);                       // kernel.py:296
+              const double mult = s8 * dist;                            // kernel.py:265
+              double u;                                                 // sum_i coeff_i mult^(p-i), kernel.py:266
+              if (mp == 0) u = c0;
+              else if (mp == 1) u = fma(c0, mult, c1);
+              else if (mp == 2) u = fma(fma(c0, mult, c1), mult, c2);
+              else u = fma(fma(fma(c0, mult, c1), mult, c2), mult, c3);
+              kv = u * (gsc * exp_fast_neg(-s2 * dist, ec));             // kernel.py:268-269, 298
+            }
+            kvs[j] = kv;
+          }
+          double* __restrict__ rowp = Kt + (long)(i * 16 + 4 * r) * p.ldk;      // wave-uniform
+          if (FULL) {
+            *reinterpret_cast<double2_t*>(rowp + voff) = (double2_t){kvs[0], kvs[1]};
+          } else {
+            const long row = m0 + i * 16 + l4 + 4 * r, col = n0 + 2 * l15;
+            if (row < p.n1 && col < p.n2) rowp[voff] = kvs[0];
+            if (row < p.n1 && col + 1 < p.n2) rowp[voff + 1] = kvs[1];
+          }
+        }
+      }
+    };
+    if (rows_full && n0 + 16 * WJ <= p.n2) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      nbh[j] = nbn[j];
+#pragma unroll
+      for (int c = 0; c < C; ++c) b[j][c] = bn[j][c];
+    }
+  }
+}
+
+template <int KIND, int MP>
+int launch_strip(dfh_ctx* ctx, KmArgs a, int C) {
+  // enough waves for 256 CUs x 4 SIMDs x 2: split the columns of a 64-row strip into segments
+  const long strips = ((long)a.n1 + 63) / 64;
+  const long ntile = ((long)a.n2 + 31) / 32;
+  long segs = (4096 + strips - 1) / strips;
+  if (segs > ntile) segs = ntile;
+  if (segs < 1) segs = 1;
+  const int tps = (int)((ntile + segs - 1) / segs);
+  segs = (ntile + tps - 1) / tps;
+  dim3 grid((unsigned)segs, (unsigned)((strips + 3) / 4));
+  switch (C) {
+    case 2: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 2, MP>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+    case 4: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 4, MP>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+    case 6: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 6, MP>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+    default: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 8, MP>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+  }
+  DFH_LAUNCH_CHECK();
+  return DFH_OK;
 }
 
 // ---- packing -----------------------------------------------------------------------------
@@ -1046,6 +1251,22 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
         hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7, true>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem_bytes(64, 16, 32), ctx->stream, a);
       }
     } else {
+      // strip kernel: SE / Matern (nu = 0.5, 1.5, 2.5), packed width 8 / 16 / 24 / 32, 32-bit in-strip offsets
+      static const bool strip_on = []() { const char* e = getenv("DFH_KM_STRIP"); return e ? atoi(e) != 0 : true; }();
+      const PartDev& hp = kd.parts[part_lo];
+      const bool strip_ok = strip_on && (hp.kind == DFH_KERNEL_SE || (hp.kind == DFH_KERNEL_MATERN && hp.p <= 2)) &&
+                            hp.kc >= 8 && hp.kc <= 32 && hp.kc % 8 == 0 && kd.P % 2 == 0 && hp.poff % 2 == 0 &&
+                            64 * ldk + 64 < (1LL << 31) && (n1 + 255) / 256 <= 65535 &&
+                            (reinterpret_cast<uintptr_t>(Xp1) & 15) == 0 && (reinterpret_cast<uintptr_t>(Xp2) & 15) == 0;
+      if (strip_ok) {
+        if (hp.kind == DFH_KERNEL_SE) {
+          for (int i = 0; i < 12; ++i) a.ec.c[i] *= hp.scale_c;      // scale folded into the exp polynomial
+          return launch_strip<DFH_KERNEL_SE, 0>(ctx, a, hp.kc / 4);
+        }
+        if (hp.p == 0) return launch_strip<DFH_KERNEL_MATERN, 0>(ctx, a, hp.kc / 4);
+        if (hp.p == 1) return launch_strip<DFH_KERNEL_MATERN, 1>(ctx, a, hp.kc / 4);
+        return launch_strip<DFH_KERNEL_MATERN, 2>(ctx, a, hp.kc / 4);
+      }
       dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64));
       hipLaunchKernelGGL((kernmat_sym_kernel<64, 16, 32, 7, false>), grid, dim3(256), smem_bytes(64, 16, 32), ctx->stream, a);
     }
