@@ -420,24 +420,26 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
 // both together 0.89 ms -- fp64 matrix and fp64 vector instructions share the SIMD's fp64 pipe on
 // this part, they do not overlap -- and the 4.3 GB of output 0.72 ms.  The pass is bound by that
 // pipe, so the kernel is organised to keep it fed: no LDS, no barriers, a wave keeps the operand
-// fragments of its 64 rows in registers and walks along the columns in tiles of 32, loading the
+// fragments of its 32 rows in registers and walks along the columns in tiles of 64, loading the
 // next tile's column fragments a whole tile ahead (register double buffer) while the current tile
-// runs its 16 * C MFMAs and its epilogue; stores are fire-and-forget.
+// runs its 8 * C MFMAs and its epilogue; stores are fire-and-forget; two such waves per SIMD.
 // Operand fragments come straight from L2: lane (l15, l4) of an MFMA holds, for row l15 of a
 // 16-row tile, the packed columns [l4 * C, (l4 + 1) * C) -- which k of the dot product sits in
 // which MFMA slot is free as long as both operands agree -- i.e. contiguous 16-byte loads.
 // Same expansion as the reference ((|a|^2 + |b|^2) - 2 a.b, clipped at 0; general_utils.py:66-69),
 // only the summation order inside a.b differs from the LDS kernel's.
 // The 64 x 64-tile LDS kernel (kernmat_sym_kernel<..., false>) took 1.45 ms on this shape and
-// 1.14 ms for 65536 x 4096 at d = 6, this one 1.2 ms and 0.47 ms.
+// 0.84 ms (Matern-2.5) for 65536 x 4096 at d = 6, this one 1.1-1.2 ms and 0.5 ms.
 // ---------------------------------------------------------------------------------------------
 template <int KIND, int C, int MP>
-__global__ __launch_bounds__(256, (C <= 4 ? 2 : 1)) void kernmat_strip_kernel(KmArgs p, int tiles_per_seg) {
-  constexpr int WI = 4, WJ = 2;
+__global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int tiles_per_seg) {
+  // 32 rows x 64 (wide packed inputs: 32) columns per wave and tile, at least 2 waves per SIMD (measured
+  // 1.40 -> 1.12 ms against 64 x 32 at one wave per SIMD: a lone wave has nothing to cover its own stalls)
+  constexpr int WI = 2, WJ = (C >= 6 ? 2 : 4);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
-  const long m0 = ((long)blockIdx.y * 4 + wave) * 64;
+  const long m0 = ((long)blockIdx.y * 4 + wave) * (16 * WI);
   if (m0 >= p.n1) return;
   const long ntile = ((long)p.n2 + 16 * WJ - 1) / (16 * WJ);
   const long t0 = (long)blockIdx.x * tiles_per_seg;
@@ -476,9 +478,9 @@ __global__ __launch_bounds__(256, (C <= 4 ? 2 : 1)) void kernmat_strip_kernel(Km
   auto load_b = [&](long t, double (&bb)[WJ][C], double (&nn)[WJ]) {
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      // MFMA tile j, lane column l15 <-> matrix column n0 + 2 l15 + j: a lane then owns two ADJACENT
-      // columns of every row it holds and stores them with one 16-byte instruction
-      long col = t * (16 * WJ) + 2 * l15 + j;
+      // MFMA tile j, lane column l15 <-> matrix column n0 + WJ l15 + j: a lane then owns WJ ADJACENT
+      // columns of every row it holds and stores them with 16-byte instructions
+      long col = t * (16 * WJ) + WJ * l15 + j;
       col = col < p.n2 ? col : p.n2 - 1;
       const double* src = B + col * p.P;
 #pragma unroll
@@ -492,9 +494,9 @@ __global__ __launch_bounds__(256, (C <= 4 ? 2 : 1)) void kernmat_strip_kernel(Km
   };
   // per-lane element offset inside a 4-row group: the store address is a wave-uniform row-group base
   // plus this
-  const unsigned voff = (unsigned)(l4 * p.ldk + 2 * l15);
+  const unsigned voff = (unsigned)(l4 * p.ldk + WJ * l15);
   double* __restrict__ Kstrip = p.K + m0 * p.ldk;
-  const bool rows_full = m0 + 64 <= p.n1;
+  const bool rows_full = m0 + 16 * WI <= p.n1;
   load_b(t0, b, nbh);
   for (long t = t0; t < t1; ++t) {
     double bn[WJ][C], nbn[WJ];
@@ -545,11 +547,14 @@ __global__ __launch_bounds__(256, (C <= 4 ? 2 : 1)) void kernmat_strip_kernel(Km
           }
           double* __restrict__ rowp = Kt + (long)(i * 16 + 4 * r) * p.ldk;      // wave-uniform
           if (FULL) {
-            *reinterpret_cast<double2_t*>(rowp + voff) = (double2_t){kvs[0], kvs[1]};
+#pragma unroll
+            for (int j = 0; j < WJ; j += 2)
+              *reinterpret_cast<double2_t*>(rowp + voff + j) = (double2_t){kvs[j], kvs[j + 1]};
           } else {
-            const long row = m0 + i * 16 + l4 + 4 * r, col = n0 + 2 * l15;
-            if (row < p.n1 && col < p.n2) rowp[voff] = kvs[0];
-            if (row < p.n1 && col + 1 < p.n2) rowp[voff + 1] = kvs[1];
+            const long row = m0 + i * 16 + l4 + 4 * r, col = n0 + WJ * l15;
+#pragma unroll
+            for (int j = 0; j < WJ; ++j)
+              if (row < p.n1 && col + j < p.n2) rowp[voff + j] = kvs[j];
           }
         }
       }
@@ -568,9 +573,11 @@ __global__ __launch_bounds__(256, (C <= 4 ? 2 : 1)) void kernmat_strip_kernel(Km
 template <int KIND, int MP>
 int launch_strip(dfh_ctx* ctx, KmArgs a, int C) {
   // enough waves for 256 CUs x 4 SIMDs x 2: split the columns of a 64-row strip into segments
-  const long strips = ((long)a.n1 + 63) / 64;
-  const long ntile = ((long)a.n2 + 31) / 32;
-  long segs = (4096 + strips - 1) / strips;
+  const long strips = ((long)a.n1 + 31) / 32;
+  const int tile_cols = C >= 6 ? 32 : 64;
+  const long ntile = ((long)a.n2 + tile_cols - 1) / tile_cols;
+  static const long want_waves = []() { const char* e = getenv("DFH_KM_WAVES"); long v = e ? atol(e) : 8192; return v > 0 ? v : 8192; }();
+  long segs = (want_waves + strips - 1) / strips;
   if (segs > ntile) segs = ntile;
   if (segs < 1) segs = 1;
   const int tps = (int)((ntile + segs - 1) / segs);
@@ -1256,7 +1263,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
       const PartDev& hp = kd.parts[part_lo];
       const bool strip_ok = strip_on && (hp.kind == DFH_KERNEL_SE || (hp.kind == DFH_KERNEL_MATERN && hp.p <= 2)) &&
                             hp.kc >= 8 && hp.kc <= 32 && hp.kc % 8 == 0 && kd.P % 2 == 0 && hp.poff % 2 == 0 &&
-                            64 * ldk + 64 < (1LL << 31) && (n1 + 255) / 256 <= 65535 &&
+                            32 * ldk + 64 < (1LL << 31) && (n1 + 127) / 128 <= 65535 &&
                             (reinterpret_cast<uintptr_t>(Xp1) & 15) == 0 && (reinterpret_cast<uintptr_t>(Xp2) & 15) == 0;
       if (strip_ok) {
         if (hp.kind == DFH_KERNEL_SE) {

@@ -127,12 +127,11 @@ __global__ __launch_bounds__(256) void km_reg(Args p) {
 // current tile runs its MFMAs and epilogue.  fp64 MFMA and fp64 VALU share the SIMD's fp64 pipe
 // on this part (measured: mfma 0.56 ms + valu 0.43 ms -> 0.89 ms together), so the job is to keep
 // that pipe busy: no barriers, no LDS, loads a full tile ahead, stores fire-and-forget.
-template <int WJ, int C>
-__global__ __launch_bounds__(256) void km_strip(Args p, int tiles_per_seg) {
-  constexpr int WI = 4;
+template <int WJ, int C, int NOSTORE = 0, int WI = 4>
+__global__ __launch_bounds__(256, (WI <= 2 ? 2 : 1)) void km_strip(Args p, int tiles_per_seg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const long m0 = ((long)blockIdx.y * 4 + wave) * 64;
+  const long m0 = ((long)blockIdx.y * 4 + wave) * (16 * WI);
   if (m0 >= p.n1) return;
   const long ntile = (p.n2 + 16 * WJ - 1) / (16 * WJ);
   const long t0 = (long)blockIdx.x * tiles_per_seg;
@@ -199,7 +198,8 @@ __global__ __launch_bounds__(256) void km_strip(Args p, int tiles_per_seg) {
           tt = tt > 0.0 ? 0.0 : tt;
           const double v = sexp(tt, p.ec);
           const long col = n0 + j * 16 + l15;
-          if (row < p.n1 && col < p.n2) p.K[row * p.ldk + col] = v;
+          if (NOSTORE) { if (v == 123.456) p.K[row * p.ldk + col] = v; }
+          else if (row < p.n1 && col < p.n2) p.K[row * p.ldk + col] = v;
         }
       }
     }
@@ -212,17 +212,17 @@ __global__ __launch_bounds__(256) void km_strip(Args p, int tiles_per_seg) {
   }
 }
 
-template <int WJ, int C>
+template <int WJ, int C, int NOSTORE = 0, int WI = 4>
 static float run_strip(const Args& a, int reps, int segs, const char* name) {
   const long ntile = (a.n2 + 16 * WJ - 1) / (16 * WJ);
   const int tps = (int)((ntile + segs - 1) / segs);
-  dim3 grid((unsigned)segs, (unsigned)((a.n1 + 255) / 256));
+  dim3 grid((unsigned)segs, (unsigned)((a.n1 + 64 * WI - 1) / (64 * WI)));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((km_strip<WJ, C>), grid, dim3(256), 0, 0, a, tps);
+  hipLaunchKernelGGL((km_strip<WJ, C, NOSTORE, WI>), grid, dim3(256), 0, 0, a, tps);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((km_strip<WJ, C>), grid, dim3(256), 0, 0, a, tps);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((km_strip<WJ, C, NOSTORE, WI>), grid, dim3(256), 0, 0, a, tps);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -297,6 +297,12 @@ int main(int argc, char** argv) {
     CK(hipMemset(dK, 0, (size_t)n1 * n2 * 8));
     run_strip<2, 8>(a, reps, 4, "strip WJ=2 segs=4");
     check("strip");
+    run_strip<2, 8, 1>(a, reps, 4, "strip WJ=2 segs=4 NO STORES");
+    run_strip<2, 8, 0, 2>(a, reps, 2, "strip WI=2 WJ=2 segs=2");
+    run_strip<2, 8, 0, 2>(a, reps, 4, "strip WI=2 WJ=2 segs=4");
+    run_strip<4, 8, 0, 2>(a, reps, 2, "strip WI=2 WJ=4 segs=2");
+    run_strip<4, 8, 0, 2>(a, reps, 4, "strip WI=2 WJ=4 segs=4");
+    run_strip<2, 8, 1, 2>(a, reps, 2, "strip WI=2 WJ=2 segs=2 NO STORES");
     run_strip<2, 8>(a, reps, 8, "strip WJ=2 segs=8");
     run_strip<2, 8>(a, reps, 16, "strip WJ=2 segs=16");
     run_strip<2, 8>(a, reps, 2, "strip WJ=2 segs=2");
