@@ -466,6 +466,23 @@ def main():
       gen['host_numpy_draw_ms'] = round((t1 - t0) * 1e3, 3)
       gen['host_upload_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
       buf.free()
+      # the TS normals (general_utils.py:230 -- np.random.normal(size=(m, 1))): device (bit for bit) vs host + upload
+      nb = eng.empty((CANDS_PER_GPU,))
+      rng = np.random.RandomState(12)
+      eng.random_normals(64, rng=rng, out=nb)
+      eng.sync()
+      t0 = time.perf_counter()
+      eng.random_normals(CANDS_PER_GPU, rng=rng, out=nb)
+      eng.sync()
+      gen['normals_mt19937_device_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+      t0 = time.perf_counter()
+      host_norm = np.random.RandomState(12).standard_normal(CANDS_PER_GPU)
+      t1 = time.perf_counter()
+      nb.upload(host_norm)
+      eng.sync()
+      gen['normals_host_numpy_draw_ms'] = round((t1 - t0) * 1e3, 3)
+      gen['normals_host_upload_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
+      nb.free()
       out['candidate_generation_untimed_rank0'] = gen
       out['configs'] = other_configs(eng)
     if not args.no_cpu_baseline and world == 1:

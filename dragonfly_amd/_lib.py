@@ -78,6 +78,7 @@ SIGNATURES = {
                                    C.c_void_p]),
   'dfh_rand_mt19937_uniform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, C.c_void_p, C.c_void_p]),
+  'dfh_rand_mt19937_normal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
   'dfh_rand_philox_uniform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
   'dfh_gp_free': (C.c_int, [C.c_void_p]),

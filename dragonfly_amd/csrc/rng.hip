@@ -15,6 +15,7 @@
 //  * Philox4x64-10 (numpy.random.Philox) is counter based: every thread computes its own block
 //    of four words, no sequential part at all.
 #include "common.h"
+#include <math.h>
 
 namespace {
 
@@ -182,6 +183,192 @@ __global__ __launch_bounds__(256) void philox_uniform_kernel(Philox4 counter, Ph
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// np.random.normal from the legacy MT19937 state, on the device, bit for bit
+// ---------------------------------------------------------------------------------------------
+// draw_gaussian_samples (dragonfly/utils/general_utils.py:230) takes its standard normals from
+// np.random.normal(size=(m, 1)): NumPy's legacy_gauss, the Marsaglia polar method with rejection,
+//     do { x1 = 2 u - 1; x2 = 2 u' - 1; r2 = x1 x1 + x2 x2; } while (r2 >= 1 || r2 == 0);
+//     f = sqrt(-2 log(r2) / r2);   return f x2 now, f x1 on the next call (has_gauss / gauss)
+// on the MT19937 double stream.  Here: the uniforms of P attempted pairs come from the stream
+// walker above; acceptance flags, an exclusive prefix sum and a compaction put the k-th accepted
+// pair's two normals at out[base + 2k], out[base + 2k + 1]; the generator state handed back is the
+// state after the last pair NumPy would have consumed (rejected attempts included), has_gauss and
+// the cached second normal included.
+//
+// Every operation but one is an IEEE-exact +, *, /, sqrt on both sides.  The one is log(): glibc's
+// (what NumPy calls) is within 0.519 ulp, i.e. it returns the correctly rounded value unless the
+// true log lies within 0.019 ulp of a rounding boundary.  The device evaluates log(r2) in
+// double-double (error ~1e-30), rounds once, and flags the ~4 % of pairs within 0.025 ulp of a
+// boundary; for those -- and only those -- the host calls the C library's log() on the same r2 and
+// patches the two normals.  Result: word for word np.random.normal (tests/test_gpu_rng.py), with
+// O(0.04 m) doubles crossing PCIe instead of m.
+struct dd { double hi, lo; };
+__host__ __device__ inline dd two_sum(double a, double b) { const double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)}; }
+__host__ __device__ inline dd quick_two_sum(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+__host__ __device__ inline dd two_prod(double a, double b) { const double p = a * b; return {p, fma(a, b, -p)}; }
+__host__ __device__ inline dd dd_add(dd a, dd b) {
+  dd s = two_sum(a.hi, b.hi); const dd t = two_sum(a.lo, b.lo);
+  s.lo += t.hi; s = quick_two_sum(s.hi, s.lo); s.lo += t.lo; return quick_two_sum(s.hi, s.lo);
+}
+__host__ __device__ inline dd dd_add_d(dd a, double b) { dd s = two_sum(a.hi, b); s.lo += a.lo; return quick_two_sum(s.hi, s.lo); }
+__host__ __device__ inline dd dd_mul(dd a, dd b) { dd p = two_prod(a.hi, b.hi); p.lo += a.hi * b.lo + a.lo * b.hi; return quick_two_sum(p.hi, p.lo); }
+__host__ __device__ inline dd dd_mul_d(dd a, double b) { dd p = two_prod(a.hi, b); p.lo += a.lo * b; return quick_two_sum(p.hi, p.lo); }
+__host__ __device__ inline dd dd_div(dd a, dd b) {
+  const double q1 = a.hi / b.hi;
+  dd r = dd_add(a, dd_mul_d(b, -q1));
+  const double q2 = r.hi / b.hi;
+  r = dd_add(r, dd_mul_d(b, -q2));
+  const double q3 = r.hi / b.hi;
+  return dd_add_d(quick_two_sum(q1, q2), q3);
+}
+
+// log(x), 0 < x < 1 finite normal, in double-double: x = 2^e m, m in [sqrt(1/2), sqrt(2));
+// log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716:
+//   2 s (1 + s^2/3 + s^4/5 + s^6 (1/7 + s^2/9 + ...)) -- the first two terms of the bracket in
+// double-double, the tail (<= 3.6e-6, needed to 3e-15 relative) in double.
+__host__ __device__ inline dd log_dd(double x) {
+  int e;
+  double m = frexp(x, &e);                 // m in [0.5, 1)
+  if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+  const dd num = two_sum(m, -1.0), den = two_sum(m, 1.0);
+  const dd s = dd_div(num, den);
+  const dd s2 = dd_mul(s, s);
+  const double z = s2.hi;
+  double tail = 1.0 / 43.0;
+  for (int k = 41; k >= 7; k -= 2) tail = fma(tail, z, 1.0 / (double)k);      // 1/7 + z/9 + ... + z^18/43
+  const dd third = {0.33333333333333331, 1.8503717077085941e-17};
+  const dd fifth = {0.20000000000000001, -1.1102230246251566e-17};
+  dd br = dd_mul(s2, dd_add(third, dd_mul(s2, fifth)));                       // s^2/3 + s^4/5
+  br = dd_add_d(br, (z * z * z) * tail);                                      // + s^6 (...)
+  br = dd_add_d(br, 1.0);
+  dd r = dd_mul(dd_mul_d(s, 2.0), br);
+  const dd ln2 = {0.69314718055994529, 2.3190468138462996e-17};
+  return dd_add(dd_mul_d(ln2, (double)e), r);
+}
+
+struct NormalPair { double x1, x2, r2; int ok; };
+__host__ __device__ inline NormalPair polar_pair(double u0, double u1) {
+  NormalPair p;
+  p.x1 = 2.0 * u0 - 1.0;
+  p.x2 = 2.0 * u1 - 1.0;
+  p.r2 = p.x1 * p.x1 + p.x2 * p.x2;
+  p.ok = !(p.r2 >= 1.0 || p.r2 == 0.0);
+  return p;
+}
+
+// flags[i] = pair i accepted (as uint32 for the scan)
+__global__ __launch_bounds__(256) void normal_flags_kernel(const double2_t* __restrict__ U, int64_t P,
+                                                            uint32_t* __restrict__ flags) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < P; i += stride) {
+    const double2_t u = U[i];
+    flags[i] = (uint32_t)polar_pair(u.x, u.y).ok;
+  }
+}
+
+// three-kernel exclusive scan of uint32 flags into int64 positions: per-block sums, scan of the
+// block sums by one block, per-block rescan with the offset
+constexpr int SCAN_ITEMS = 2048;     // items per block (256 threads x 8)
+__global__ __launch_bounds__(256) void scan_block_sums(const uint32_t* __restrict__ f, int64_t n, int64_t* __restrict__ sums) {
+  __shared__ int64_t sm[256];
+  const int64_t base = int64_t(blockIdx.x) * SCAN_ITEMS;
+  int64_t s = 0;
+  for (int k = 0; k < 8; ++k) { const int64_t i = base + threadIdx.x * 8 + k; if (i < n) s += f[i]; }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) sums[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(256) void scan_sums_inplace(int64_t* __restrict__ sums, int64_t nb, int64_t* __restrict__ total) {
+  // one block, sequential over chunks of 256 (nb is a few thousand at most)
+  __shared__ int64_t sm[256];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < nb; c0 += 256) {
+    const int64_t i = c0 + threadIdx.x;
+    const int64_t v = i < nb ? sums[i] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int64_t t = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) sums[i] = carry + sm[threadIdx.x] - v;      // exclusive
+    __syncthreads();
+    if (threadIdx.x == 255) carry += sm[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// Emits the normals of the accepted pairs with rank < pairs_needed.  out[base + 2k] = f x2,
+// out[base + 2k + 1] = f x1 (if inside m, else it is the cached gaussian).  last_idx receives the
+// attempt index of the pair with rank pairs_needed - 1.  Hard log() cases are appended to
+// hard_k / hard_u (rank, the pair's two uniforms).
+__global__ __launch_bounds__(256) void normal_emit_kernel(const double2_t* __restrict__ U, int64_t P,
+                                                           const uint32_t* __restrict__ flags,
+                                                           const int64_t* __restrict__ block_off,
+                                                           int64_t pairs_needed, int64_t base, int64_t m,
+                                                           double* __restrict__ out, double* __restrict__ cached,
+                                                           int64_t* __restrict__ last_idx,
+                                                           unsigned long long* __restrict__ hard_count,
+                                                           int64_t hard_cap, int64_t* __restrict__ hard_k,
+                                                           double2_t* __restrict__ hard_u) {
+  __shared__ int64_t sm[256];
+  const int64_t b0 = int64_t(blockIdx.x) * SCAN_ITEMS;
+  // exclusive scan of this block's 2048 flags: per-thread 8 items
+  uint32_t f[8];
+  int64_t s = 0;
+  for (int k = 0; k < 8; ++k) { const int64_t i = b0 + threadIdx.x * 8 + k; f[k] = i < P ? flags[i] : 0u; s += f[k]; }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int64_t t = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t rank = block_off[blockIdx.x] + sm[threadIdx.x] - s;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = b0 + threadIdx.x * 8 + k;
+    if (i >= P || !f[k]) continue;
+    const int64_t kk = rank++;
+    if (kk >= pairs_needed) continue;
+    if (kk == pairs_needed - 1) *last_idx = i;
+    const double2_t u = U[i];
+    const NormalPair p = polar_pair(u.x, u.y);
+    const dd L = log_dd(p.r2);
+    // L.hi is the correctly rounded log unless L sits within 0.025 ulp of the midpoint between two
+    // doubles: |L.lo| close to half the spacing of doubles at L.hi
+    const double ulp = ldexp(1.0, ilogb(L.hi) - 52);
+    const double t = fabs(L.lo) / ulp;
+    if (t > 0.475) {
+      const unsigned long long slot = atomicAdd(hard_count, 1ull);
+      if ((int64_t)slot < hard_cap) { hard_k[slot] = kk; hard_u[slot] = u; }
+    }
+    const double fct = sqrt(-2.0 * L.hi / p.r2);
+    const int64_t o = base + 2 * kk;
+    out[o] = fct * p.x2;
+    if (o + 1 < m) out[o + 1] = fct * p.x1;
+    else *cached = fct * p.x1;
+  }
+}
+
+__global__ void normal_patch_kernel(const int64_t* __restrict__ k, const double2_t* __restrict__ z, int64_t count,
+                                    int64_t base, int64_t m, double* __restrict__ out, double* __restrict__ cached) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t o = base + 2 * k[i];
+  out[o] = z[i].x;
+  if (o + 1 < m) out[o + 1] = z[i].y;
+  else *cached = z[i].y;
+}
+
 // width[d] then lo[d] on the device (SCR_VEC3), from the caller's host bounds[d][2]
 int upload_box(dfh_ctx* ctx, const double* bounds, int64_t d, const double** d_box) {
   *d_box = nullptr;
@@ -315,4 +502,104 @@ extern "C" int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64
   if (!out_on_device) DFH_TRY(from_device(ctx, out, d_out, size_t(keep) * sizeof(double)));
   else DFH_HIP(hipStreamSynchronize(ctx->stream));
   return DFH_OK;
+}
+
+extern "C" int dfh_rand_mt19937_normal(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int32_t* has_gauss,
+                                       double* gauss, int64_t m, double* out) {
+  DFH_ARG(ctx != nullptr && key != nullptr && pos != nullptr && has_gauss != nullptr && gauss != nullptr);
+  DFH_ARG(m >= 0 && *pos >= 0 && *pos <= MT_N && (out != nullptr || m == 0));
+  DFH_ARG(!is_device_ptr(key) && !is_device_ptr(pos));
+  DFH_HIP(hipSetDevice(ctx->device));
+  if (m == 0) return DFH_OK;
+  const bool out_on_device = is_device_ptr(out);
+  void* p = nullptr;
+  double* d_out = out;
+  if (!out_on_device) {
+    DFH_TRY(scratch_get(ctx, SCR_OUT2, size_t(m) * sizeof(double), &p));
+    d_out = static_cast<double*>(p);
+  }
+  const int64_t base = *has_gauss ? 1 : 0;
+  const int64_t need = m - base;                     // normals that come from new pairs
+  const int64_t pairs_needed = (need + 1) / 2;
+  if (base) DFH_HIP(hipMemcpyAsync(d_out, gauss, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (pairs_needed == 0) {                           // m == 1 served from the cache
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+    *has_gauss = 0; *gauss = 0.0;
+    if (!out_on_device) DFH_TRY(from_device(ctx, out, d_out, size_t(m) * sizeof(double)));
+    return DFH_OK;
+  }
+  // small scalars on the device: [0] cached gaussian (double), [1] last_idx, [2] hard count, [3] accepted total
+  DFH_TRY(scratch_get(ctx, SCR_RED, 256, &p));
+  double* d_cached = static_cast<double*>(p);
+  int64_t* d_last = reinterpret_cast<int64_t*>(d_cached + 1);
+  unsigned long long* d_hard = reinterpret_cast<unsigned long long*>(d_cached + 2);
+  int64_t* d_total = reinterpret_cast<int64_t*>(d_cached + 3);
+  int64_t P = (int64_t)((double)pairs_needed / 0.75) + 64;      // acceptance probability pi/4 = 0.785
+  for (int attempt = 0; attempt < 8; ++attempt, P = P * 3 / 2) {
+    std::vector<uint32_t> key_try(key, key + MT_N);
+    int32_t pos_try = *pos;
+    double* dU = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_XS, size_t(P) * 16, (void**)&dU));
+    DFH_TRY(dfh_rand_mt19937_uniform(ctx, key_try.data(), &pos_try, P, 2, 0, P, nullptr, dU));
+    const int64_t nb = (P + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    DFH_TRY(scratch_get(ctx, SCR_XS2, size_t(P) * 4 + size_t(nb) * 8 + 64, &p));
+    int64_t* d_sums = static_cast<int64_t*>(p);
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_sums + nb + 1);
+    normal_flags_kernel<<<grid_for(ctx, P, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const double2_t*>(dU), P, d_flags);
+    DFH_LAUNCH_CHECK();
+    scan_block_sums<<<(unsigned)nb, 256, 0, ctx->stream>>>(d_flags, P, d_sums);
+    DFH_LAUNCH_CHECK();
+    scan_sums_inplace<<<1, 256, 0, ctx->stream>>>(d_sums, nb, d_total);
+    DFH_LAUNCH_CHECK();
+    int64_t accepted = 0;
+    DFH_HIP(hipMemcpyAsync(&accepted, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+    if (accepted < pairs_needed) continue;           // too few accepted pairs (practically never): more attempts
+    const int64_t hard_cap = pairs_needed / 8 + 1024;
+    char* hb = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_AUG, size_t(hard_cap) * 24 + 64, (void**)&hb));
+    int64_t* d_hk = reinterpret_cast<int64_t*>(hb);
+    double2_t* d_hu = reinterpret_cast<double2_t*>(hb + ((size_t(hard_cap) * 8 + 15) / 16) * 16);
+    DFH_HIP(hipMemsetAsync(d_hard, 0, 8, ctx->stream));
+    normal_emit_kernel<<<(unsigned)nb, 256, 0, ctx->stream>>>(reinterpret_cast<const double2_t*>(dU), P, d_flags, d_sums,
+                                                              pairs_needed, base, m, d_out, d_cached, d_last, d_hard,
+                                                              hard_cap, d_hk, d_hu);
+    DFH_LAUNCH_CHECK();
+    struct { double cached; int64_t last; unsigned long long hard; } h;
+    DFH_HIP(hipMemcpyAsync(&h, d_cached, 24, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+    DFH_ARG((int64_t)h.hard <= hard_cap);            // 4 % expected against a 12.5 % reserve
+    if (h.hard > 0) {
+      // the C library's log() decides the pairs whose log is within 0.025 ulp of a rounding boundary
+      std::vector<int64_t> hk(h.hard);
+      std::vector<double2_t> hu(h.hard);
+      DFH_HIP(hipMemcpyAsync(hk.data(), d_hk, h.hard * 8, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipMemcpyAsync(hu.data(), d_hu, h.hard * 16, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t i = 0; i < hk.size(); ++i) {
+        const NormalPair pr = polar_pair(hu[i].x, hu[i].y);
+        volatile double lg = log(pr.r2);              // libm, as NumPy's legacy_gauss
+        const double fct = sqrt(-2.0 * lg / pr.r2);
+        hu[i].x = fct * pr.x2;
+        hu[i].y = fct * pr.x1;
+      }
+      DFH_HIP(hipMemcpyAsync(d_hk, hk.data(), h.hard * 8, hipMemcpyHostToDevice, ctx->stream));
+      DFH_HIP(hipMemcpyAsync(d_hu, hu.data(), h.hard * 16, hipMemcpyHostToDevice, ctx->stream));
+      normal_patch_kernel<<<(unsigned)((h.hard + 255) / 256), 256, 0, ctx->stream>>>(d_hk, d_hu, (int64_t)h.hard, base, m,
+                                                                                     d_out, d_cached);
+      DFH_LAUNCH_CHECK();
+      DFH_HIP(hipMemcpyAsync(&h.cached, d_cached, 8, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    // the state NumPy is left in: 2 (last + 1) doubles consumed; the second normal of the last pair is
+    // cached when an odd number was asked of the pairs
+    DFH_TRY(dfh_rand_mt19937_uniform(ctx, key, pos, h.last + 1, 2, 0, 0, nullptr, nullptr));
+    if (need % 2 == 1) { *has_gauss = 1; *gauss = h.cached; }
+    else { *has_gauss = 0; *gauss = 0.0; }
+    if (!out_on_device) DFH_TRY(from_device(ctx, out, d_out, size_t(m) * sizeof(double)));
+    else DFH_HIP(hipStreamSynchronize(ctx->stream));
+    return DFH_OK;
+  }
+  dfh_set_error("dfh_rand_mt19937_normal: could not collect %lld accepted pairs", (long long)pairs_needed);
+  return DFH_ERR_HIP;
 }

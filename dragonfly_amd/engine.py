@@ -264,6 +264,31 @@ class Engine(object):
     bit_gen.state = state
     return out
 
+  def random_normals(self, num, rng=None, out=None):
+    """ np.random.normal(size=num) -- the standard normals of draw_gaussian_samples
+        (general_utils.py:230) -- generated in HBM from the legacy MT19937 state of `rng` (None / the
+        np.random module: the global state the reference uses; or a RandomState), bit for bit, the
+        cached second gaussian included; the generator is advanced exactly as the host draw would
+        have advanced it.  Returns a DeviceArray [num] (or fills `out`). """
+    num = int(num)
+    if num < 0:
+      raise ValueError('random_normals needs num >= 0.')
+    legacy = np.random if (rng is None or rng is np.random) else rng
+    if not (legacy is np.random or isinstance(legacy, np.random.RandomState)):
+      raise ValueError('Device normals follow the legacy MT19937 stream (np.random / RandomState).')
+    if out is None:
+      out = DeviceArray(self, (max(num, 1),))
+      out.shape, out.size = (num,), num
+    state = legacy.get_state()
+    if state[0] != 'MT19937':
+      raise ValueError('The legacy NumPy state is not MT19937.')
+    key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+    pos, has_gauss, gauss = C.c_int32(int(state[2])), C.c_int32(int(state[3])), C.c_double(float(state[4]))
+    check(self.lib.dfh_rand_mt19937_normal(self.ctx, _ptr(key), C.byref(pos), C.byref(has_gauss), C.byref(gauss),
+                                           num, _ptr(out)))
+    legacy.set_state((state[0], key, int(pos.value), int(has_gauss.value), float(gauss.value)))
+    return out
+
   def mem_info(self):
     """ (free, total) HBM bytes of this engine's device. """
     f, t = C.c_uint64(0), C.c_uint64(0)

@@ -7,6 +7,7 @@ Gaussian draws are all computed by libdfhip.so and stay resident in HBM; `L`, `a
 `K_trtr_wo_noise` are materialised as NumPy arrays only when something reads them
 (gpb_acquisitions.py:169,171 and gp_core.py:203 do).  There is no NumPy compute path.
 """
+import os
 import sys
 
 import numpy as np
@@ -33,6 +34,10 @@ def _check_feature_label_lengths_and_format(X, Y):
   if len(X) != len(Y):
     raise ValueError('Length of X (' + str(len(X)) + ') and Y (' + \
       str(len(Y)) + ') do not match.')
+
+
+# DFH_HOST_CANDIDATES=1 keeps every random draw of the acquisitions on the host (A/B switch)
+DEVICE_NORMALS = os.environ.get('DFH_HOST_CANDIDATES', '0') != '1'
 
 
 class GP(object):
@@ -277,14 +282,19 @@ class GP(object):
   # -- sampling --------------------------------------------------------------------------------
   def draw_samples(self, num_samples, X_test=None, mean_vals=None, covar=None):
     """ gp_core.py:250-254.  A single joint draw at X_test runs fused on the device
-        (covariance, stable_cholesky and L u never leave HBM); the standard normals are taken
-        from the global np.random state exactly as draw_gaussian_samples does. """
+        (covariance, stable_cholesky and L u never leave HBM); the standard normals continue
+        the global np.random state exactly as draw_gaussian_samples' np.random.normal call does
+        (Engine.random_normals: generated on the device, bit for bit). """
     if X_test is not None and num_samples == 1 and self.num_tr_data > 0 and not self._generic:
       Xt = _as_2d_array(X_test)
       test_mean = self.mean_func(X_test)
-      U = np.random.normal(size=(len(Xt), 1))
-      _, _, samples, _ = self._need_fit().thompson(Xt, U.ravel(), block=len(Xt),
-                                                   mean_vals=test_mean, return_samples=True)
+      fit = self._need_fit()
+      draw = getattr(fit.engine, 'random_normals', None)      # the stand-in engine of the CPU tests has none
+      if draw is not None and DEVICE_NORMALS:
+        U = draw(len(Xt))                                       # np.random.normal(size=(m, 1)), in HBM
+      else:
+        U = np.random.normal(size=(len(Xt), 1)).ravel()
+      _, _, samples, _ = fit.thompson(Xt, U, block=len(Xt), mean_vals=test_mean, return_samples=True)
       return samples.reshape((1, -1))
     if X_test is not None:
       mean_vals, covar = self.eval(X_test, 'covar')

@@ -239,11 +239,14 @@ def asy_ts(gp, anc_data):
     return maximise_acquisition(get_gp_sampler_for_parallel_strategy(gp, anc_data), anc_data,
                                 vectorised=True)
   # covariance, stable_cholesky, L u and the arg-max stay on the device; the standard normals are
-  # np.random.normal(size=(m, 1)) as in draw_gaussian_samples (general_utils.py:230)
+  # np.random.normal(size=(m, 1)) as in draw_gaussian_samples (general_utils.py:230) -- drawn in HBM
+  # as well (Engine.random_normals continues the global state bit for bit): nothing of size m
+  # crosses PCIe in either direction
   if DEVICE_CANDIDATES:
     cands, mean = _device_candidates(gp, anc_data)
-    normals = np.random.normal(size=(cands.shape[0], 1)).ravel()
+    normals = gp.device_gp.engine.random_normals(cands.shape[0])
     _, idx = gp.device_gp.thompson(cands, normals, block=cands.shape[0], **mean)
+    normals.free()
     return cands.row(idx)
   cands = _candidates(anc_data)
   normals = np.random.normal(size=(len(cands), 1)).ravel()

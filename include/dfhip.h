@@ -276,6 +276,15 @@ int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double* Xg_all, co
  * whatever the shard; Philox computes the shard's blocks only.                                   */
 int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int64_t m, int64_t d,
                              int64_t row_begin, int64_t row_count, const double* bounds, double* out);
+/* np.random.normal(size=m) from the same legacy state -- the standard normals draw_gaussian_samples
+ * takes (dragonfly/utils/general_utils.py:230; Thompson sampling, gp_core.py:250-254) -- produced in
+ * HBM bit for bit: NumPy's legacy_gauss (polar method with rejection on the MT19937 double stream).
+ * has_gauss / gauss: in/out, the cached second normal of np.random.get_state()[3:5]; key / pos are
+ * updated as by the uniform entry point.  `out` [m] may be a host or a device pointer.  log() is
+ * evaluated in double-double on the device; the ~4 % of pairs whose log lies within 0.025 ulp of a
+ * rounding boundary are decided by the host C library's log() (what NumPy itself calls).        */
+int dfh_rand_mt19937_normal(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int32_t* has_gauss, double* gauss,
+                            int64_t m, double* out);
 int dfh_rand_philox_uniform(dfh_ctx* ctx, const uint64_t* key, uint64_t* counter, uint64_t* buffer,
                             int32_t* buffer_pos, int64_t m, int64_t d, int64_t row_begin,
                             int64_t row_count, const double* bounds, double* out);

@@ -163,3 +163,46 @@ def test_c_abi_argument_checks(engine):
   bp = C.c_int32(5)
   with pytest.raises(ValueError):
     check(engine.lib.dfh_rand_philox_uniform(engine.ctx, ptr(pk), ptr(ctr), ptr(held), C.byref(bp), 4, 2, 0, 4, None, ptr(out)))
+
+
+# ---- np.random.normal on the device (dfh_rand_mt19937_normal) ----------------------------------
+@pytest.mark.parametrize('m', [1, 2, 3, 10, 1001, 4096, 300000])
+def test_device_normals_equal_numpy_word_for_word(engine, m):
+  """ draw_gaussian_samples' np.random.normal(size=(m, 1)) (general_utils.py:230): the device
+      stream equals NumPy's bit for bit and leaves the generator -- cached second gaussian
+      included -- where NumPy leaves it, so later host draws continue identically """
+  for seed, warm in ((5, 0), (6, 1), (7, 3)):
+    ref = np.random.RandomState(seed)
+    dev = np.random.RandomState(seed)
+    for rs in (ref, dev):
+      rs.random_sample(11)
+      if warm:
+        rs.normal(size=warm)          # odd counts leave a cached gaussian behind
+    want = ref.normal(size=(m, 1)).ravel()
+    got = engine.random_normals(m, rng=dev).download()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), \
+        (m, seed, int(np.sum(got != want)), float(np.max(np.abs(got - want))))
+    sr, sd = ref.get_state(), dev.get_state()
+    assert np.array_equal(sr[1], sd[1]) and sr[2:] == sd[2:]
+    assert np.array_equal(ref.normal(size=5), dev.normal(size=5))
+    assert np.array_equal(ref.random_sample(7), dev.random_sample(7))
+
+
+def test_device_normals_two_million_match_numpy(engine):
+  """ the size of BASELINE config 4's draw: 2 097 152 normals, every one equal to NumPy's """
+  m = 2097152
+  ref, dev = np.random.RandomState(304), np.random.RandomState(304)
+  want = ref.standard_normal(m)
+  got = engine.random_normals(m, rng=dev).download()
+  assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), int(np.sum(got != want))
+  assert np.array_equal(ref.get_state()[1], dev.get_state()[1]) and ref.get_state()[2:] == dev.get_state()[2:]
+
+
+def test_device_normals_global_state_and_host_output(engine):
+  np.random.seed(99)
+  want = np.random.normal(size=777)
+  tail = np.random.random(3)
+  np.random.seed(99)
+  out = np.empty(777)
+  engine.random_normals(777, out=out)
+  assert np.array_equal(out, want) and np.array_equal(np.random.random(3), tail)
