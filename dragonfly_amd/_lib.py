@@ -15,7 +15,7 @@ DFH_OK, DFH_ERR_NOT_PD, DFH_ERR_BAD_ARG, DFH_ERR_HIP, DFH_ERR_JITTER = 0, 1, 2, 
 KERNEL_SE, KERNEL_MATERN, KERNEL_ADDITIVE, KERNEL_PRODUCT = 0, 1, 2, 3
 ACQ_MEAN, ACQ_UCB, ACQ_EI, ACQ_PI, ACQ_TTEI, ACQ_STD = 0, 1, 2, 3, 4, 5
 GET_L, GET_ALPHA, GET_K = 0, 1, 2
-FIT_NO_JITTER = 1
+FIT_NO_JITTER, FIT_PROJECT_FIRST, FIT_TRY_BEFORE_PROJECT = 1, 2, 4
 T_NAMES = ['kernmat', 'chol', 'solve', 'cross', 'trsm', 'acq', 'ts', 'spare']
 INT32_MIN = -2**31
 UNIQUE_ID_BYTES = 128
@@ -57,6 +57,7 @@ SIGNATURES = {
                          C.c_int64, C.c_int]),
   'dfh_cholesky': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_int64_p]),
   'dfh_stable_cholesky': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, c_int32_p]),
+  'dfh_project_psd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
   'dfh_solve_triangular': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                      C.c_int64, C.c_void_p]),
   'dfh_gp_fit': (C.c_int, [C.c_void_p, C.POINTER(KernelDesc), C.c_void_p, C.c_int64, C.c_int64,

@@ -662,6 +662,24 @@ extern "C" int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const d
       DFH_TRY(copy_matrix(ctx, dK, n, gp->L, n, n, n));
       return add_diag(ctx, gp->L, n, n, noise_var);
     };
+    bool project = (flags & DFH_FIT_PROJECT_FIRST) != 0;
+    if (flags & DFH_FIT_TRY_BEFORE_PROJECT) {
+      // gp_core.py:829-837: plain Cholesky of K + noise I (no ladder); only if that fails, project
+      DFH_TRY(build_M());
+      SectionTimer t(ctx, DFH_T_CHOL);
+      int64_t piv = 0;
+      const int rc = cholesky_device(ctx, gp->L, n, n, gp->inv, &piv, 1, 0, 0, gp->refine.data());
+      if (rc == DFH_OK) return gp_alpha_and_lml(gp, dy, lml);
+      if (rc != DFH_ERR_NOT_PD) return rc;
+      project = true;
+    }
+    if (project) {
+      // gp_core.py:838-841: the kernel matrix (without noise) goes to the PSD cone first
+      double* Kp = nullptr;
+      DFH_TRY(scratch_get(ctx, SCR_TSK, (size_t)n * n * 8, (void**)&Kp));
+      DFH_TRY(psd_project_device(ctx, dK, n, n, 0.0, Kp, n));
+      dK = Kp;
+    }
     DFH_TRY(build_M());
     {
       SectionTimer t(ctx, DFH_T_CHOL);

@@ -289,6 +289,9 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
 int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, double* inv,
                        int* refine_out = nullptr, double* diag = nullptr);
 
+// projection of a symmetric matrix onto {eigenvalues >= eps} (psdproj.hip); out may alias M
+int psd_project_device(dfh_ctx* ctx, const double* M, int64_t n, int64_t ldm, double eps, double* out, int64_t ldo);
+
 // small helpers (elementwise / reductions)
 int fill_f64(dfh_ctx* ctx, double* p, int64_t n, double v);
 int zero_upper(dfh_ctx* ctx, double* A, int64_t n, int64_t lda);

@@ -427,10 +427,22 @@ class Engine(object):
       return lml, [None if p == INT32_MIN else int(p) for p in jps]
     return lml
 
-  def gp_fit_gram(self, K, y_centred, noise_var, allow_jitter=True):
-    """ Posterior from a Gram matrix the caller evaluated (any PSD kernel): a FittedGP without a
-        kernel -- use predict_gram / predict_covar_gram with it. """
-    return FittedGP.from_gram(self, K, y_centred, noise_var, allow_jitter)
+  def gp_fit_gram(self, K, y_centred, noise_var, allow_jitter=True, handle_non_psd_kernels='guaranteed_psd'):
+    """ Posterior from a Gram matrix the caller evaluated: a FittedGP without a kernel -- use
+        predict_gram / predict_covar_gram with it.  handle_non_psd_kernels as in the reference's
+        _get_cholesky_decomp (gp_core.py:827-847): 'guaranteed_psd' | 'project_first' |
+        'try_before_project'. """
+    return FittedGP.from_gram(self, K, y_centred, noise_var, allow_jitter, handle_non_psd_kernels)
+
+  def project_psd(self, M, epsilon=0.0):
+    """ project_symmetric_to_psd_cone (general_utils.py:150-163) on the device. """
+    M = _f64(M)
+    n = M.shape[0]
+    if M.shape != (n, n):
+      raise ValueError('project_psd: the matrix must be square.')
+    out = np.empty_like(M)
+    check(self.lib.dfh_project_psd(self.ctx, _ptr(M), n, float(epsilon), _ptr(out)))
+    return out
 
   def gp_fit(self, spec, X, y_centred, noise_var, allow_jitter=True):
     """ Returns a FittedGP (posterior resident in HBM). """
@@ -460,7 +472,7 @@ class FittedGP(object):
     self.jitter_power = None if jp.value == INT32_MIN else jp.value
 
   @classmethod
-  def from_gram(cls, engine, K, y_centred, noise_var, allow_jitter=True):
+  def from_gram(cls, engine, K, y_centred, noise_var, allow_jitter=True, handle_non_psd_kernels='guaranteed_psd'):
     Kh = K if isinstance(K, DeviceArray) else _f64(K)
     n = Kh.shape[0]
     if Kh.shape != (n, n):
@@ -471,8 +483,12 @@ class FittedGP(object):
     h = C.c_void_p()
     lml = C.c_double(0)
     jp = C.c_int32(INT32_MIN)
-    check(engine.lib.dfh_gp_fit_gram(engine.ctx, _ptr(Kh), n, _ptr(yh), float(noise_var),
-                                     0 if allow_jitter else _lib.FIT_NO_JITTER, C.byref(h),
+    if handle_non_psd_kernels not in ('guaranteed_psd', 'project_first', 'try_before_project'):
+      raise ValueError('Unknown option for handle_non_psd_kernels: %s' % (handle_non_psd_kernels))
+    flags = (0 if allow_jitter else _lib.FIT_NO_JITTER) | \
+        {'guaranteed_psd': 0, 'project_first': _lib.FIT_PROJECT_FIRST,
+         'try_before_project': _lib.FIT_TRY_BEFORE_PROJECT}[handle_non_psd_kernels]
+    check(engine.lib.dfh_gp_fit_gram(engine.ctx, _ptr(Kh), n, _ptr(yh), float(noise_var), flags, C.byref(h),
                                      C.byref(lml), C.byref(jp)))
     new = cls.__new__(cls)
     new.engine, new.spec, new.handle = engine, None, h

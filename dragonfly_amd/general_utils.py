@@ -71,6 +71,19 @@ def solve_upper_triangular(A, b):
   return _solve_triangular_common(A, b, lower=False)
 
 
+def project_symmetric_to_psd_cone(M, is_symmetric=True, epsilon=0):
+  """ V max(Lambda, epsilon) V^T of the symmetric M (general_utils.py:150-163), on the device:
+      no eigen-decomposition, the matrix sign function by Newton-Schulz steps on the fp64 MFMA GEMM
+      (csrc/psdproj.hip).  The reference's non-symmetric branch (np.linalg.eig) has no caller on
+      the GP path and is not provided. """
+  if not is_symmetric:
+    raise NotImplementedError('project_symmetric_to_psd_cone: symmetric matrices only.')
+  M = np.asarray(M, dtype=np.float64)
+  if M.size == 0:
+    return M
+  return get_engine().project_psd(M, epsilon=float(epsilon))
+
+
 def draw_gaussian_samples(num_samples, mu, K):
   """ num_samples draws from N(mu, K) (general_utils.py:224-232); the normals come from the
       global np.random state with the reference's call, the factor and the product from the

@@ -64,11 +64,14 @@ class GP(object):
       self.build_posterior()
 
   def _set_up(self):
-    """ gp_core.py:112-118: guaranteed-psd kernels only ('project_first' is an eigen-projection on
-        the host in the reference and stays there). """
-    if not self.kernel.is_guaranteed_psd() or self.handle_non_psd_kernels != 'guaranteed_psd':
-      raise NotImplementedError('dragonfly_amd.GP handles guaranteed-psd kernels '
-                                '(handle_non_psd_kernels="guaranteed_psd") only.')
+    """ gp_core.py:112-118: a kernel that is not guaranteed PSD needs a way to handle it.  The
+        device builds 'project_first' / 'try_before_project' posteriors from a caller-evaluated
+        Gram matrix (dfh_gp_fit_gram with the projection of csrc/psdproj.hip), so such GPs run in
+        host-kernel mode whatever the kernel object. """
+    if self.handle_non_psd_kernels not in ('guaranteed_psd', 'project_first', 'try_before_project'):
+      raise ValueError('Unknown option for handle_non_psd_kernels: %s' % (self.handle_non_psd_kernels))
+    if not self.kernel.is_guaranteed_psd():
+      assert self.handle_non_psd_kernels in ['project_first', 'try_before_project']
 
   @property
   def _generic(self):
@@ -79,7 +82,7 @@ class GP(object):
         run on the device (dfh_gp_fit_gram, dfh_gp_predict_gram). """
     has_spec = hasattr(self.kernel, 'to_spec') and \
                getattr(self.kernel, 'has_device_spec', lambda: True)()
-    return (not has_spec) or \
+    return (not has_spec) or self.handle_non_psd_kernels != 'guaranteed_psd' or \
            type(self)._get_training_kernel_matrix is not GP._get_training_kernel_matrix
 
   def _write_message(self, msg):
@@ -146,7 +149,8 @@ class GP(object):
       Y_centred = np.asarray(self.Y, dtype=np.float64) - self.mean_func(self.X)
       K = np.ascontiguousarray(self._get_training_kernel_matrix(), dtype=np.float64)
       self._cache['K'] = K
-      self._fitted = get_engine().gp_fit_gram(K, Y_centred, self.noise_var)
+      self._fitted = get_engine().gp_fit_gram(K, Y_centred, self.noise_var,
+                                              handle_non_psd_kernels=self.handle_non_psd_kernels)
       self._fit_sig = None
       return
     hint = getattr(self, '_X_dev_hint', None)      # training inputs already resident in HBM
@@ -218,9 +222,10 @@ class GP(object):
         mu_raw, _ = fitted.predict_gram(K_tetr)
         return test_mean + mu_raw, None
       K_tete = np.ascontiguousarray(self.kernel(X_test, X_test), dtype=np.float64)
-      if uncert_form == 'covar':
+      if uncert_form == 'covar' or not self.kernel.is_guaranteed_psd():
         mu_raw, covar = fitted.predict_covar_gram(K_tetr, K_tete)
-        return test_mean + mu_raw, covar
+        covar = self._post_covar_from_raw(covar)                     # gp_core.py:182-183
+        return test_mean + mu_raw, (covar if uncert_form == 'covar' else np.sqrt(np.diag(covar)))
       mu_raw, sd = fitted.predict_gram(K_tetr, np.diag(K_tete).copy())
       return test_mean + mu_raw, sd
     if uncert_form == 'covar':
@@ -250,10 +255,30 @@ class GP(object):
     _, sd = fitted.predict(Xt, want_std=True, X_halluc=Xh)
     return (pred_mean, sd)
 
+  def _post_covar_from_raw(self, raw_post_covar):
+    """ get_post_covar_from_raw_covar (gp_core.py:849-857): the posterior covariance of a kernel that
+        is not guaranteed PSD is projected onto {eigenvalues >= 0.05 noise_var} -- on the device. """
+    if self.kernel.is_guaranteed_psd():
+      return raw_post_covar
+    return get_engine().project_psd(raw_post_covar, epsilon=0.05 * self.noise_var)
+
   def _generic_hallucinated_uncert(self, X_test, X_halluc, uncert_form):
     """ gp_core.py:199-220 for a caller-evaluated kernel: the augmented factor is assembled block-
         wise exactly as the reference does, every solve / factorisation on the device. """
     from .general_utils import solve_lower_triangular, stable_cholesky
+    if self.handle_non_psd_kernels != 'guaranteed_psd':
+      # the whole augmented matrix takes the projection branch (gp_core.py:199-206), then :207-213
+      X_aug = list(self.X) + list(X_halluc)
+      K_haha = self.kernel(X_halluc, X_halluc)
+      K_trha = self.kernel(self.X, X_halluc)
+      aug_K = np.vstack((np.hstack((self.K_trtr_wo_noise, K_trha)), np.hstack((K_trha.T, K_haha))))
+      aug = get_engine().gp_fit_gram(aug_K, np.zeros(len(X_aug)), self.noise_var,
+                                     handle_non_psd_kernels=self.handle_non_psd_kernels)
+      _, covar = aug.predict_covar_gram(np.ascontiguousarray(self.kernel(X_test, X_aug), dtype=np.float64),
+                                        np.ascontiguousarray(self.kernel(X_test, X_test), dtype=np.float64))
+      aug.free()
+      covar = self._post_covar_from_raw(covar)
+      return covar if uncert_form == 'covar' else np.sqrt(np.diag(covar))
     K_haltr = self.kernel(X_halluc, self.X)                       # gp_core.py:201
     L = self.L
     B = solve_lower_triangular(L, K_haltr.T).T                    # q x n

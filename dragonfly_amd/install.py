@@ -21,6 +21,12 @@ edited):
                constructs its GP through this module global (dragonfly/gp/euclidean_gp.py:707).
                Opt-in because the reference class cannot be reached once the name is rebound (its
                __init__ calls super(EuclideanMFGP, self)).
+  S2'' CP GP   (only with install(cartesian_product=True)) dragonfly.gp.cartesian_product_gp.CPGP ->
+               dragonfly_amd.cartesian_product_gp.CPGP: the kernel (the reference's
+               CartesianProductKernel) stays on the host, the 'project_first' eigen-projection of
+               the Gram matrix and of every posterior covariance (gp_core.py:838-841, 849-857), the
+               factorisation and the posterior run on the device.  The CP fitter constructs its GP
+               through this module global.  Opt-in for the same reason as the MF GP.
   S4 acquisitions  dispatchers are written into the namespaces
                dragonfly.opt.gpb_acquisitions.asy / syn / seq (looked up with getattr at
                dragonfly/opt/gp_bandit.py:490,510,651,681): the fused callables on Euclidean
@@ -50,7 +56,7 @@ import numpy as np
 _saved = []     # (object, attribute name, original value)
 
 
-def install(multi_fidelity=False, batched_tuning=True):
+def install(multi_fidelity=False, batched_tuning=True, cartesian_product=False):
   """ Rebinds the names listed above; returns the list of patched attributes. """
   import dragonfly.gp.kernel as ref_kernel
   import dragonfly.gp.euclidean_gp as ref_egp
@@ -68,6 +74,10 @@ def install(multi_fidelity=False, batched_tuning=True):
 
   if multi_fidelity:
     _set(ref_egp, 'EuclideanMFGP', mf_gp.EuclideanMFGP)
+  if cartesian_product:
+    import dragonfly.gp.cartesian_product_gp as ref_cpgp
+    from . import cartesian_product_gp
+    _set(ref_cpgp, 'CPGP', cartesian_product_gp.CPGP)
   for ns_name in ('asy', 'syn', 'seq'):
     ref_ns = getattr(ref_acq, ns_name)
     our_ns = getattr(gpb_acquisitions, ns_name)

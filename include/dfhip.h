@@ -131,6 +131,15 @@ int dfh_cholesky(dfh_ctx* ctx, double* A, int64_t n, int64_t* info_pivot);
 int dfh_stable_cholesky(dfh_ctx* ctx, const double* M_in, int64_t n, double* L_out,
                         int32_t* jitter_power);
 
+/* project_symmetric_to_psd_cone (utils/general_utils.py:150-163): out = V max(Lambda, epsilon) V^T
+ * for the symmetric M = V Lambda V^T (n x n; out may equal M).  Used on the Gram matrix of kernels
+ * that are not guaranteed PSD (gp_core.py:838-841, epsilon = 0) and on their posterior covariances
+ * (get_post_covar_from_raw_covar, gp_core.py:849-857, epsilon = 0.05 noise_var).  No eigenvectors
+ * are formed: epsilon I + (B + B sign(B)) / 2 with B = M - epsilon I and the matrix sign function
+ * from 96 Newton-Schulz steps on the fp64 MFMA GEMM (csrc/psdproj.hip); agrees with the eigh route
+ * to ~1e-13 |M|.                                                                                */
+int dfh_project_psd(dfh_ctx* ctx, const double* M, int64_t n, double epsilon, double* out);
+
 /* Solve L x = b (upper = 0) or L^T x = b (upper = 1) with L lower-triangular n x n row major;
  * b is n x nrhs row-major (nrhs >= 1).  Replaces solve_lower_triangular /
  * solve_upper_triangular (general_utils.py:208-221) as used at gp_core.py:162-163,180.       */
@@ -139,6 +148,12 @@ int dfh_solve_triangular(dfh_ctx* ctx, const double* L, int64_t n, int upper,
 
 /* ---- GP fit / posterior ----------------------------------------------------------------- */
 #define DFH_FIT_NO_JITTER 1  /* report DFH_ERR_NOT_PD instead of running the jitter ladder    */
+/* dfh_gp_fit_gram only -- kernels that are not guaranteed PSD (Cartesian-product / neural-network
+ * GPs), _get_cholesky_decomp's other branches (gp/gp_core.py:827-840):                        */
+#define DFH_FIT_PROJECT_FIRST      2  /* 'project_first': K -> its projection onto the PSD cone
+                                         (dfh_project_psd), then K + noise I and the ladder     */
+#define DFH_FIT_TRY_BEFORE_PROJECT 4  /* 'try_before_project': plain Cholesky of K + noise I; only
+                                         if that is not positive definite, as project_first    */
 
 /* GP.build_posterior (gp_core.py:155-163) + _get_cholesky_decomp 'guaranteed_psd'
  * (gp_core.py:841-844) + compute_log_marginal_likelihood (gp_core.py:222-227):

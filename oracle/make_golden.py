@@ -479,6 +479,70 @@ def gen_trajectory_case():
            [e['acq'] for e in events if e['type'] == 'acq']))
 
 
+def gen_nonpsd_cases():
+  """ Kernels that are NOT guaranteed PSD through the real reference:
+      (1) gp_core.GP with a sigmoid kernel tanh(a x.y + b) and handle_non_psd_kernels =
+          'project_first' / 'try_before_project' (gp_core.py:827-857: eigen-projection of the Gram
+          matrix and of every posterior covariance);
+      (2) cartesian_product_gp.CPGP (cartesian_product_gp.py:208-248) with the reference's
+          CartesianProductKernel over [SE on R^2, sigmoid on R^1], one part also from a distance
+          list... (parts evaluated directly here).
+      Stored: inputs, the reference's K, L, alpha, lml, eval mean / std / covar, hallucinated std. """
+  from dragonfly.gp import gp_core as GC
+  from dragonfly.gp.kernel import Kernel, SEKernel, CartesianProductKernel
+  from dragonfly.gp.cartesian_product_gp import CPGP
+
+  class SigmoidKernel(Kernel):
+    """ k(x, y) = tanh(a x.y + b): symmetric, indefinite. """
+    def __init__(self, a, b):
+      super(SigmoidKernel, self).__init__()
+      self.add_hyperparams(a=a, b=b)
+    def is_guaranteed_psd(self):
+      return False
+    def _child_evaluate(self, X1, X2):
+      X1, X2 = np.array(X1, dtype=float), np.array(X2, dtype=float)
+      return np.tanh(self.hyperparams['a'] * X1.dot(X2.T) + self.hyperparams['b'])
+
+  rs = np.random.RandomState(909)
+  res = {}
+  # (1) plain GP, sigmoid kernel on R^3
+  n, d, m, q = 60, 3, 15, 2
+  X = rs.randn(n, d)
+  Y = np.sin(X.sum(axis=1)) + 0.05 * rs.randn(n)
+  Xs, Xh = rs.randn(m, d), rs.randn(q, d)
+  a, b, noise, mean_c = 0.7, -0.4, 0.05, float(np.median(Y))
+  mean_func = lambda x: np.array([mean_c] * len(x))
+  res.update(X=X, Y=Y, Xs=Xs, Xh=Xh, a=a, b=b, noise=noise, mean_c=mean_c)
+  for mode in ('project_first', 'try_before_project'):
+    gp = GC.GP(list(X), list(Y), SigmoidKernel(a, b), mean_func, noise, handle_non_psd_kernels=mode)
+    mu, sd = gp.eval(list(Xs), 'std')
+    _, cov = gp.eval(list(Xs), 'covar')
+    _, sdh = gp.eval_with_hallucinated_observations(list(Xs), list(Xh), 'std')
+    res.update({mode + '_K': gp.K_trtr_wo_noise, mode + '_L': gp.L, mode + '_alpha': gp.alpha,
+                mode + '_lml': gp.compute_log_marginal_likelihood(), mode + '_mu': mu, mode + '_sd': sd,
+                mode + '_cov': cov, mode + '_sdh': sdh})
+  res['min_eig_K'] = float(np.linalg.eigvalsh(res['project_first_K']).min())
+  # (2) CPGP: domain = R^2 x R^1, kernel = scale * SE(part 0) * sigmoid(part 1)
+  n2, m2 = 50, 12
+  P0, P1 = rs.rand(n2, 2), rs.randn(n2, 1)
+  Yc = np.cos(3 * P0.sum(axis=1)) + 0.3 * P1[:, 0] + 0.05 * rs.randn(n2)
+  T0, T1 = rs.rand(m2, 2), rs.randn(m2, 1)
+  H0, H1 = rs.rand(q, 2), rs.randn(q, 1)
+  cp_scale, bw0, a1, b1, noise2, mean2 = 1.3, np.array([0.4, 0.6]), 0.9, 0.2, 0.03, float(np.median(Yc))
+  kern = CartesianProductKernel(cp_scale, [SEKernel(2, 1.0, bw0), SigmoidKernel(a1, b1)])
+  to_lists = lambda A, B: [[A[i], B[i]] for i in range(len(A))]
+  gp = CPGP(to_lists(P0, P1), list(Yc), kern, lambda x: np.array([mean2] * len(x)), noise2)
+  mu, sd = gp.eval(to_lists(T0, T1), 'std')
+  _, cov = gp.eval(to_lists(T0, T1), 'covar')
+  _, sdh = gp.eval_with_hallucinated_observations(to_lists(T0, T1), to_lists(H0, H1), 'std')
+  res.update(cp_P0=P0, cp_P1=P1, cp_Y=Yc, cp_T0=T0, cp_T1=T1, cp_H0=H0, cp_H1=H1, cp_scale=cp_scale, cp_bw0=bw0,
+             cp_a=a1, cp_b=b1, cp_noise=noise2, cp_mean=mean2, cp_K=gp.K_trtr_wo_noise, cp_L=gp.L,
+             cp_alpha=gp.alpha, cp_lml=gp.compute_log_marginal_likelihood(), cp_mu=mu, cp_sd=sd, cp_cov=cov,
+             cp_sdh=sdh, cp_min_eig_K=float(np.linalg.eigvalsh(gp.K_trtr_wo_noise).min()))
+  np.savez_compressed(os.path.join(OUT, 'nonpsd_gp.npz'), **res)
+  print('wrote nonpsd_gp (min eig K: plain %.3f, cp %.3f)' % (res['min_eig_K'], res['cp_min_eig_K']))
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   import_reference()
@@ -491,6 +555,9 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'pdoo':
     gen_pdoo_cases()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'nonpsd':
+    gen_nonpsd_cases()
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':
     gen_trajectory_case()
     sys.exit(0)
@@ -501,3 +568,4 @@ if __name__ == '__main__':
   gen_pdoo_cases()
   gen_slice_cases()
   gen_trajectory_case()
+  gen_nonpsd_cases()

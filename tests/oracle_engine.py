@@ -24,11 +24,16 @@ def to_oracle_spec(spec):
 class OracleFittedGP(object):
   """ FittedGP's interface over GPOracle (zero mean: the mirrors centre Y and add the mean). """
 
-  def __init__(self, engine, spec, X, y_centred, noise_var, gram=None):
+  def __init__(self, engine, spec, X, y_centred, noise_var, gram=None, handle_non_psd_kernels='guaranteed_psd'):
     self.engine = engine
     X = np.asarray(X, dtype=np.float64)
     kernel = (lambda A, B=None: gram) if gram is not None else to_oracle_spec(spec)
     self.oracle = O.GPOracle(X, np.asarray(y_centred, dtype=np.float64), kernel, 0.0, noise_var)
+    if handle_non_psd_kernels != 'guaranteed_psd':      # _get_cholesky_decomp's other branches
+      og = self.oracle
+      og.L = O.get_cholesky_decomp(og.K_trtr_wo_noise, noise_var, handle_non_psd_kernels)
+      og.jitter_power = None
+      og.alpha = O.solve_upper_triangular(og.L.T, O.solve_lower_triangular(og.L, og.Y))
     self.spec, self.n, self.d = spec, len(X), (X.shape[1] if X.ndim == 2 else 0)
     self.lml = float(self.oracle.lml())
     self.jitter_power = self.oracle.jitter_power
@@ -116,8 +121,12 @@ class OracleEngine(object):
   def gp_fit(self, spec, X, y_centred, noise_var, allow_jitter=True):
     return OracleFittedGP(self, spec, X, y_centred, noise_var)
 
-  def gp_fit_gram(self, K, y_centred, noise_var, allow_jitter=True):
-    return OracleFittedGP(self, None, np.zeros((len(K), 0)), y_centred, noise_var, gram=np.asarray(K))
+  def gp_fit_gram(self, K, y_centred, noise_var, allow_jitter=True, handle_non_psd_kernels='guaranteed_psd'):
+    return OracleFittedGP(self, None, np.zeros((len(K), 0)), y_centred, noise_var, gram=np.asarray(K),
+                          handle_non_psd_kernels=handle_non_psd_kernels)
+
+  def project_psd(self, M, epsilon=0.0):
+    return O.project_symmetric_to_psd_cone(np.asarray(M, dtype=np.float64), epsilon=epsilon)
 
   def kernel_matrix(self, spec, X1, X2=None, diag_add=0.0, out=None):
     K = to_oracle_spec(spec)(np.asarray(X1, dtype=np.float64), None if X2 is None else np.asarray(X2, dtype=np.float64))
