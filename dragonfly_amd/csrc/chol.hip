@@ -608,14 +608,18 @@ __global__ void k_copy_lower_block(const double* __restrict__ D, long lda, int n
   out[(long)i * CHOL_NB + j] = (i < nbk && j <= i) ? D[(long)i * lda + j] : 0.0;
 }
 
-// delta[blockIdx.x * strideDelta] = max_ij |E_ij - [i == j]| over the nbk x nbk block E (ld NB); NaN if any
-__global__ __launch_bounds__(1024) void k_inv_delta(const double* __restrict__ E, int nbk, long strideE,
-                                                     double* __restrict__ delta, long strideDelta) {
-  __shared__ double sm[1024];
+// delta[blockIdx.x * strideDelta] = max_ij |E_ij - [i == j]| over the nbk x nbk block E (ld NB); +inf if any
+// NaN.  blockIdx.y = slice of the elements; the slices combine through an atomic max on the bit
+// pattern (non-negative doubles order like their bit patterns; the slot is zeroed beforehand).
+constexpr int DELTA_SLICES = 32;
+__global__ __launch_bounds__(256) void k_inv_delta(const double* __restrict__ E, int nbk, long strideE,
+                                                    double* __restrict__ delta, long strideDelta) {
+  __shared__ double sm[256];
   E += (long)blockIdx.x * strideE;
   double m = 0.0;
   bool bad = false;
-  for (long idx = threadIdx.x; idx < (long)nbk * nbk; idx += 1024) {
+  const long total = (long)nbk * nbk;
+  for (long idx = (long)blockIdx.y * 256 + threadIdx.x; idx < total; idx += (long)DELTA_SLICES * 256) {
     const int i = (int)(idx / nbk), j = (int)(idx % nbk);
     const double v = fabs(E[(long)i * CHOL_NB + j] - (i == j ? 1.0 : 0.0));
     if (v != v) bad = true;
@@ -623,11 +627,13 @@ __global__ __launch_bounds__(1024) void k_inv_delta(const double* __restrict__ E
   }
   sm[threadIdx.x] = bad ? INFINITY : m;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) delta[(long)blockIdx.x * strideDelta] = sm[0];
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(delta + (long)blockIdx.x * strideDelta),
+              (unsigned long long)__double_as_longlong(sm[0]));
 }
 
 // clean copy of the diagonal block + delta, asynchronous on ctx->stream (T: NB*NB doubles per matrix)
@@ -641,8 +647,9 @@ int block_inverse_quality(dfh_ctx* ctx, const double* D, int64_t lda, int64_t nb
   GemmBatch b;
   b.count = nbatch; b.sA = strideInv; b.sB = strideInv; b.sCout = strideT;
   DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, nbk, nbk, nbk, 1.0, Linv, NB, Ldiag, NB, 0.0, nullptr, 0, T, NB, &b));
-  hipLaunchKernelGGL(k_inv_delta, dim3((unsigned)nbatch), dim3(1024), 0, ctx->stream, T, (int)nbk, (long)strideT,
-                     d_delta, (long)strideDelta);
+  for (int b = 0; b < nbatch; ++b) DFH_HIP(hipMemsetAsync(d_delta + (long)b * strideDelta, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_inv_delta, dim3((unsigned)nbatch, DELTA_SLICES), dim3(256), 0, ctx->stream, T, (int)nbk,
+                     (long)strideT, d_delta, (long)strideDelta);
   DFH_LAUNCH_CHECK();
   return DFH_OK;
 }

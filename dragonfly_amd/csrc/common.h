@@ -158,7 +158,6 @@ struct SectionTimer {
 #define GEMM_LOWER   1   // compute only tiles intersecting the lower triangle (row >= col)
 #define GEMM_KTRI_B  2   // B is [N x K] lower triangular (B[j][k]=0 for k>j): clip k-range
 #define GEMM_TRANSB  4   // B is [K x N]
-#define GEMM_LOWER_ROWS 8 // (A/B knob) enumerate the lower-triangular tiles row by row instead of in 8 x 8 super-blocks
 
 // Two-level batch: blockIdx.z = b2 * count + b1 ; operand offset = b1 * s? + b2 * s?2
 struct GemmBatch {

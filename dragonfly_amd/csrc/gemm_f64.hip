@@ -22,7 +22,6 @@
 //   C/D       : reg r of lane l holds D[i = (l>>4) + 4r][j = l&15]
 #include "common.h"
 #include <algorithm>
-#include <stdlib.h>
 #include <utility>
 
 namespace {
@@ -63,39 +62,19 @@ __device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
   const unsigned nb = gridDim.x, b = blockIdx.x;
   const unsigned q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  if ((p.flags & GEMM_LOWER) && (p.flags & GEMM_LOWER_ROWS)) {
-    // A/B knob (DFH_SYRK_ROWS=1): round 1's row-by-row enumeration of the lower-triangular tile set
+  if (p.flags & GEMM_LOWER) {
+    // row-by-row enumeration of the lower-triangular tile set.  (Round 2 tried 8 x 8 super-blocks
+    // instead: rocprofv3 FETCH_SIZE of the K = 512 SYRK fell from 5.0 to 2.7 GB per launch, its time
+    // did not move (54 TF/s either way) -- and the extra index arithmetic in this prologue shifted
+    // the start times of the workgroups of the PLAIN tile order enough to nearly triple the L2
+    // misses of the posterior TRSM products (3.0 -> 8.6 GB per 32768 x 512 x 8192 launch, +3 % time:
+    // tiles that share an A panel miss together instead of one after the other).  Reverted; see
+    // DESIGN.md section 7.)
     unsigned i = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
     while ((unsigned long long)i * (i + 1) / 2 > lin) --i;
     while ((unsigned long long)(i + 1) * (i + 2) / 2 <= lin) ++i;
     tm = (int)i;
     tn = (int)(lin - (unsigned)((unsigned long long)i * (i + 1) / 2));
-  } else if (p.flags & GEMM_LOWER) {
-    // Lower-triangular tile set in super-blocks of 8 x 8 tiles, super-row by super-row.  The 64
-    // workgroups an XCD runs at a time (32 CUs x 2) then cover ONE super-block: 8 A panels and 8 B
-    // panels, each shared by 8 co-resident tiles that start together and advance through K in step,
-    // so each panel chunk comes from HBM once per super-block.  (Round 1 enumerated row by row: the
-    // 64 co-resident tiles shared their A panel but streamed 64 different B panels -- measured
-    // 517 KB of HBM fetches per tile, an L2 hit rate of ~50 %, on the K = 512 SYRK of the
-    // factorisation.)  Tiles before super-row I: 32 I^2 + 4 I; a short last super-row has h < 8 rows.
-    constexpr unsigned G = 8;
-    unsigned I = (unsigned)((sqrt(16.0 + 128.0 * (double)lin) - 4.0) * (1.0 / 64.0));
-    while (32ull * I * I + 4ull * I > lin) --I;
-    while (32ull * (I + 1) * (I + 1) + 4ull * (I + 1) <= lin) ++I;
-    unsigned rem = lin - (unsigned)(32ull * I * I + 4ull * I);
-    const unsigned h = min(G, (unsigned)p.tiles_m - G * I);
-    if (rem < I * G * h) {                       // off-diagonal super-block J < I: h x 8 tiles
-      const unsigned J = rem / (G * h), in = rem % (G * h);
-      tm = (int)(G * I + in % h);
-      tn = (int)(G * J + in / h);
-    } else {                                     // diagonal super-block: tiles with column <= row
-      rem -= I * G * h;
-      unsigned i = (unsigned)((sqrt(8.0 * (double)rem + 1.0) - 1.0) * 0.5);
-      while (i * (i + 1) / 2 > rem) --i;
-      while ((i + 1) * (i + 2) / 2 <= rem) ++i;
-      tm = (int)(G * I + i);
-      tn = (int)(G * I + rem - i * (i + 1) / 2);
-    }
   } else {
     constexpr unsigned GROUP_M = 8;
     const unsigned width = GROUP_M * (unsigned)p.tiles_n;
@@ -549,11 +528,7 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
   if (M <= 0 || N <= 0) return DFH_OK;
   DFH_ARG(M < (1LL << 30) && N < (1LL << 30) && K < (1LL << 30) && K >= 0);
   DFH_ARG(beta == 0.0 || Cin != nullptr);
-  if (flags & GEMM_LOWER) {
-    DFH_ARG(M == N);
-    static const bool rows = []() { const char* e = getenv("DFH_SYRK_ROWS"); return e && atoi(e) != 0; }();
-    if (rows) flags |= GEMM_LOWER_ROWS;
-  }
+  if (flags & GEMM_LOWER) DFH_ARG(M == N);
   GemmArgs p;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;

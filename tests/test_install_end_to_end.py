@@ -310,10 +310,13 @@ def test_top_level_maximise_function_with_default_options(monkeypatch):
   assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
 
 
-def test_cartesian_product_domain_runs_keep_working(monkeypatch):
+@pytest.mark.parametrize('install_kwargs', [{}, dict(cartesian_product=True)], ids=['reference-cpgp', 'mirror-cpgp'])
+def test_cartesian_product_domain_runs_keep_working(install_kwargs, monkeypatch):
   """ install() must not break what it does not accelerate: on a Cartesian-product domain (float +
       int + discrete variables) the acquisition entries dispatch to the reference's own callables
-      and the CP GP evaluates its Euclidean factor kernels through the mirror kernel classes. """
+      and the CP GP evaluates its Euclidean factor kernels through the mirror kernel classes.
+      With install(cartesian_product=True) the CP GP itself is the mirror class (project_first
+      posterior on the engine, kernel parts on the host): same run, same points. """
   from oracle.make_golden import import_reference
   import_reference()
   from oracle_engine import patch_engine
@@ -334,7 +337,8 @@ def test_cartesian_product_domain_runs_keep_working(monkeypatch):
     return val, str(pt), str(hist.query_points)
   want = run()
   patch_engine(monkeypatch)
-  install.install()
+  patched = install.install(**install_kwargs)
+  assert ('dragonfly.gp.cartesian_product_gp.CPGP' in patched) == bool(install_kwargs)
   try:
     got = run()
   finally:

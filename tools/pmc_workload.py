@@ -16,6 +16,22 @@ Kd = eng.empty((n, n))
 spec = KernelSpec('se', d, 1.3, 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0))
 for _ in range(3):
   eng.kernel_matrix(spec, X, None, out=Kd)
+# Matern-2.5 Gram matrix, and the cross matrices K(X*, X) of a posterior chunk (strip kernel):
+# SE 32768 x 16384 at d = 32 and Matern-2.5 65536 x 4096 at d = 6 (BASELINE config 2's shape)
+spec_m = KernelSpec('matern', d, 1.3, 0.5 * np.ones(d), nu=2.5)
+for _ in range(2):
+  eng.kernel_matrix(spec_m, X, None, out=Kd)
+Xs = eng.to_device(rs.rand(32768, d))
+Kc = eng.empty((32768, n))
+for _ in range(3):
+  eng.kernel_matrix(spec, Xs, X, out=Kc)
+Kc.free(); Xs.free()
+X6, Xs6 = eng.to_device(rs.rand(4096, 6)), eng.to_device(rs.rand(65536, 6))
+Kc6 = eng.empty((65536, 4096))
+spec6 = KernelSpec('matern', 6, 1.3, 0.5 * np.ones(6), nu=2.5)
+for _ in range(3):
+  eng.kernel_matrix(spec6, Xs6, X6, out=Kc6)
+Kc6.free(); X6.free(); Xs6.free()
 M, K = 15872, 512
 A = eng.to_device(rs.rand(M, K) - 0.5)
 Cd = eng.empty((M, M))

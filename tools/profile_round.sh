@@ -9,7 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $REPO/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B --steps 2 --warmup 1 > $OUT/trace.log 2>&1
-tail -1 $OUT/trace.log | cut -c1-2000 > $OUT/bench_under_trace.json
+grep -h "^{\"metric" $OUT/trace.log | cut -c1-4000 > $OUT/bench_under_trace.json
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $set -d $OUT/wl_$tag -o wl -- python $REPO/tools/pmc_workload.py > $OUT/wl_$tag.log 2>&1
