@@ -431,7 +431,7 @@ def main():
       },
       'device': eng.name(),
     }
-    if not args.no_extras:
+    if not args.no_extras and world == 1:       # (ranks of a multi-process run stay in step: no rank-0-only extras)
       # conditioning of the matrix that was factored (quoted next to the parity numbers):
       # lambda_max(K) by power iteration on the host, lambda_min(K + noise I) >= noise
       gp = eng.gp_fit(spec, prob['X'], prob['Y'] - prob['mean_c'], prob['noise'])

@@ -28,11 +28,22 @@ struct dfh_gp {
 namespace {
 
 int64_t pick_chunk(int64_t n, int64_t m) {
-  // candidate rows per posterior chunk: keep the m_c x n cross matrix near DFH_CHUNK_GIB (4) GiB
-  // (measured on the bench step: 2 GiB 1465 ms, 4 GiB 1434 ms, 8 GiB 1439 ms -- eight TS blocks per batch)
-  static const double chunk_gib = []() { const char* e = getenv("DFH_CHUNK_GIB"); double v = e ? atof(e) : 4.0; return v > 0.0 ? v : 4.0; }();
-  int64_t mc = (int64_t)(chunk_gib * (double)(1LL << 27)) / (n > 0 ? n : 1);
-  mc = std::max<int64_t>(512, std::min<int64_t>(mc, 65536));
+  // candidate rows per posterior chunk: the m_c x n cross matrix (solved in place into V^T) is sized
+  // for a 288 GB part -- DFH_CHUNK_GIB (32) GiB, two of them alive in the pipelined Thompson
+  // sampling, never more than an eighth of the device's memory each.  Measured on the bench step
+  // (n = 16384, 262144 candidates, TS blocks factored in lock-step batches of DFH_TS_BATCH):
+  // 4 GiB / 8 blocks 1434 ms, 8 GiB / 16 1403-1412, 16 GiB / 32 1397, 32 GiB / 64 1389 -- bigger
+  // chunks mean taller TRSM products (1048 -> 1021 ms) and more Thompson blocks per latency-bound
+  // factorisation chain (332 -> 310 ms).
+  static const double chunk_gib = []() { const char* e = getenv("DFH_CHUNK_GIB"); double v = e ? atof(e) : 32.0; return v > 0.0 ? v : 32.0; }();
+  static const double mem_cap = []() {
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return 36.0; }
+    return (double)t / 8.0 / 1073741824.0;
+  }();
+  const double gib = chunk_gib < mem_cap ? chunk_gib : mem_cap;
+  int64_t mc = (int64_t)(gib * (double)(1LL << 27)) / (n > 0 ? n : 1);
+  mc = std::max<int64_t>(512, std::min<int64_t>(mc, 262144));
   mc = (mc / 512) * 512;
   if (mc > m) mc = m;
   return mc;
@@ -1377,8 +1388,8 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   double* vec[2] = {nullptr, nullptr};
   DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 2, (void**)&vec[0]));
   DFH_TRY(scratch_get(ctx, SCR_VECB, (size_t)mc_max * 8 * 2, (void**)&vec[1]));
-  // up to DFH_TS_BATCH (8) blocks of a chunk are factored as one lock-step batch
-  static const int ts_batch = []() { const char* e = getenv("DFH_TS_BATCH"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+  // up to DFH_TS_BATCH (64) blocks of a chunk are factored as one lock-step batch
+  static const int ts_batch = []() { const char* e = getenv("DFH_TS_BATCH"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > CHOL_MAX_BATCH ? CHOL_MAX_BATCH : v); }();
   const int64_t lb_slots = std::max<int64_t>(1, std::min<int64_t>(ts_batch, mc_max / block));
   double* Lb = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TSL, (size_t)lb_slots * block * block * 8, (void**)&Lb));

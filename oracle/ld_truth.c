@@ -24,7 +24,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 typedef long double ld;
+
+/* OpenMP team size (hundreds of host threads on a GPU box do not help an n = 2048 problem) */
+void ld_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 static ld kern_value(int kind, double nu, ld scale, ld d2) {
   if (kind == 0) return scale * expl(-d2 / 2);

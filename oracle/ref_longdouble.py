@@ -33,6 +33,8 @@ def _load():
                                      C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.ld_gaussian_draw.restype = C.c_int64
     lib.ld_gaussian_draw.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ld_set_threads.argtypes = [C.c_int]
+    lib.ld_set_threads(min(32, os.cpu_count() or 1))
     _lib = lib
   return _lib
 
