@@ -550,6 +550,15 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
   // 128-tiling would leave most of the 256 CUs idle.
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * (long)count;
   if (t128 < 192) return dispatch<2>(ctx, p, count, edge);
+  if (!edge && !(flags & GEMM_LOWER) && (N % 128) == 0 && (M % 128) != 0 && M >= 1024) {
+    // A ragged last row tile would send EVERY tile through the bounds-checked kernel (scalar,
+    // predicated operand loads): the full row tiles take the fast kernel, the < 128 leftover rows a
+    // launch of their own.  A row's sum runs over the same chunks in the same order either way.
+    const int64_t M1 = (M / 128) * 128;
+    DFH_TRY(gemm_f64(ctx, flags, M1, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, Cout, ldc, batch));
+    return gemm_f64(ctx, flags, M - M1, N, K, alpha, A + M1 * lda, lda, B, ldb, beta,
+                    Cin ? Cin + M1 * ldcin : nullptr, ldcin, Cout + M1 * ldc, ldc, batch);
+  }
   return dispatch<4>(ctx, p, count, edge);
 }
 

@@ -319,7 +319,13 @@ extern "C" int dfh_mgpu_create(int n_devices, const int* device_ids, dfh_mgpu** 
     return DFH_ERR_BAD_ARG;
   }
   const RcclApi* api = nullptr;
-  DFH_TRY(rccl_load(&api));
+  {
+    // one device has nobody to exchange with: RCCL is used when it is there (the same code path as
+    // N devices), but its absence is not an error
+    const int rc = rccl_load(&api);
+    if (rc != DFH_OK && n_devices > 1) return rc;
+    if (rc != DFH_OK) api = nullptr;
+  }
   dfh_mgpu* mg = new dfh_mgpu();
   mg->n = n_devices;
   auto body = [&]() -> int {
@@ -331,6 +337,8 @@ extern "C" int dfh_mgpu_create(int n_devices, const int* device_ids, dfh_mgpu** 
       DFH_TRY(dfh_ctx_create(dev, &ctx));
       mg->ctxs.push_back(ctx);
     }
+    mg->gps.assign((size_t)n_devices, nullptr);
+    if (!api) return DFH_OK;                  // single device without RCCL: no communicator
     std::vector<ncclComm_t> cs((size_t)n_devices, nullptr);
     {
       StdoutToStderr quiet;
@@ -359,7 +367,7 @@ extern "C" dfh_gp* dfh_mgpu_gp(dfh_mgpu* mg, int rank) {
   return (mg && rank >= 0 && rank < mg->n) ? mg->gps[rank] : nullptr;
 }
 extern "C" dfh_comm* dfh_mgpu_comm(dfh_mgpu* mg, int rank) {
-  return (mg && rank >= 0 && rank < mg->n) ? mg->comms[rank] : nullptr;
+  return (mg && rank >= 0 && rank < (int)mg->comms.size()) ? mg->comms[rank] : nullptr;
 }
 
 namespace {
@@ -394,6 +402,10 @@ int fan_out(dfh_mgpu* mg, Fn fn) {
 // checking that the others hold the same
 int exchange(dfh_mgpu* mg, const std::vector<double>& vals, const std::vector<int64_t>& idxs, double* best_val,
              int64_t* best_idx) {
+  if (mg->comms.empty()) {                    // single device, RCCL not installed: the reduce alone
+    DFH_ARG(mg->n == 1);
+    return dfh_reduce_argmax(vals.data(), idxs.data(), 1, best_val, best_idx);
+  }
   const RcclApi* api = mg->comms[0]->api;
   DFH_NCCL(api, api->GroupStart());
   int rc = DFH_OK;
