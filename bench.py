@@ -420,6 +420,7 @@ def main():
         'avg_launch_us_incl_overlap': round(g0['ms'] * 1e3 / max(1, g0['launches']), 2),
         'achieved_from_sum_of_durations': round(achieved_sum, 2),
         'algorithmic_gflop_per_launch': round(g0['flop'] / max(1, g0['launches']) / 1e9, 3),
+        'algorithmic_bytes_per_launch': round(g0['bytes'] / max(1, g0['launches'])),
         'all_gemm_variants': {'ms_per_step': round(all_ms / args.steps, 3),
                               'tflops': round(all_flop / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0},
         'side_targets': {

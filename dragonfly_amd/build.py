@@ -45,7 +45,7 @@ def build(force=False, verbose=True, debug_hooks=False):
   """Compile every HIP translation unit for gfx950 and link libdfhip.so. Returns its path."""
   hipcc = _hipcc()
   os.makedirs(OBJ_DIR, exist_ok=True)
-  flags = CXXFLAGS + (['-DDFH_DEBUG_HOOKS'] if debug_hooks else [])
+  flags = CXXFLAGS + (['-DDFH_DEBUG_HOOKS'] if debug_hooks else []) + os.environ.get('DFH_EXTRA_CXXFLAGS', '').split()
   stamp = os.path.join(OBJ_DIR, 'flags.txt')
   if not os.path.exists(stamp) or open(stamp).read() != ' '.join(flags):
     force = True                   # different flags than the objects on disk were built with

@@ -74,7 +74,7 @@ struct dfh_ctx {
   // CU: the other half of every CU stays available to latency-critical kernels of another stream.
   bool gemm_half_occupancy = false;
   bool gemm_prof = false;
-  struct GemmRec { hipEvent_t e0, e1; double flops; int variant; };
+  struct GemmRec { hipEvent_t e0, e1; double flops, bytes; int variant; };
   std::vector<GemmRec> gemm_recs;
   size_t gemm_used = 0;
   hipEvent_t gemm_base = nullptr;   // time origin of the per-launch intervals

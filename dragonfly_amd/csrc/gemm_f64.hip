@@ -22,6 +22,7 @@
 //   C/D       : reg r of lane l holds D[i = (l>>4) + 4r][j = l&15]
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -42,6 +43,10 @@ template <int WT> struct Geo {
   static constexpr int NN_ROWS = 256 / NN_LANES;       // k-rows per pass
   static constexpr int NN_PASSES = BK / NN_ROWS;
 };
+
+#ifndef DFH_GEMM_GROUP_M
+#define DFH_GEMM_GROUP_M 8      // row tiles per group of the plain tile order (map_tile)
+#endif
 
 struct GemmArgs {
   int M, N, K;
@@ -76,7 +81,7 @@ __device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
     tm = (int)i;
     tn = (int)(lin - (unsigned)((unsigned long long)i * (i + 1) / 2));
   } else {
-    constexpr unsigned GROUP_M = 8;
+    constexpr unsigned GROUP_M = DFH_GEMM_GROUP_M;
     const unsigned width = GROUP_M * (unsigned)p.tiles_n;
     const unsigned group = lin / width;
     const unsigned first_m = group * GROUP_M;
@@ -318,7 +323,7 @@ int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
       dfh_ctx::GemmRec r;
       DFH_HIP(hipEventCreate(&r.e0));
       DFH_HIP(hipEventCreate(&r.e1));
-      r.flops = 0.0; r.variant = 0;
+      r.flops = 0.0; r.bytes = 0.0; r.variant = 0;
       ctx->gemm_recs.push_back(r);
     }
     rec = &ctx->gemm_recs[ctx->gemm_used++];
@@ -327,6 +332,11 @@ int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
     if (p.flags & GEMM_LOWER) f = (double)p.M * ((double)p.M + 1.0) * (double)p.K;
     if (p.flags & GEMM_KTRI_B) f = (double)p.M * (double)p.N * ((double)p.N + 1.0);
     rec->flops = f * (double)grid.z;
+    // algorithmic bytes: each operand once, the output tile written (and read when it is updated)
+    const double c_elems = (p.flags & GEMM_LOWER) ? 0.5 * (double)p.M * ((double)p.M + 1.0) : (double)p.M * (double)p.N;
+    const double b_elems = (p.flags & GEMM_KTRI_B) ? 0.5 * (double)p.N * ((double)p.N + 1.0) : (double)p.N * (double)p.K;
+    rec->bytes = 8.0 * (double)grid.z * ((double)p.M * (double)p.K + (p.B == p.A ? 0.0 : b_elems) +
+                                         c_elems * ((p.Cin != nullptr && p.beta != 0.0) ? 2.0 : 1.0));
     rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);
     DFH_HIP(hipEventRecord(rec->e0, ctx->stream));
   }
@@ -550,6 +560,19 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
   // 128-tiling would leave most of the 256 CUs idle.
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * (long)count;
   if (t128 < 192) return dispatch<2>(ctx, p, count, edge);
+  // Tuning knob (tools/gemm_rows.py): cut a tall product into launches of this many rows.  Measured
+  // on the posterior shape 262144 x 512 x 8192: L2 misses fall from 1.9x to 1.5x the operand bytes
+  // (two-wave launches keep the tiles that share a panel in step), the time does not move (31.55 vs
+  // 31.61 ms, 69.7 TF/s) -- the kernel is bound by the fp64 pipe, not by HBM.  Off by default.
+  static const long split_rows = getenv("DFH_GEMM_SPLIT_ROWS") ? atol(getenv("DFH_GEMM_SPLIT_ROWS")) : 0;
+  if (split_rows >= 128 && !batch && !(flags & GEMM_LOWER) && M > split_rows) {
+    for (int64_t r0 = 0; r0 < M; r0 += split_rows) {
+      const int64_t mr = (M - r0 < split_rows) ? M - r0 : split_rows;
+      p.M = (int)mr; p.A = A + r0 * lda; p.Cin = Cin ? Cin + r0 * ldcin : nullptr; p.Cout = Cout + r0 * ldc;
+      DFH_TRY(dispatch<4>(ctx, p, count, edge));
+    }
+    return DFH_OK;
+  }
   if (!edge && !(flags & GEMM_LOWER) && (N % 128) == 0 && (M % 128) != 0 && M >= 1024) {
     // A ragged last row tile would send EVERY tile through the bounds-checked kernel (scalar,
     // predicated operand loads): the full row tiles take the fast kernel, the < 128 leftover rows a
@@ -563,15 +586,15 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
 }
 
 // Enable / disable per-launch event timing of the GEMM kernel and fetch the totals.
-// stats_out[8][4]: per kernel variant (bit2 = NN, bit1 = edge path, bit0 = 64x64 tiles; variant 0
+// stats_out[8][5]: per kernel variant (bit2 = NN, bit1 = edge path, bit0 = 64x64 tiles; variant 0
 // is the 128x128 NT throughput configuration) {launches, sum of launch durations in ms,
-// algorithmic flop, busy ms}.  `busy` is the length of the union of the variant's launch
+// algorithmic flop, busy ms, algorithmic bytes}.  `busy` is the length of the union of the variant's launch
 // intervals: launches on different streams overlap (look-ahead Cholesky, TS pipeline) and then
 // share the CUs, so the plain sum counts that wall-clock more than once.
 extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out) {
   DFH_ARG(ctx != nullptr);
   if (stats_out) {
-    for (int i = 0; i < 32; ++i) stats_out[i] = 0.0;
+    for (int i = 0; i < 40; ++i) stats_out[i] = 0.0;
     DFH_HIP(hipStreamSynchronize(ctx->main_stream));
     DFH_HIP(hipStreamSynchronize(ctx->side));
     DFH_HIP(hipStreamSynchronize(ctx->bulk));
@@ -583,9 +606,10 @@ extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out)
       DFH_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
       if (ctx->gemm_base) DFH_HIP(hipEventElapsedTime(&t0, ctx->gemm_base, r.e0));
       const int v = r.variant;
-      stats_out[v * 4 + 0] += 1.0;
-      stats_out[v * 4 + 1] += (double)ms;
-      stats_out[v * 4 + 2] += r.flops;
+      stats_out[v * 5 + 0] += 1.0;
+      stats_out[v * 5 + 1] += (double)ms;
+      stats_out[v * 5 + 2] += r.flops;
+      stats_out[v * 5 + 4] += r.bytes;
       iv[v].emplace_back(t0, t0 + ms);
     }
     for (int v = 0; v < 8; ++v) {
@@ -595,7 +619,7 @@ extern "C" int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out)
         if (x.first >= hi) { busy += x.second - x.first; hi = x.second; }
         else if (x.second > hi) { busy += x.second - hi; hi = x.second; }
       }
-      stats_out[v * 4 + 3] = busy;
+      stats_out[v * 5 + 3] = busy;
     }
   }
   ctx->gemm_used = 0;

@@ -311,10 +311,11 @@ class Engine(object):
 
   def gemm_profile(self, enable=True, fetch=True):
     """ Per-variant {launches, ms (sum of launch durations), flop, busy_ms (union of the launch
-        intervals)} of the GEMM kernel since the last call (HIP events). """
-    arr = (C.c_double * 32)()
+        intervals), bytes (algorithmic)} of the GEMM kernel since the last call (HIP events). """
+    arr = (C.c_double * 40)()
     check(self.lib.dfh_ctx_gemm_profile(self.ctx, 1 if enable else 0, arr if fetch else None))
-    return [dict(launches=int(arr[4 * v]), ms=arr[4 * v + 1], flop=arr[4 * v + 2], busy_ms=arr[4 * v + 3]) for v in range(8)]
+    return [dict(launches=int(arr[5 * v]), ms=arr[5 * v + 1], flop=arr[5 * v + 2], busy_ms=arr[5 * v + 3],
+                 bytes=arr[5 * v + 4]) for v in range(8)]
 
   # -- building blocks ---------------------------------------------------------------------
   def kernel_matrix(self, spec, X1, X2=None, diag_add=0.0, out=None):

@@ -393,10 +393,13 @@ int dfh_ctx_timings(dfh_ctx* ctx, int enable, double* ms_out /* [DFH_T_COUNT] or
 
 /* Per-launch HIP-event timing of the fp64 MFMA GEMM kernel (the dominant kernel of the path),
  * recorded on the stream each launch goes to.  Returns the totals since the last call in
- * stats_out[8][3] = per kernel variant {launches, total ms, algorithmic flop}; variant index =
- * 4*(B is [K x N]) + 2*(edge path) + (64x64 tiles), so variant 0 is the 128x128 NT throughput
- * configuration.  stats_out may be NULL.  Then enables (1) / disables (0) further recording.   */
-int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out /* [32] or NULL */);
+ * stats_out[8][5] = per kernel variant {launches, sum of launch durations in ms, algorithmic
+ * flop, busy ms = length of the union of the launch intervals (launches of different streams
+ * overlap), algorithmic bytes = each operand once + the output tile written (and read when it
+ * is updated)}; variant index = 4*(B is [K x N]) + 2*(edge path) + (64x64 tiles), so variant 0 is
+ * the 128x128 NT throughput configuration.  stats_out may be NULL.  Then enables (1) / disables
+ * (0) further recording.                                                                        */
+int dfh_ctx_gemm_profile(dfh_ctx* ctx, int enable, double* stats_out /* [40] or NULL */);
 
 #ifdef __cplusplus
 }

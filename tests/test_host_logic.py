@@ -113,8 +113,14 @@ def test_gp_kernel_modes_and_bad_lengths():
   assert g._generic
   g2 = GP([np.zeros(2)], [0.0], K.SEKernel(2, 1.0, [1, 1]), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
   assert not g2._generic
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(AssertionError):        # the reference's check (gp_core.py:116-118)
     GP([np.zeros(2)], [0.0], NotPsd(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False)
+  g3 = GP([np.zeros(2)], [0.0], NotPsd(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False,
+          handle_non_psd_kernels='project_first')
+  assert g3._generic
+  with pytest.raises(ValueError):
+    GP([np.zeros(2)], [0.0], NotPsd(), lambda x: np.zeros(len(x)), 0.1, build_posterior=False,
+       handle_non_psd_kernels='something_else')
   with pytest.raises(ValueError):
     GP([np.zeros(2)], [0.0, 1.0], K.SEKernel(2, 1.0, [1, 1]), lambda x: np.zeros(len(x)), 0.1,
        build_posterior=False)

@@ -4,6 +4,8 @@
 set -e
 R=${1:-r02}
 P=gpurun_out/prof
+# launches of the dominant kernel in the timed step, from the bench line of the PMC pass itself
+export FIRST_LAUNCHES=$(grep -h '^{"metric' $P/bench_FETCH_SIZE.log | python -c "import json,sys; print(int(json.loads(sys.stdin.readline())['roofline']['launches_per_step']))")
 python tools/rocpd_pmc_traffic.py $P/bench_FETCH_SIZE/bench_results.db $P/bench_WRITE_SIZE/bench_results.db 'gemm_f64_kernel<false, false, 4>' profiles/${R}_pmc_traffic.json > /dev/null
 {
 echo "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 2 --warmup 1   (MI355X, tools/profile_round.sh; rocpd database summarised by tools/rocpd_stats.py)"
@@ -11,6 +13,16 @@ echo "4 steps in the trace: 1 warm-up + 2 timed + 1 untimed section-timing step.
 grep -h '^{"metric' $P/trace.log
 echo
 python tools/rocpd_stats.py $P/trace/bench_results.db
+echo
+echo "The dominant kernel step by step (its first 4 x launches_per_step dispatches; steps 1 and 2 are the timed ones; compare roofline.avg_launch_us_incl_overlap of the bench line above):"
+python - $P/trace/bench_results.db $FIRST_LAUNCHES <<'PY'
+import sqlite3, sys
+c = sqlite3.connect(sys.argv[1]); n = int(sys.argv[2])
+d = [r[0] for r in c.execute("select (end-start)/1e3 from kernels where instr(name,'gemm_f64_kernel<false, false, 4>')>0 order by start")]
+for s in range(4):
+  seg = d[s * n:(s + 1) * n]
+  print('  step %d: %d launches, avg %.1f us, total %.1f ms' % (s, len(seg), sum(seg) / len(seg), sum(seg) / 1e3))
+PY
 echo
 echo "PMC passes over the same command (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --no-cpu-baseline --steps 1 --warmup 0; kernels are serialised under --pmc):"
 python tools/rocpd_pmc_traffic.py $P/bench_FETCH_SIZE/bench_results.db $P/bench_WRITE_SIZE/bench_results.db
