@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdfhip.so')
 
 DFH_OK, DFH_ERR_NOT_PD, DFH_ERR_BAD_ARG, DFH_ERR_HIP, DFH_ERR_JITTER = 0, 1, 2, 3, 4
-KERNEL_SE, KERNEL_MATERN, KERNEL_ADDITIVE, KERNEL_PRODUCT = 0, 1, 2, 3
+KERNEL_SE, KERNEL_MATERN, KERNEL_ADDITIVE, KERNEL_PRODUCT, KERNEL_POLY, KERNEL_EXPDECAY = 0, 1, 2, 3, 4, 5
 ACQ_MEAN, ACQ_UCB, ACQ_EI, ACQ_PI, ACQ_TTEI, ACQ_STD = 0, 1, 2, 3, 4, 5
 GET_L, GET_ALPHA, GET_K = 0, 1, 2
 FIT_NO_JITTER, FIT_PROJECT_FIRST, FIT_TRY_BEFORE_PROJECT = 1, 2, 4

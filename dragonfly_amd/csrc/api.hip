@@ -158,8 +158,9 @@ __device__ __forceinline__ double ei_norm_diff(double nd) {
 
 // mu/sd/acquisition for one chunk.
 //   mu_raw = K(Xs,X) alpha ; ss = ||L^-1 k||^2 ; ss2 = extra hallucination term (or null)
-__global__ void k_posterior_acq(int acq, double p0, double p1, double kxx, double mean_const,
-                                const double* __restrict__ mean_vals, const double* __restrict__ mu_raw,
+//   kss = prior variances k(x_i, x_i) of a kernel that is not stationary (else null: kxx)
+__global__ void k_posterior_acq(int acq, double p0, double p1, double kxx, const double* __restrict__ kss,
+                                double mean_const, const double* __restrict__ mean_vals, const double* __restrict__ mu_raw,
                                 const double* __restrict__ ss, const double* __restrict__ ss2, long m,
                                 double* __restrict__ mu_out, double* __restrict__ sd_out,
                                 double* __restrict__ val_out) {
@@ -168,6 +169,7 @@ __global__ void k_posterior_acq(int acq, double p0, double p1, double kxx, doubl
   const double mu = (mean_vals ? mean_vals[i] : mean_const) + mu_raw[i];   // gp_core.py:173-175
   double sd = 0.0;
   if (ss) {
+    if (kss) kxx = kss[i];
     double var = kxx - ss[i];                               // diag(K_tete - V^T V), gp_core.py:181
     if (ss2) var = kxx - (ss[i] + ss2[i]);
     sd = sqrt(var);                                         // gp_core.py:187 (NaN if var < 0)
@@ -1159,7 +1161,9 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
   const bool xs_dev = is_device_ptr(Xs);
   const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
   double* vec = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 7, (void**)&vec));
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 8, (void**)&vec));
+  // a kernel with a polynomial / exponential-decay factor: k(x, x) per candidate (never on the add-UCB group path)
+  double* kss = (want_var && !gp->kd.stationary && !pre_gathered) ? vec + 7 * mc_max : nullptr;
   double* mu_raw = vec; double* ss = vec + mc_max; double* ss2 = vec + 2 * mc_max;
   double* mu_c = vec + 3 * mc_max; double* sd_c = vec + 4 * mc_max; double* val_c = vec + 5 * mc_max;
   bool have = false; double bv = 0.0; int64_t bi = -1;
@@ -1174,18 +1178,22 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
       if (mv_dev) mv_c = mean_vals + i0;
       else DFH_TRY(to_device(ctx, mean_vals + i0, (size_t)mc * 8, SCR_STAGE_D, &mv_c));
     }
+    double* xsp = nullptr; double* nsp = nullptr;
     if (aug) {
       // mean from the real data, variance from the augmented factor (gp_core.py:195, 207-213)
       DFH_TRY(posterior_chunk(aug, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, true, nullptr, nullptr, vec + 6 * mc_max, ss, ss2));
-      DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, false, nullptr, nullptr, mu_raw, nullptr, nullptr));
+      DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, false, nullptr, nullptr, mu_raw, nullptr, nullptr,
+                              0, &xsp, &nsp));
     } else {
-      DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, want_var, &h, nullptr, mu_raw, ss, ss2));
+      DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, want_var, &h, nullptr, mu_raw, ss, ss2,
+                              0, &xsp, &nsp));
     }
+    if (kss) DFH_TRY(prior_diag(ctx, gp->kd, xsp, nsp, mc, kss));
     {
       SectionTimer t(ctx, DFH_T_ACQ);
       const bool need_val = vals_out || best_val || best_idx;
       hipLaunchKernelGGL(k_posterior_acq, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, acq, p0, p1,
-                         kxx, mean_const, mv_c, mu_raw, want_var ? ss : nullptr,
+                         kxx, kss, mean_const, mv_c, mu_raw, want_var ? ss : nullptr,
                          (want_var && h.q > 0) ? ss2 : nullptr, (long)mc, mu_out ? mu_c : nullptr,
                          sd_out ? sd_c : nullptr, need_val ? val_c : nullptr);
       DFH_LAUNCH_CHECK();
@@ -1299,7 +1307,7 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
     const double kxx = kd.outer_scale * kerndev_part_kxx(kd, g);        // kern_scale * kernel_j(x, x)
     const int64_t mg = m_per_group[g];
     hipLaunchKernelGGL(k_posterior_acq, dim3((unsigned)((mg + 255) / 256)), dim3(256), 0, ctx->stream, (int)DFH_ACQ_UCB,
-                       betas[g], 0.0, kxx, 0.0, (const double*)nullptr, mu_raw + off[g], ss + off[g],
+                       betas[g], 0.0, kxx, (const double*)nullptr, 0.0, (const double*)nullptr, mu_raw + off[g], ss + off[g],
                        (const double*)nullptr, (long)mg, (double*)nullptr, (double*)nullptr, val + off[g]);
     DFH_LAUNCH_CHECK();
   }

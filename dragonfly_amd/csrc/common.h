@@ -188,15 +188,17 @@ int gemm_skinny_nt(dfh_ctx* ctx, int64_t m, int64_t N, int64_t K, double alpha, 
 // row norms Np[n][n_parts] ((X**2).sum(axis=1), general_utils.py:66-67).
 #define DFH_KERNEL_DIST 3   // internal: clip(dist_sq) itself (dfh_dist_squared)
 struct PartDev {
-  int kind;        // DFH_KERNEL_SE | DFH_KERNEL_MATERN | DFH_KERNEL_DIST
+  int kind;        // DFH_KERNEL_SE | DFH_KERNEL_MATERN | DFH_KERNEL_DIST | DFH_KERNEL_POLY | DFH_KERNEL_EXPDECAY
   int poff;        // first packed column
   int kc;          // packed (padded to 4) column count
-  int p;           // Matern: int(nu)
-  double scale_c;  // SE: scale ; Matern: scale * norm_constant (kernel.py:298)
+  int p;           // Matern: int(nu) ; Poly: order ; ExpDecay: number of (real) columns
+  double scale_c;  // SE / Poly / ExpDecay: scale ; Matern: scale * norm_constant (kernel.py:298)
   double s8, s2;   // Matern: sqrt(8 nu), sqrt(2 nu)
-  double gfac;     // Matern: Gamma(p+1)/Gamma(2p+1)
-  double coeff[8]; // Matern: (p+i)!/(i!(p-i)!)
+  double gfac;     // Matern: Gamma(p+1)/Gamma(2p+1) ; ExpDecay: offset
+  double coeff[8]; // Matern: (p+i)!/(i!(p-i)!) ; ExpDecay: powers
+  double k0;       // SE / Matern: k_part(x, x) (distance 0); unused for the non-stationary kinds
 };
+constexpr int EXPDECAY_MAX_DIM = 8;
 struct KernDev {
   int kind = 0, dim = 0, n_parts = 0, P = 0;
   bool multi = false;          // additive: sum over parts then outer scale; product: scale * prod over parts
@@ -211,7 +213,8 @@ struct KernDev {
   int* d_lcols = nullptr;
   double* d_bw = nullptr;
   void* d_blob = nullptr;      // the one device allocation behind the four pointers (owned if set)
-  double kxx = 0.0;            // prior variance k(x,x)
+  double kxx = 0.0;            // prior variance k(x,x) of a stationary kernel
+  bool stationary = true;      // false with a Poly / ExpDecay part: k(x,x) depends on x (prior_diag)
 };
 int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* out);
 // host-only part of kerndev_build, and the upload of several descriptors with one copy into a
@@ -231,6 +234,8 @@ int kerndev_build_dist(dfh_ctx* ctx, int dim, KernDev* out);
 int kerndev_clone(dfh_ctx* ctx, const KernDev& src, KernDev* out);   // deep copy with its own device image
 void kerndev_free(KernDev* kd);
 double kerndev_part_kxx(const KernDev& kd, int part);
+// out[i] = k(x_i, x_i) from the packed inputs of m points (any kernel; needed when !kd.stationary)
+int prior_diag(dfh_ctx* ctx, const KernDev& kd, const double* Xp, const double* Np, int64_t m, double* out);
 
 // Xp[n][P] / Np[n][n_parts] for parts [part_lo, part_hi) (other parts' columns untouched).
 // pre_gathered: X holds only the columns of part_lo (ldx >= |cols|), as in add-UCB group

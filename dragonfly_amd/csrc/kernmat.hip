@@ -123,7 +123,31 @@ __device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq, const
   return dsq;                                              // DFH_KERNEL_DIST
 }
 
-template <int TJ, bool MULTI>
+// x ** order as NumPy evaluates it for a scalar integer exponent: its fast paths for 0, 1 and 2
+// (ones, copy, square), libm pow otherwise.
+__device__ __forceinline__ double pow_order(double x, int order) {
+  if (order == 0) return 1.0;
+  if (order == 1) return x;
+  if (order == 2) return x * x;
+  return pow(x, (double)order);
+}
+
+// Polynomial kernel from the dot product of the scaled points (kernel.py:381-386)
+__device__ __forceinline__ double poly_eval(const PartDev& pd, double dot) {
+  return pd.scale_c * pow_order(dot + 1.0, pd.p);
+}
+
+// Exponential-decay kernel from the two (unscaled) points (kernel.py:418-432): the product runs
+// over the dimensions in order, starting from the scale, and the offset is added last.
+__device__ __forceinline__ double expdecay_eval(const PartDev& pd, const double* x, const double* y) {
+  double r = pd.scale_c;
+  for (int c = 0; c < pd.p; ++c) r *= 1.0 / pow(1.0 + (x[c] + y[c]), pd.coeff[c]);
+  return r + pd.gfac;
+}
+
+// NS: the parts may be polynomial / exponential-decay kernels (an instance of its own: their pow()
+// calls cost the stationary multi-part kernel its registers)
+template <int TJ, bool MULTI, bool NS = false>
 __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
   constexpr int BN = 2 * TJ * 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -211,9 +235,17 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int lc = wn * TJ * 16 + j * 16 + l15;
-          double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];     // general_utils.py:66-68
-          dsq = dsq < 0.0 ? 0.0 : dsq;                           // np.clip(.,0,inf), NaN kept
-          const double kv = kern_eval(pd, dsq, ec);
+          double kv;
+          if (NS && pd.kind == DFH_KERNEL_POLY) {
+            kv = poly_eval(pd, acc[i][j][r]);
+          } else if (NS && pd.kind == DFH_KERNEL_EXPDECAY) {
+            // the part's columns (kc <= KM_KC: one chunk) are still in the operand tiles
+            kv = expdecay_eval(pd, As + lr * KM_KP, Bs + lc * KM_KP);
+          } else {
+            double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];     // general_utils.py:66-68
+            dsq = dsq < 0.0 ? 0.0 : dsq;                           // np.clip(.,0,inf), NaN kept
+            kv = kern_eval(pd, dsq, ec);
+          }
           if (MULTI) res[i][j][r] = p.product ? res[i][j][r] * kv : res[i][j][r] + kv;   // kernel.py:493 / :588
           else acc[i][j][r] = kv;
         }
@@ -609,7 +641,9 @@ __global__ void k_pack_cols(const double* __restrict__ X, long n, long ldx, int 
     const long row = idx / w;
     const int pc = c_lo + (int)(idx - row * w);
     const int c = cols[pc];
-    Xp[row * P + pc] = c >= 0 ? X[row * ldx + c] / bw[pc] : 0.0;    // kernel.py:181
+    // kernel.py:181 (X / bandwidths); a negative entry is a polynomial kernel's scaling: X * s (kernel.py:383)
+    const double b = bw[pc];
+    Xp[row * P + pc] = c >= 0 ? (b < 0.0 ? X[row * ldx + c] * -b : X[row * ldx + c] / b) : 0.0;
   }
 }
 
@@ -656,12 +690,27 @@ double factorial_d(int n) {
   return r;
 }
 
+double part_value_at_zero(const PartDev& pd);
+
 int fill_part(PartDev& pd, int kind, double scale, double nu) {
   pd.kind = kind;
-  pd.p = 0; pd.s8 = pd.s2 = pd.gfac = 0.0;
+  pd.p = 0; pd.s8 = pd.s2 = pd.gfac = 0.0; pd.k0 = 0.0;
   for (int i = 0; i < 8; ++i) pd.coeff[i] = 0.0;
   if (kind == DFH_KERNEL_SE || kind == DFH_KERNEL_DIST) {
     pd.scale_c = scale;
+    pd.k0 = part_value_at_zero(pd);
+    return DFH_OK;
+  }
+  if (kind == DFH_KERNEL_POLY) {               // nu carries the order
+    if (!(nu >= 0.0 && nu <= 64.0 && nu == floor(nu))) {
+      dfh_set_error("polynomial kernel: the order has to be an integer in [0, 64] (got %g)", nu);
+      return DFH_ERR_BAD_ARG;
+    }
+    pd.p = (int)nu; pd.scale_c = scale;
+    return DFH_OK;
+  }
+  if (kind == DFH_KERNEL_EXPDECAY) {           // nu carries the offset; powers are set by the caller
+    pd.scale_c = scale; pd.gfac = nu;
     return DFH_OK;
   }
   // Matern: kernel.py:242-253, 259-270
@@ -688,6 +737,7 @@ int fill_part(PartDev& pd, int kind, double scale, double nu) {
   u0 *= (pd.gfac * exp(-pd.s2 * 0.0));
   const double norm_constant = 1.0 / u0;
   pd.scale_c = scale * norm_constant;
+  pd.k0 = part_value_at_zero(pd);
   return DFH_OK;
 }
 
@@ -972,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
 bool lml_tiny_applies(const KernDev* kds, int count, int64_t n) {
   if (n > TINY_MAX_N) return false;
   for (int c = 0; c < count; ++c)
-    if (kds[c].P > TINY_MAX_P || kds[c].n_parts > TINY_MAX_PARTS || kds[c].P < 1) return false;
+    if (kds[c].P > TINY_MAX_P || kds[c].n_parts > TINY_MAX_PARTS || kds[c].P < 1 || !kds[c].stationary) return false;
   return true;
 }
 
@@ -1058,21 +1108,57 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   return DFH_OK;
 }
 
+// One part from (kind, scale, nu, per-column parameters): SE / Matern bandwidths divide the inputs,
+// polynomial scalings multiply them (stored negated, see k_pack_cols), exponential-decay powers go
+// into the part and its inputs stay as they are.
+static int make_part(KernDev* kd, int kind, double scale, double nu, const int* cols, const double* par, int ncols) {
+  PartDev pd;
+  DFH_TRY(fill_part(pd, kind, scale, nu));
+  std::vector<double> bw((size_t)ncols);
+  if (kind == DFH_KERNEL_POLY) {
+    for (int c = 0; c < ncols; ++c) {
+      if (!(par[c] > 0.0)) { dfh_set_error("polynomial kernel: dim_scalings must be positive"); return DFH_ERR_BAD_ARG; }
+      bw[c] = -par[c];
+    }
+  } else if (kind == DFH_KERNEL_EXPDECAY) {
+    if (ncols > EXPDECAY_MAX_DIM) {
+      dfh_set_error("exponential-decay kernel: at most %d dimensions (got %d)", EXPDECAY_MAX_DIM, ncols);
+      return DFH_ERR_BAD_ARG;
+    }
+    pd.p = ncols;
+    for (int c = 0; c < ncols; ++c) { pd.coeff[c] = par[c]; bw[c] = 1.0; }
+  } else {
+    for (int c = 0; c < ncols; ++c) bw[c] = par[c];
+  }
+  add_part_cols(kd, pd, cols, bw.data(), ncols);
+  kd->parts.push_back(pd);
+  return DFH_OK;
+}
+
+static bool kind_is_stationary(int kind) { return kind == DFH_KERNEL_SE || kind == DFH_KERNEL_MATERN; }
+
 int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
   DFH_ARG(k != nullptr && kd != nullptr);
   DFH_ARG(k->dim >= 1);
   kd->kind = k->kind; kd->dim = k->dim; kd->P = 0;
   kd->parts.clear(); kd->cols.clear(); kd->lcols.clear(); kd->bw.clear();
+  kd->stationary = true; kd->kxx = 0.0;
   if (k->kind == DFH_KERNEL_SE || k->kind == DFH_KERNEL_MATERN) {
     DFH_ARG(k->bw != nullptr);
-    PartDev pd;
-    DFH_TRY(fill_part(pd, k->kind, k->scale, k->nu));
     std::vector<int> ident(k->dim);
     for (int i = 0; i < k->dim; ++i) ident[i] = i;
-    add_part_cols(kd, pd, ident.data(), k->bw, k->dim);
-    kd->parts.push_back(pd);
+    DFH_TRY(make_part(kd, k->kind, k->scale, k->nu, ident.data(), k->bw, k->dim));
     kd->multi = false; kd->product = false; kd->outer_scale = 1.0;
-    kd->kxx = part_value_at_zero(pd);
+    kd->kxx = kd->parts[0].k0;
+  } else if (k->kind == DFH_KERNEL_POLY || k->kind == DFH_KERNEL_EXPDECAY) {
+    // a product with one factor and outer scale 1 (1.0 * k is exact): the generic multi-part
+    // kernel-matrix kernel is the only one that knows these kinds
+    DFH_ARG(k->bw != nullptr);
+    std::vector<int> ident(k->dim);
+    for (int i = 0; i < k->dim; ++i) ident[i] = i;
+    DFH_TRY(make_part(kd, k->kind, k->scale, k->nu, ident.data(), k->bw, k->dim));
+    kd->multi = true; kd->product = true; kd->outer_scale = 1.0;
+    kd->stationary = false;
   } else if (k->kind == DFH_KERNEL_ADDITIVE || k->kind == DFH_KERNEL_PRODUCT) {
     DFH_ARG(k->n_groups >= 1 && k->group_off && k->group_dims && k->sub_kind && k->sub_scale && k->sub_bw);
     const bool product = (k->kind == DFH_KERNEL_PRODUCT);
@@ -1081,21 +1167,51 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
       const int lo = k->group_off[g], hi = k->group_off[g + 1];
       DFH_ARG(hi > lo);
       for (int c = lo; c < hi; ++c) DFH_ARG(k->group_dims[c] >= 0 && k->group_dims[c] < k->dim);
-      DFH_ARG(k->sub_kind[g] == DFH_KERNEL_SE || k->sub_kind[g] == DFH_KERNEL_MATERN);
-      PartDev pd;
-      DFH_TRY(fill_part(pd, k->sub_kind[g], k->sub_scale[g], k->sub_nu ? k->sub_nu[g] : 0.0));
-      add_part_cols(kd, pd, k->group_dims + lo, k->sub_bw + lo, hi - lo);
-      kd->parts.push_back(pd);
-      if (product) acc *= part_value_at_zero(pd);     // K *= kernel(...)        kernel.py:588
-      else acc += part_value_at_zero(pd);             // result += kernel(...)   kernel.py:493
+      const int sk = k->sub_kind[g];
+      DFH_ARG(kind_is_stationary(sk) || (product && (sk == DFH_KERNEL_POLY || sk == DFH_KERNEL_EXPDECAY)));
+      DFH_TRY(make_part(kd, sk, k->sub_scale[g], k->sub_nu ? k->sub_nu[g] : 0.0, k->group_dims + lo,
+                        k->sub_bw + lo, hi - lo));
+      if (!kind_is_stationary(sk)) kd->stationary = false;
+      const double k0 = kd->parts.back().k0;
+      if (product) acc *= k0;                         // K *= kernel(...)        kernel.py:588
+      else acc += k0;                                 // result += kernel(...)   kernel.py:493
     }
     kd->multi = true; kd->product = product; kd->outer_scale = k->scale;
-    kd->kxx = product ? acc : k->scale * acc;        // kernel.py:494
+    kd->kxx = !kd->stationary ? 0.0 : (product ? acc : k->scale * acc);        // kernel.py:494
   } else {
     dfh_set_error("unknown kernel kind %d", k->kind);
     return DFH_ERR_BAD_ARG;
   }
   kd->n_parts = (int)kd->parts.size();
+  return DFH_OK;
+}
+
+// k(x_i, x_i) for every packed point: what the diagonal of kernel(X, X) holds in the reference
+// (gp_core.py:181 takes it from the full test Gram matrix).
+__global__ void k_prior_diag(const PartDev* __restrict__ parts, int n_parts, int multi, int product, double outer,
+                             const double* __restrict__ Xp, const double* __restrict__ Np, long m, int P,
+                             double* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double res = (multi && product) ? outer : 0.0;
+  for (int g = 0; g < n_parts; ++g) {
+    const PartDev& pd = parts[g];
+    double kv;
+    if (pd.kind == DFH_KERNEL_POLY) kv = poly_eval(pd, Np[i * n_parts + g]);
+    else if (pd.kind == DFH_KERNEL_EXPDECAY) kv = expdecay_eval(pd, Xp + i * P + pd.poff, Xp + i * P + pd.poff);
+    else kv = pd.k0;
+    if (!multi) res = kv;
+    else res = product ? res * kv : res + kv;
+  }
+  if (multi && !product) res = outer * res;
+  out[i] = res;
+}
+
+int prior_diag(dfh_ctx* ctx, const KernDev& kd, const double* Xp, const double* Np, int64_t m, double* out) {
+  if (m <= 0) return DFH_OK;
+  hipLaunchKernelGGL(k_prior_diag, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, kd.d_parts,
+                     kd.n_parts, kd.multi ? 1 : 0, kd.product ? 1 : 0, kd.outer_scale, Xp, Np, (long)m, kd.P, out);
+  DFH_LAUNCH_CHECK();
   return DFH_OK;
 }
 
@@ -1232,6 +1348,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM4));
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<2, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
     attr_set = true;
   }
   if (!multi && part_hi == part_lo + 1 && (ldk & 1) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 &&
@@ -1288,7 +1406,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
     if (r0 != 0) b.symmetric = 0;    // only reachable for n1 > 8M rows; diagonal handled in slab 0
     if (multi) {
       dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((rr + KM_BM - 1) / KM_BM));
-      hipLaunchKernelGGL((kernmat_kernel<2, true>), grid, dim3(256), SM2, ctx->stream, b);
+      if (kd.stationary) hipLaunchKernelGGL((kernmat_kernel<2, true>), grid, dim3(256), SM2, ctx->stream, b);
+      else hipLaunchKernelGGL((kernmat_kernel<2, true, true>), grid, dim3(256), SM2, ctx->stream, b);
     } else {
       dim3 grid((unsigned)((n2 + 127) / 128), (unsigned)((rr + KM_BM - 1) / KM_BM));
       hipLaunchKernelGGL((kernmat_kernel<4, false>), grid, dim3(256), SM4, ctx->stream, b);

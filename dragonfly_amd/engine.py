@@ -10,7 +10,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import (ACQ_EI, ACQ_MEAN, ACQ_PI, ACQ_STD, ACQ_TTEI, ACQ_UCB, GET_ALPHA, GET_K, GET_L,
-                   INT32_MIN, KERNEL_ADDITIVE, KERNEL_MATERN, KERNEL_PRODUCT, KERNEL_SE, KernelDesc,
+                   INT32_MIN, KERNEL_ADDITIVE, KERNEL_EXPDECAY, KERNEL_MATERN, KERNEL_POLY, KERNEL_PRODUCT, KERNEL_SE,
+                   KernelDesc,
                    check)
 
 ACQ_IDS = {'mean': ACQ_MEAN, 'ucb': ACQ_UCB, 'ei': ACQ_EI, 'pi': ACQ_PI, 'ttei': ACQ_TTEI,
@@ -80,10 +81,14 @@ class DeviceArray(object):
       pass
 
 
+_SINGLE_KINDS = {'se': KERNEL_SE, 'matern': KERNEL_MATERN, 'poly': KERNEL_POLY, 'expdecay': KERNEL_EXPDECAY}
+
+
 class KernelSpec(object):
   """ Host-side description of a Euclidean kernel, convertible to struct dfh_kernel_desc.
-      kind: 'se' | 'matern' | 'additive' | 'product' (coordinate-wise product of SE / Matern
-      kernels, kernel.py:541). """
+      kind: 'se' | 'matern' | 'poly' (nu = order, bandwidths = dim_scalings) | 'expdecay' (nu =
+      offset, bandwidths = powers) | 'additive' | 'product' (coordinate-wise product, kernel.py:541;
+      its factors may be any of the four single kinds, an additive kernel's only se / matern). """
 
   def __init__(self, kind, dim, scale, bandwidths=None, nu=0.0, groups=None, sub_kinds=None,
                sub_scales=None, sub_nus=None, sub_bandwidths=None):
@@ -116,8 +121,8 @@ class KernelSpec(object):
         spec stays valid (a list of specs may hold one object several times). """
     d = KernelDesc()
     first = len(self._keep)
-    if self.kind in ('se', 'matern'):
-      d.kind = KERNEL_SE if self.kind == 'se' else KERNEL_MATERN
+    if self.kind in _SINGLE_KINDS:
+      d.kind = _SINGLE_KINDS[self.kind]
       d.dim = self.dim
       d.scale = self.scale
       d.nu = self.nu
@@ -136,8 +141,7 @@ class KernelSpec(object):
       off[1:] = np.cumsum([len(g) for g in self.groups])
       dims = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int32).ravel()
                                                   for g in self.groups]), dtype=np.int32)
-      kinds = np.ascontiguousarray([KERNEL_SE if k == 'se' else KERNEL_MATERN
-                                    for k in self.sub_kinds], dtype=np.int32)
+      kinds = np.ascontiguousarray([_SINGLE_KINDS[k] for k in self.sub_kinds], dtype=np.int32)
       scales = _f64(self.sub_scales)
       nus = _f64(self.sub_nus if self.sub_nus is not None else np.zeros(ng))
       bws = _f64(np.concatenate([_f64(np.ravel(b)) for b in self.sub_bandwidths]))

@@ -1,4 +1,5 @@
-"""Euclidean kernels evaluated on the MI355X: SE, Matern, Additive and coordinate-wise Product.
+"""Euclidean kernels evaluated on the MI355X: SE, Matern, Polynomial, Exponential-decay, Additive
+and coordinate-wise Product.
 
 Host-side counterpart of dragonfly/gp/kernel.py: the class names, constructor arguments, the
 `hyperparams` dictionary, the printed form and the error behaviour are the reference's (its lines
@@ -191,6 +192,130 @@ class MaternKernel(_EuclideanDeviceKernel):
     return 'Matern: nu=%0.1f %s %s' % ((self.hyperparams['nu'],) + _scale_and_bandwidth_text(self))
 
 
+class PolyKernel(_EuclideanDeviceKernel):
+  """ The polynomial kernel scale * ((x*s).(y*s) + 1)^order (kernel.py:331-395).  Not stationary:
+      the prior variance k(x, x) depends on x (the library evaluates it per point). """
+
+  def __init__(self, dim, order, scale, dim_scalings=None):
+    super(PolyKernel, self).__init__()
+    self.dim = dim
+    self.set_poly_hyperparams(order, scale, dim_scalings)
+
+  def is_guaranteed_psd(self):
+    return True
+
+  def set_order(self, order):
+    self.add_hyperparams(order=order)
+
+  def set_scale(self, scale):
+    self.add_hyperparams(scale=scale)
+
+  def set_dim_scalings(self, dim_scalings):
+    """ kernel.py:356-364 """
+    if dim_scalings is not None:
+      if len(dim_scalings) != self.dim:
+        raise ValueError('Dimension of dim_scalings should be dim.')
+      dim_scalings = np.array(dim_scalings)
+    self.add_hyperparams(dim_scalings=dim_scalings)
+
+  def set_single_scaling(self, scaling):
+    self.set_dim_scalings(None if scaling is None else [scaling] * self.dim)
+
+  def set_poly_hyperparams(self, order, scale, dim_scalings):
+    """ kernel.py:373-380 """
+    self.set_order(order)
+    self.set_scale(scale)
+    if hasattr(dim_scalings, '__len__'):
+      self.set_dim_scalings(dim_scalings)
+    else:
+      self.set_single_scaling(dim_scalings)
+
+  def get_scaled_repr(self, X):
+    return X * self.hyperparams['dim_scalings']
+
+  def to_spec(self, in_dim=None):
+    return _poly_spec(self)
+
+  def __str__(self):
+    return 'Poly: d=%d, scale=%0.2f, %s'%(self.hyperparams['order'], self.hyperparams['scale'],
+                                          ','.join('%0.2f'%(elem) for elem in self.hyperparams['dim_scalings']))
+
+
+class ExpDecayKernel(_EuclideanDeviceKernel):
+  """ The kernel for exponentially decaying functions of Freeze-Thaw Bayesian optimisation,
+      scale * prod_d (1 + x_d + y_d)^(-powers_d) + offset (kernel.py:398-437): the fidelity kernel of
+      the reference's multi-fidelity GPs (euclidean_gp.py:881-887).  Not stationary. """
+
+  def __init__(self, dim, scale=None, offset=None, powers=None):
+    super(ExpDecayKernel, self).__init__()
+    self.dim = dim
+    if not hasattr(powers, '__iter__'):
+      powers = [powers] * dim
+    self.set_hyperparams(scale=scale, offset=offset, powers=powers)
+
+  def is_guaranteed_psd(self):
+    return True
+
+  def get_scaled_repr(self, X):
+    raise NotImplementedError('Not defined for the exponential-decay kernel.')
+
+  def to_spec(self, in_dim=None):
+    return _expdecay_spec(self)
+
+  def __str__(self):
+    return 'ExpDec: sc=%0.3f, offset=%0.3f, pow=%s'%(self.hyperparams['scale'], self.hyperparams['offset'],
+        '[' + ', '.join('%0.3f'%(b) for b in np.ravel(self.hyperparams['powers'])) + ']')
+
+
+def _factor_kind(kern):
+  """ 'se' | 'matern' | 'poly' | 'expdecay' | None for a factor of a grouped kernel.  Decided by the
+      class NAME and the hyper-parameters it carries, so that the reference's own PolyKernel /
+      ExpDecayKernel objects (dragonfly/gp/kernel.py), which `install()` may leave in place inside a
+      product kernel, reach the device as well. """
+  hps = getattr(kern, 'hyperparams', None)
+  if not isinstance(hps, dict):
+    return None
+  name = type(kern).__name__
+  if isinstance(kern, SEKernel):
+    return 'se'
+  if isinstance(kern, MaternKernel):
+    return 'matern'
+  if name == 'PolyKernel' and all(k in hps for k in ('order', 'scale', 'dim_scalings')):
+    order = hps['order']
+    if hps['dim_scalings'] is not None and float(order) == int(order) and 0 <= int(order) <= 64:
+      return 'poly'
+  if name == 'ExpDecayKernel' and all(k in hps for k in ('scale', 'offset', 'powers')):
+    if len(np.ravel(hps['powers'])) <= 8:
+      return 'expdecay'
+  return None
+
+
+def _factor_fields(kern, kind):
+  """ (scale, nu field, per-column field) of one factor, as struct dfh_kernel_desc carries them """
+  hps = kern.hyperparams
+  if kind == 'se':
+    return hps['scale'], 0.0, np.ravel(np.asarray(hps['dim_bandwidths'], dtype=float))
+  if kind == 'matern':
+    return hps['scale'], hps['nu'], np.ravel(np.asarray(hps['dim_bandwidths'], dtype=float))
+  if kind == 'poly':
+    return hps['scale'], float(hps['order']), np.ravel(np.asarray(hps['dim_scalings'], dtype=float))
+  return hps['scale'], float(hps['offset']), np.ravel(np.asarray(hps['powers'], dtype=float))
+
+
+def _poly_spec(kern):
+  scale, order, scalings = _factor_fields(kern, 'poly')
+  if scalings.size != kern.dim:
+    raise ValueError('Dimension of dim_scalings should be dim.')
+  return KernelSpec('poly', kern.dim, scale, scalings, nu=order)
+
+
+def _expdecay_spec(kern):
+  scale, offset, powers = _factor_fields(kern, 'expdecay')
+  if powers.size != kern.dim:
+    raise ValueError('Dimension of powers should be dim.')
+  return KernelSpec('expdecay', kern.dim, scale, powers, nu=offset)
+
+
 class _GroupedKernel(_EuclideanDeviceKernel):
   """ A kernel assembled from SE / Matern factors on groups of coordinates: the additive kernel
       (sum) and the coordinate-wise product kernel.  `_groups()` gives the coordinate lists. """
@@ -206,8 +331,10 @@ class _GroupedKernel(_EuclideanDeviceKernel):
   def get_scaled_repr(self, X):
     raise NotImplementedError('Not defined for grouped kernels.')
 
+  _factor_kinds = ('se', 'matern')          # what the device evaluates inside this grouped kernel
+
   def has_device_spec(self):
-    return all(isinstance(kern, (SEKernel, MaternKernel)) for kern in self.kernel_list)
+    return all(_factor_kind(kern) in self._factor_kinds for kern in self.kernel_list)
 
   def to_spec(self, in_dim=None):
     groups = [[int(c) for c in grp] for grp in self._groups()]
@@ -215,17 +342,15 @@ class _GroupedKernel(_EuclideanDeviceKernel):
       raise ValueError("number of kernels do not correspond to number of groups.")
     kinds, scales, nus, bws = [], [], [], []
     for kern in self.kernel_list:
-      if isinstance(kern, SEKernel):
-        kinds.append('se')
-        nus.append(0.0)
-      elif isinstance(kern, MaternKernel):
-        kinds.append('matern')
-        nus.append(kern.hyperparams['nu'])
-      else:
-        raise TypeError('%s on the device supports SE/Matern sub-kernels only, got %s.'
-                        % (type(self).__name__, type(kern)))
-      scales.append(kern.hyperparams['scale'])
-      bws.append(np.ravel(np.asarray(kern.hyperparams['dim_bandwidths'], dtype=float)))
+      kind = _factor_kind(kern)
+      if kind not in self._factor_kinds:
+        raise TypeError('%s on the device supports %s sub-kernels only, got %s.'
+                        % (type(self).__name__, '/'.join(self._factor_kinds), type(kern)))
+      scale, nu, per_col = _factor_fields(kern, kind)
+      kinds.append(kind)
+      nus.append(nu)
+      scales.append(scale)
+      bws.append(per_col)
     if in_dim is None:
       in_dim = max(1 + max(max(grp) for grp in groups), self.dim)
     return KernelSpec(self._kind, in_dim, self.hyperparams['scale'], groups=groups, sub_kinds=kinds,
@@ -266,6 +391,7 @@ class CoordinateProductKernel(_GroupedKernel):
       (kernel.py:541-591); the kernel of a Euclidean multi-fidelity GP (fidelity x domain). """
   _kind = 'product'
   _label = 'CoordProd'
+  _factor_kinds = ('se', 'matern', 'poly', 'expdecay')
 
   def __init__(self, dim, scale, kernel_list=None, coordinate_list=None):
     super(CoordinateProductKernel, self).__init__()

@@ -43,8 +43,18 @@ extern "C" {
 #define DFH_KERNEL_ADDITIVE 2 /* dragonfly/gp/kernel.py:461 AdditiveKernel over SE/Matern    */
 #define DFH_KERNEL_PRODUCT  3 /* dragonfly/gp/kernel.py:541 CoordinateProductKernel over SE/Matern
                                * (scale * prod_g k_g(X[:, coords_g]); same group fields as ADDITIVE) */
+#define DFH_KERNEL_POLY     4 /* dragonfly/gp/kernel.py:331 PolyKernel: scale * ((x*s).(y*s) + 1)^order;
+                               * `nu` = order (a non-negative integer), `bw` = dim_scalings s   */
+#define DFH_KERNEL_EXPDECAY 5 /* dragonfly/gp/kernel.py:398 ExpDecayKernel (the multi-fidelity
+                               * kernel of euclidean_gp.py:881-887): scale * prod_d (1 + x_d +
+                               * y_d)^-powers_d + offset; `nu` = offset, `bw` = powers, dim <= 8.
+                               * POLY and EXPDECAY are not stationary: k(x,x) depends on x.  They
+                               * are accepted alone and as factors of a PRODUCT (sub_kind, with
+                               * sub_nu = order / offset and sub_bw = scalings / powers), not as
+                               * groups of an ADDITIVE kernel.                                   */
 
-/* One Euclidean kernel.  For SE / MATERN: `dim`, `scale`, `nu`, `bw[dim]` (dim_bandwidths).
+/* One Euclidean kernel.  For SE / MATERN: `dim`, `scale`, `nu`, `bw[dim]` (dim_bandwidths); POLY /
+ * EXPDECAY reuse `nu` and `bw` as described above.
  * For ADDITIVE: `scale` is the outer scale, and the n_groups sub-kernels are described by the
  * flattened arrays: group g covers input columns group_dims[group_off[g] .. group_off[g+1])
  * with bandwidths sub_bw[group_off[g] .. group_off[g+1]) , kind sub_kind[g], scale
@@ -53,12 +63,12 @@ typedef struct dfh_kernel_desc {
   int32_t kind;
   int32_t dim;            /* input dimension d (number of columns of X)                      */
   double  scale;
-  double  nu;             /* MATERN only                                                     */
-  const double*  bw;      /* [dim]   (SE / MATERN)                                           */
+  double  nu;             /* MATERN: nu ; POLY: order ; EXPDECAY: offset                     */
+  const double*  bw;      /* [dim]   SE / MATERN: bandwidths ; POLY: scalings ; EXPDECAY: powers */
   int32_t n_groups;       /* ADDITIVE only                                                   */
   const int32_t* group_off;   /* [n_groups+1]                                                */
   const int32_t* group_dims;  /* [group_off[n_groups]] column indices                        */
-  const int32_t* sub_kind;    /* [n_groups] DFH_KERNEL_SE | DFH_KERNEL_MATERN                */
+  const int32_t* sub_kind;    /* [n_groups] SE | MATERN (| POLY | EXPDECAY in a PRODUCT)     */
   const double*  sub_scale;   /* [n_groups]                                                  */
   const double*  sub_nu;      /* [n_groups]                                                  */
   const double*  sub_bw;      /* [group_off[n_groups]]                                       */

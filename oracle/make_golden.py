@@ -261,6 +261,71 @@ def gen_mfgp_case():
   print('wrote mfgp_f1_d3_n70')
 
 
+def gen_poly_expdecay_cases():
+  """ The two kernels that are not stationary (kernel.py:331-437): their matrices, a plain GP
+      with a polynomial kernel, and the multi-fidelity GP the reference's MF fitter builds for
+      fidel_kernel_type='expdecay' (euclidean_gp.py:881-887, 707): scale * ExpDecay(z) * SE(x);
+      posterior mean / std / covariance, hallucinated std, lml, a joint sample. """
+  from dragonfly.gp.euclidean_gp import EuclideanMFGP
+  from dragonfly.gp.gp_core import GP
+  from dragonfly.gp import kernel as rk
+  from dragonfly.utils.general_utils import draw_gaussian_samples
+  rs = np.random.RandomState(1311)
+  res = {}
+  # kernel matrices
+  X1, X2 = rs.random_sample((40, 3)) - 0.3, rs.random_sample((27, 3)) - 0.3
+  scalings = np.array([0.8, 1.3, 0.45])
+  for order in (1, 2, 3, 5):
+    kern = rk.PolyKernel(3, order, 1.7, scalings)
+    res['poly%d_K12' % order] = kern(X1, X2)
+    res['poly%d_K11' % order] = kern(X1)
+  Z1, Z2 = rs.random_sample((33, 2)), rs.random_sample((21, 2))
+  powers = np.array([1.6, 0.7])
+  ed = rk.ExpDecayKernel(2, 1.3, 0.21, powers)
+  res.update(X1=X1, X2=X2, scalings=scalings, Z1=Z1, Z2=Z2, powers=powers, ed_scale=1.3, ed_offset=0.21,
+             ed_K12=ed(Z1, Z2), ed_K11=ed(Z1))
+  # a GP with the polynomial kernel
+  n, m = 50, 29
+  Xp = rs.random_sample((n, 3)) - 0.5
+  Yp = (Xp.sum(axis=1)) ** 2 - Xp[:, 0] + 0.03 * rs.randn(n)
+  pk = rk.PolyKernel(3, 3, 0.9, np.array([1.1, 0.7, 0.9]))
+  p_noise, p_mean = float(Yp.var() / 15), float(np.median(Yp))
+  pgp = GP(list(Xp), list(Yp), pk, lambda x: np.array([p_mean] * len(x)), p_noise)
+  Xps = rs.random_sample((m, 3)) - 0.5
+  p_mu, p_sd = pgp.eval(list(Xps), 'std')
+  Xph = rs.random_sample((3, 3)) - 0.5
+  _, p_sdh = pgp.eval_with_hallucinated_observations(list(Xps), list(Xph), 'std')
+  res.update(p_X=Xp, p_Y=Yp, p_scalings=np.array([1.1, 0.7, 0.9]), p_order=3, p_scale=0.9, p_noise=p_noise,
+             p_mean=p_mean, p_alpha=pgp.alpha, p_lml=pgp.compute_log_marginal_likelihood(), p_Xs=Xps, p_mu=p_mu,
+             p_sd=p_sd, p_Xh=Xph, p_sdh=p_sdh)
+  # the multi-fidelity GP with the exponential-decay fidelity kernel
+  n, fd, dd, m = 64, 2, 3, 31
+  ZZ, XX = rs.random_sample((n, fd)), rs.random_sample((n, dd))
+  YY = np.sin(3 * XX.sum(axis=1)) * (1.0 - 0.4 / (1.0 + 3 * ZZ.sum(axis=1))) + 0.04 * rs.randn(n)
+  f_powers, f_offset, dbw = np.array([1.2, 2.3]), 0.15, np.array([0.4, 0.55, 0.7])
+  scale, noise, mean_c = 1.4, float(YY.var() / 20), float(np.median(YY))
+  fidel_kernel = rk.ExpDecayKernel(fd, 1.0, f_offset, f_powers)
+  domain_kernel = rk.SEKernel(dd, 1.0, dbw)
+  gp = EuclideanMFGP(list(ZZ), list(XX), list(YY), None, scale, fidel_kernel, domain_kernel,
+                     lambda x: np.array([mean_c] * len(x)), noise)
+  Zs, Xs = rs.random_sample((m, fd)), rs.random_sample((m, dd))
+  mu, sd = gp.eval_at_fidel(list(Zs), list(Xs), 'std')
+  _, cov = gp.eval_at_fidel(list(Zs), list(Xs), 'covar')
+  Zh, Xh = rs.random_sample((4, fd)), rs.random_sample((4, dd))
+  _, sdh = gp.eval_at_fidel_with_hallucinated_observations(list(Zs), list(Xs), list(Zh), list(Xh), 'std')
+  U = rs.randn(m)
+  np.random.seed(77)
+  sample = gp.draw_mf_samples(1, list(Zs), list(Xs)).ravel()
+  np.random.seed(77)
+  sample_normals = np.random.normal(size=(m, 1)).ravel()
+  res.update(ZZ=ZZ, XX=XX, YY=YY, f_powers=f_powers, f_offset=f_offset, dbw=dbw, scale=scale, noise=noise,
+             mean_c=mean_c, K=gp.K_trtr_wo_noise, L=gp.L, alpha=gp.alpha,
+             lml=gp.compute_log_marginal_likelihood(), Zs=Zs, Xs=Xs, mu=mu, sd=sd, cov=cov, Zh=Zh, Xh=Xh,
+             sdh=sdh, sample=sample, sample_normals=sample_normals, U=U)
+  np.savez_compressed(os.path.join(OUT, 'poly_expdecay.npz'), **res)
+  print('wrote poly_expdecay')
+
+
 def gen_pdoo_cases():
   """ The reference's PDOO (utils/doo.py, oper_utils.py:257-271) on closed-form objectives -- value,
       point and the full query sequence -- and its acquisitions maximised with acq_opt_method
@@ -549,6 +614,9 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'mfgp':
     gen_mfgp_case()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'polyexp':
+    gen_poly_expdecay_cases()
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'slice':
     gen_slice_cases()
     sys.exit(0)
@@ -565,6 +633,7 @@ if __name__ == '__main__':
   gen_fitter_case()
   gen_c1_case()
   gen_mfgp_case()
+  gen_poly_expdecay_cases()
   gen_pdoo_cases()
   gen_slice_cases()
   gen_trajectory_case()

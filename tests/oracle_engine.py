@@ -13,7 +13,7 @@ from oracle import ref_numpy as O
 
 def to_oracle_spec(spec):
   """ dragonfly_amd.engine.KernelSpec -> oracle KernelSpec """
-  if spec.kind in ('se', 'matern'):
+  if spec.kind in ('se', 'matern', 'poly', 'expdecay'):
     return O.KernelSpec(spec.kind, spec.dim, spec.scale, spec.bandwidths, nu=spec.nu)
   subs = [O.KernelSpec(kind, len(grp), sc, bw, nu=nu)
           for kind, grp, sc, nu, bw in zip(spec.sub_kinds, spec.groups, spec.sub_scales, spec.sub_nus,

@@ -1,0 +1,81 @@
+"""MI355X: the polynomial and exponential-decay kernels on the device (DFH_KERNEL_POLY /
+DFH_KERNEL_EXPDECAY, alone and as factors of the product kernel), the per-candidate prior variance
+their posteriors need, against the real reference's outputs and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import ref_numpy as O
+from polyexp_replay import check
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kernels_gp_and_mf_gp_against_reference_outputs(engine):
+  check(tol=1e-10)
+
+
+@pytest.mark.parametrize('n1,n2,d', [(1, 1, 1), (130, 67, 5), (300, 515, 8)])
+def test_kernel_matrices_against_the_oracle(engine, n1, n2, d):
+  """ ragged sizes (tile edges), symmetric and cross, both kinds alone and inside a product """
+  from dragonfly_amd import kernel as K
+  rs = np.random.RandomState(n1 + d)
+  X1, X2 = rs.random_sample((n1, d)), rs.random_sample((n2, d))
+  sc, pw = rs.random_sample(d) + 0.3, 3 * rs.random_sample(d) + 0.1
+  pairs = [(K.PolyKernel(d, 4, 0.8, sc), O.KernelSpec('poly', d, 0.8, sc, nu=4)),
+           (K.ExpDecayKernel(d, 1.1, 0.05, pw), O.KernelSpec('expdecay', d, 1.1, pw, nu=0.05))]
+  if d >= 5:
+    g0, g1, g2 = [0, 3], [1, 2], list(range(4, d))
+    bw = rs.random_sample(len(g2)) + 0.4
+    pairs.append((K.CoordinateProductKernel(d, 1.9, [K.ExpDecayKernel(2, 1.0, 0.1, pw[:2]), K.PolyKernel(2, 2, 1.0, sc[:2]),
+                                                      K.MaternKernel(len(g2), 1.5, 1.0, bw)], [g0, g1, g2]),
+                  O.KernelSpec('product', d, 1.9, groups=[g0, g1, g2],
+                               subs=[O.KernelSpec('expdecay', 2, 1.0, pw[:2], nu=0.1), O.KernelSpec('poly', 2, 1.0, sc[:2], nu=2),
+                                     O.KernelSpec('matern', len(g2), 1.0, bw, nu=2.5 - 1.0)])))
+  for kern, spec in pairs:
+    assert relerr(kern(X1, X2), spec(X1, X2)) < 1e-13
+    assert relerr(kern(X1), spec(X1)) < 1e-13
+
+
+def test_posterior_and_acquisitions_with_a_non_stationary_kernel(engine):
+  """ fused posterior + EI / UCB arg-max and a joint Thompson block with per-candidate prior variances """
+  from dragonfly_amd import kernel as K
+  from dragonfly_amd.gp_core import GP
+  rs = np.random.RandomState(5)
+  n, fd, dd, m = 700, 1, 4, 5000
+  X = rs.random_sample((n, fd + dd))
+  Y = np.sin(3 * X[:, 1:].sum(axis=1)) * (1 - 0.5 / (1 + 4 * X[:, 0])) + 0.05 * rs.randn(n)
+  pw, bw = np.array([1.7]), np.full(dd, 0.5)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 20)
+  kern = K.CoordinateProductKernel(fd + dd, float(Y.var()), [K.ExpDecayKernel(fd, 1.0, 0.2, pw), K.SEKernel(dd, 1.0, bw)],
+                                   [[0], [1, 2, 3, 4]])
+  spec = O.KernelSpec('product', fd + dd, float(Y.var()), groups=[[0], [1, 2, 3, 4]],
+                      subs=[O.KernelSpec('expdecay', fd, 1.0, pw, nu=0.2), O.KernelSpec('se', dd, 1.0, bw)])
+  gp = GP(list(X), list(Y), kern, lambda x: np.array([mean_c] * len(x)), noise)
+  og = O.GPOracle(X, Y, spec, mean_c, noise)
+  Xs = rs.random_sample((m, fd + dd))
+  mu, sd = gp.eval(Xs, 'std')
+  mur, sdr = og.eval(Xs, 'std')
+  assert relerr(gp.alpha, og.alpha) < 1e-10 and relerr(mu, mur) < 1e-10 and relerr(sd, sdr) < 1e-9
+  prior = np.diag(spec(Xs[:50]))
+  assert prior.max() / prior.min() > 1.2                 # the prior variance really varies
+  for acq, params in (('ei', (float(Y.max()), 0.0)), ('ucb', (2.5, 0.0))):
+    bv, bi, vals = gp.device_gp.acq_argmax(acq, Xs, params=params, mean_const=mean_c, return_vals=True)
+    want = O.acq_values(acq, mur, sdr, params[0])
+    assert relerr(vals, want) < 1e-8 and bi == int(np.argmax(want))
+  U = rs.randn(1024)
+  _, ti, samp, _ = gp.device_gp.thompson(Xs[:1024], U, block=512, mean_const=mean_c, return_samples=True)
+  want = og.draw_samples_blocked(Xs[:1024], U, 512)
+  assert relerr(samp, want) < 1e-6 and ti == int(np.argmax(want))
+
+
+def test_bad_descriptions_are_rejected(engine):
+  from dragonfly_amd import kernel as K
+  X = np.random.RandomState(0).random_sample((5, 9))
+  with pytest.raises(ValueError):
+    K.ExpDecayKernel(9, 1.0, 0.1, np.ones(9))(X)           # more than 8 dimensions
+  with pytest.raises(ValueError):
+    K.PolyKernel(9, 2.5, 1.0, np.ones(9))(X)               # the order has to be an integer
+  add = K.AdditiveKernel(1.0, [K.PolyKernel(4, 2, 1.0, np.ones(4)), K.SEKernel(5, 1.0, np.ones(5))],
+                         [[0, 1, 2, 3], [4, 5, 6, 7, 8]])
+  assert not add.has_device_spec()                         # additive groups stay SE / Matern on the device
