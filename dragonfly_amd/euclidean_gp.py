@@ -135,7 +135,8 @@ def get_euclidean_integral_gp_kernel_with_scale(kernel_type, scale, kernel_hyper
                                                 gp_cts_hps, gp_dscr_hps,
                                                 use_same_bandwidth, add_gp_groupings=None,
                                                 esp_kernel_type=None):
-  """ euclidean_gp.py:808-900 for the se / matern (and additive) kernels. """
+  """ euclidean_gp.py:808-900 for the se / matern / poly / expdecay (and additive) kernels; the
+      reference's 'esp' kernels are not part of the device path. """
   # pylint: disable=unused-argument
   dim = kernel_hyperparams['dim']
   is_additive = False
@@ -145,15 +146,32 @@ def get_euclidean_integral_gp_kernel_with_scale(kernel_type, scale, kernel_hyper
   else:
     is_additive = True
     grp_scale = 1.0
-  if kernel_type not in ['se', 'matern']:
+  if kernel_type not in ['se', 'matern', 'poly', 'expdecay']:
     raise Exception('Unknown kernel type %s!'%(kernel_type))
-  if use_same_bandwidth:
-    ke_dim_bandwidths = [np.exp(gp_cts_hps[0])] * dim
-    gp_cts_hps = gp_cts_hps[1:]
-  else:
-    ke_dim_bandwidths = np.exp(gp_cts_hps[0:dim])
-    gp_cts_hps = gp_cts_hps[dim:]
-  if kernel_type == 'se':
+  if kernel_type in ['se', 'matern', 'poly']:
+    if use_same_bandwidth:
+      ke_dim_bandwidths = [np.exp(gp_cts_hps[0])] * dim
+      gp_cts_hps = gp_cts_hps[1:]
+    else:
+      ke_dim_bandwidths = np.exp(gp_cts_hps[0:dim])
+      gp_cts_hps = gp_cts_hps[dim:]
+  if kernel_type == 'poly':                 # euclidean_gp.py:870-879
+    if 'order' not in kernel_hyperparams or kernel_hyperparams['order'] < 0:
+      poly_order = gp_dscr_hps[0]
+      gp_dscr_hps = gp_dscr_hps[1:]
+    else:
+      poly_order = kernel_hyperparams['order']
+    grp_kernels = [gp_kernel.PolyKernel(dim=len(grp), order=poly_order, scale=grp_scale, \
+                     dim_scalings=get_sublist_from_indices(ke_dim_bandwidths, grp))
+                   for grp in add_gp_groupings]
+  elif kernel_type == 'expdecay':           # euclidean_gp.py:880-887
+    exp_decay_offset = np.exp(gp_cts_hps[0])
+    exp_decay_powers = np.exp(gp_cts_hps[1:dim+1])
+    gp_cts_hps = gp_cts_hps[dim+1:]
+    grp_kernels = [gp_kernel.ExpDecayKernel(dim=len(grp), scale=grp_scale, \
+                    offset=exp_decay_offset, powers=exp_decay_powers)
+                   for grp in add_gp_groupings]
+  elif kernel_type == 'se':
     grp_kernels = [gp_kernel.SEKernel(dim=len(grp), scale=grp_scale, \
                      dim_bandwidths=get_sublist_from_indices(ke_dim_bandwidths, grp))
                    for grp in add_gp_groupings]
@@ -208,11 +226,13 @@ class EuclideanGPFitter(object):
       discrete = [matern nu (if tuned), additive group size (if additive)]. """
   # pylint: disable=too-many-instance-attributes
 
+  _option_specs = euclidean_gp_args
+
   def __init__(self, X, Y, options=None, reporter=None):
     assert len(X) == len(Y)
     self.dim = len(X[0])
     self.reporter = reporter
-    self.options = load_options(euclidean_gp_args, partial_options=options)
+    self.options = load_options(self._option_specs, partial_options=options)
     self.X = X
     self.Y = np.asarray(Y, dtype=np.float64)
     self.num_data = len(X)
@@ -348,6 +368,9 @@ class EuclideanGPFitter(object):
     self.cts_hp_optimise = _rand_wrap if method == 'rand' else _tree_wrap
     self.hp_sampler = _rand_exp_sampling_wrap
 
+  def _uses_additive_model(self):
+    return self.options.use_additive_gp
+
   # -- building GPs (gp_core.py:501-543; euclidean_gp.py:325-339) ----------------------------------
   def _device_X(self):
     """ The training inputs are uploaded once and reused by every candidate GP. """
@@ -451,6 +474,11 @@ class EuclideanGPFitter(object):
       _, mean_const, noise_var, rest = self._mean_and_noise_from_hps(cts)
       kernel, left_cts, left_dscr = self._kernel_from_hps(rest, dscr, other_gp_params)
       assert len(left_cts) == 0 and len(left_dscr) == 0
+      if not kernel.has_device_spec():
+        # a composition the device does not evaluate itself (host-kernel mode): one fit per candidate
+        return np.array([self._tuning_objective(c, list(dscr_hps[j]) if per_cand_dscr else list(dscr_hps),
+                                                other_gp_params=other_gp_params)
+                         for j, c in enumerate(cts_hps_list)])
       specs.append(kernel.to_spec(self.dim))
       mean_consts.append(float(mean_const))
       noise_vars.append(float(noise_var))
@@ -490,7 +518,7 @@ class EuclideanGPFitter(object):
       opt_gp = self.build_gp(best_cts_hps, best_dscr_hps, other_gp_params=best_other_params)
       opt_hps = (best_cts_hps, best_dscr_hps)
       return 'fitted_gp', opt_gp, opt_hps
-    if self.options.use_additive_gp:
+    if self._uses_additive_model():
       raise NotImplementedError('rand_exp_sampling with additive GPs: use ml_hp_tune_opt="rand".')
     sample_cts_hps, sample_dscr_hps, sample_probs = \
       self.hp_sampler(self._tuning_objective_batch, self.hp_tune_max_evals)

@@ -326,6 +326,39 @@ def gen_poly_expdecay_cases():
   print('wrote poly_expdecay')
 
 
+def gen_mf_fitter_case():
+  """ EuclideanMFGPFitter (euclidean_gp.py:418-710), ML by random search, seeded: the chosen
+      hyper-parameters and the fitted GP's predictions for three fidelity / domain kernel pairs,
+      one of them with a tuned Matern nu (a discrete hyper-parameter). """
+  from dragonfly.gp.euclidean_gp import EuclideanMFGPFitter
+  rs = np.random.RandomState(2718)
+  n, fd, dd = 48, 2, 3
+  ZZ, XX = rs.random_sample((n, fd)), rs.random_sample((n, dd))
+  YY = np.sin(3 * XX.sum(axis=1)) * (1.0 - 0.4 / (1.0 + 3 * ZZ.sum(axis=1))) + 0.04 * rs.randn(n)
+  Zs, Xs = rs.random_sample((20, fd)), rs.random_sample((20, dd))
+  res = dict(ZZ=ZZ, XX=XX, YY=YY, Zs=Zs, Xs=Xs)
+  cases = [('se_se', dict(fidel_kernel_type='se', domain_kernel_type='se')),
+           ('expdecay_se', dict(fidel_kernel_type='expdecay', domain_kernel_type='se')),
+           ('matern_matern', dict(fidel_kernel_type='matern', domain_kernel_type='matern', fidel_matern_nu=-1.0,
+                                  domain_matern_nu=1.5))]
+  for name, kw in cases:
+    opts = Namespace(ml_hp_tune_opt='rand', hp_tune_max_evals=60, hp_tune_criterion='ml', **kw)
+    np.random.seed(1618)
+    fitter = EuclideanMFGPFitter(list(ZZ), list(XX), list(YY), options=opts)
+    _, gp, hps = fitter.fit_gp()
+    res[name + '_cts_hps'] = np.array(hps[0], dtype=float)
+    res[name + '_dscr_hps'] = np.array(hps[1], dtype=float)
+    res[name + '_bounds'] = np.array(fitter.cts_hp_bounds, dtype=float)
+    res[name + '_lml'] = gp.compute_log_marginal_likelihood()
+    res[name + '_noise'] = gp.noise_var
+    res[name + '_scale'] = gp.kernel.hyperparams['scale']
+    mu, sd = gp.eval_at_fidel(list(Zs), list(Xs), 'std')
+    res[name + '_mu'], res[name + '_sd'] = mu, sd
+    res[name + '_rand_after'] = np.random.random()       # the global stream after the fit
+  np.savez_compressed(os.path.join(OUT, 'mf_fitter_f2_d3_n48.npz'), **res)
+  print('wrote mf_fitter_f2_d3_n48')
+
+
 def gen_pdoo_cases():
   """ The reference's PDOO (utils/doo.py, oper_utils.py:257-271) on closed-form objectives -- value,
       point and the full query sequence -- and its acquisitions maximised with acq_opt_method
@@ -617,6 +650,9 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'polyexp':
     gen_poly_expdecay_cases()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'mffitter':
+    gen_mf_fitter_case()
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'slice':
     gen_slice_cases()
     sys.exit(0)
@@ -634,6 +670,7 @@ if __name__ == '__main__':
   gen_c1_case()
   gen_mfgp_case()
   gen_poly_expdecay_cases()
+  gen_mf_fitter_case()
   gen_pdoo_cases()
   gen_slice_cases()
   gen_trajectory_case()

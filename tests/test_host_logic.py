@@ -48,8 +48,14 @@ def test_kernel_desc_marshalling():
   assert [d.group_dims[i] for i in range(3)] == [2, 0, 1]
   assert [d.sub_kind[i] for i in range(2)] == [_lib.KERNEL_SE, _lib.KERNEL_MATERN]
   assert [d.sub_bw[i] for i in range(3)] == [0.5, 0.6, 0.7]
+  d = K.PolyKernel(2, 3, 1.5, [0.5, 0.7]).to_spec().to_desc()        # nu carries the order, bw the scalings
+  assert d.kind == _lib.KERNEL_POLY and d.nu == 3.0 and [d.bw[i] for i in range(2)] == [0.5, 0.7]
+  prod = K.CoordinateProductKernel(3, 2.0, [K.ExpDecayKernel(1, 1.0, 0.1, [2.0]), K.SEKernel(2, 1.0, [0.5, 0.6])],
+                                   [[0], [1, 2]]).to_spec().to_desc()
+  assert prod.kind == _lib.KERNEL_PRODUCT and [prod.sub_kind[i] for i in range(2)] == [_lib.KERNEL_EXPDECAY, _lib.KERNEL_SE]
+  assert prod.sub_nu[0] == 0.1 and [prod.sub_bw[i] for i in range(3)] == [2.0, 0.5, 0.6]    # offset; power, bandwidths
   with pytest.raises(ValueError):
-    KernelSpec('poly', 2, 1.0, [1, 1]).to_desc()
+    KernelSpec('spline', 2, 1.0, [1, 1]).to_desc()
 
 
 def test_option_handler():

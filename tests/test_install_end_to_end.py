@@ -11,6 +11,8 @@ The C-ABI side of the same acquisitions is pinned on the MI355X by tests/test_gp
 import os
 import warnings
 
+from argparse import Namespace
+
 import numpy as np
 import pytest
 
@@ -356,6 +358,20 @@ def _api_mf():
   return val, str(pt), str(hist.query_points), str(hist.query_fidels)
 
 
+def _api_mf_expdecay():
+  """ BOCA with the exponential-decay fidelity kernel (the reference's ExpDecayKernel objects, left in
+      place by install(), reach the device as product factors), ML tuning: the reference's posterior
+      sampling has no parameter order for this kernel (gp_core.py:690 fails on it). """
+  from dragonfly import maximise_multifidelity_function
+  from dragonfly.utils.reporters import get_reporter
+  f = lambda z, x: -float(np.sum((np.asarray(x) - 0.3) ** 2)) - 0.3 * (1 - float(z[0])) * float(np.sin(5 * np.sum(x)))
+  np.random.seed(3)
+  opts = Namespace(fidel_kernel_type='expdecay', mf_gp_fidel_kernel_type='expdecay', gpb_hp_tune_criterion='ml')
+  val, pt, hist = maximise_multifidelity_function(f, [[0, 1]], [[0, 1]] * 2, [1.0], lambda z: 0.2 + 0.8 * float(z[0]),
+                                                  7, options=opts, reporter=get_reporter('silent'))
+  return val, str(pt), str(hist.query_points), str(hist.query_fidels)
+
+
 def _api_moo():
   from dragonfly import multiobjective_maximise_functions
   from dragonfly.utils.reporters import get_reporter
@@ -375,8 +391,9 @@ def _api_min():
   return val, str(pt), str(hist.query_points)
 
 
-@pytest.mark.parametrize('name,install_kwargs', [('mf', {}), ('mf', dict(multi_fidelity=True)), ('moo', {}), ('min', {})],
-                         ids=['mf', 'mf-mfgp', 'moo', 'min'])
+@pytest.mark.parametrize('name,install_kwargs', [('mf', {}), ('mf', dict(multi_fidelity=True)),
+                                                 ('mf_expdecay', dict(multi_fidelity=True)), ('moo', {}), ('min', {})],
+                         ids=['mf', 'mf-mfgp', 'mf-expdecay', 'moo', 'min'])
 def test_top_level_apis_with_default_options(name, install_kwargs, monkeypatch):
   """ dragonfly.maximise_multifidelity_function (BOCA; with and without the mirror MF GP),
       multiobjective_maximise_functions and minimise_function, all options at their defaults. """
@@ -384,14 +401,27 @@ def test_top_level_apis_with_default_options(name, install_kwargs, monkeypatch):
   import_reference()
   from oracle_engine import patch_engine
   from dragonfly_amd import install
-  run = {'mf': _api_mf, 'moo': _api_moo, 'min': _api_min}[name]
+  run = {'mf': _api_mf, 'mf_expdecay': _api_mf_expdecay, 'moo': _api_moo, 'min': _api_min}[name]
   with warnings.catch_warnings():
     warnings.simplefilter('ignore')
     want = run()
     patch_engine(monkeypatch)
     install.install(**install_kwargs)
+    built = []
+    if name == 'mf_expdecay':
+      from dragonfly_amd import mf_gp
+      orig_init = mf_gp.EuclideanMFGP.__init__
+      def spy(self, *a, **k):
+        orig_init(self, *a, **k)
+        built.append((type(self.fidel_kernel).__name__, type(self.domain_kernel).__name__, self._generic))
+      monkeypatch.setattr(mf_gp.EuclideanMFGP, '__init__', spy)
     try:
       got = run()
     finally:
       install.uninstall()
   assert got == want
+  if name == 'mf_expdecay':
+    # every GP with a plain domain kernel had its exponential-decay factor evaluated by the engine; only
+    # products with an ADDITIVE domain factor (BOCA tries those too) are composed on the host
+    assert ('ExpDecayKernel', 'SEKernel', False) in built or ('ExpDecayKernel', 'MaternKernel', False) in built
+    assert all(dom == 'AdditiveKernel' for _, dom, generic in built if generic), set(built)
