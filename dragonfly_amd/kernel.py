@@ -116,7 +116,7 @@ class _EuclideanDeviceKernel(Kernel):
     return np.array([np.linalg.norm(row, ord=order) for row in scaled])
 
   def compute_std_slack(self, X1, X2):
-    pairwise = [float(self.evaluate(x1.reshape(1, -1), x2.reshape(1, -1))) for x1, x2 in zip(X1, X2)]
+    pairwise = [float(self.evaluate(x1.reshape(1, -1), x2.reshape(1, -1))[0, 0]) for x1, x2 in zip(X1, X2)]
     return np.sqrt(self.hyperparams['scale'] - np.array(pairwise))
 
   def change_smoothness(self, factor):

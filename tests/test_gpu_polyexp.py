@@ -15,6 +15,13 @@ def test_kernels_gp_and_mf_gp_against_reference_outputs(engine):
   check(tol=1e-10)
 
 
+def test_reference_known_answers_on_device(engine):
+  """ gp/unittest_kernel.py:126-151 (polynomial kernel; SE x polynomial over the same coordinates) """
+  from dragonfly_amd import kernel as K
+  from test_polyexp_cpu import known_answers
+  known_answers(K)
+
+
 @pytest.mark.parametrize('n1,n2,d', [(1, 1, 1), (130, 67, 5), (300, 515, 8)])
 def test_kernel_matrices_against_the_oracle(engine, n1, n2, d):
   """ ragged sizes (tile edges), symmetric and cross, both kinds alone and inside a product """

@@ -201,3 +201,31 @@ def test_install_rebinds_reference_names():
   finally:
     install.uninstall()
   assert ref_egp.EuclideanMFGP is orig_mfgp
+
+
+def test_reference_se_kernel_helper_known_answers(monkeypatch):
+  """ gp/unittest_kernel.py:153-209: effective norms of the SE kernel (known answers) and the
+      std-slack bounds, with the kernel matrices coming from the engine """
+  from oracle_engine import patch_engine
+  patch_engine(monkeypatch)
+  data_1, data_2 = np.array([1, 2]), np.array([[0, 1, 2], [1, 1, 0.5]])
+  for data, bws, dim, l2, l1 in ((data_1, [0.1, 1], 2, np.sqrt(104), 12),
+                                 (data_2, [0.5, 1, 2], 3, np.array([np.sqrt(2), np.sqrt(5.0625)]), np.array([2, 3.25]))):
+    kern = K.SEKernel(dim, 1, bws)
+    single = len(data.shape) == 1
+    assert np.linalg.norm(kern.get_effective_norm(data, order=2, is_single=single) - l2) < 1e-5
+    assert np.linalg.norm(kern.get_effective_norm(data, order=1, is_single=single) - l1) < 1e-5
+  def post_std(kern, X_tr, X_te):
+    K_tr, K_tetr, K_te = kern.evaluate(X_tr, X_tr), kern.evaluate(X_te, X_tr), kern.evaluate(X_te, X_te)
+    return np.sqrt(np.diag(K_te - K_tetr.dot(np.linalg.solve(K_tr, K_tetr.T))))
+  rs = np.random.RandomState(11)
+  for dim, scale, num in ([2, 1, 10], [3, 2, 0], [10, 6, 13]):
+    kern = K.SEKernel(dim, scale, list(rs.random_sample(dim) * 0.3 + 0.5))
+    X_1, X_2, X_tr = rs.random_sample((5, dim)), rs.random_sample((5, dim)), rs.random_sample((num, dim))
+    std_diff = np.abs(post_std(kern, X_tr, X_1) - post_std(kern, X_tr, X_2))
+    std_slack = kern.compute_std_slack(X_1, X_2)
+    assert np.all(std_diff <= std_slack)
+    assert np.all(std_slack <= kern.hyperparams['scale'] * kern.get_effective_norm(X_1 - X_2, order=2, is_single=False))
+  kern = K.SEKernel(2, 1.0, [0.5, 2.0])
+  kern.change_smoothness(2.0)
+  assert np.array_equal(kern.hyperparams['dim_bandwidths'], [1.0, 4.0])

@@ -29,6 +29,43 @@ def test_oracle_poly_and_expdecay_match_the_reference():
   assert relerr(mu, g['mu']) < 1e-12 and relerr(sd, g['sd']) < 1e-11
 
 
+DATA_1 = np.array([[1, 2], [3, 4.5]])
+DATA_2 = np.array([[1, 2], [3, 4]])
+POLY_TRUE = {'11': 2 * np.array([[17.25, 37.75], [37.75, 84.25]]) ** 3, '22': 2 * np.array([[17.25, 33.75], [33.75, 67.25]]) ** 3,
+             '12': 2 * np.array([[17.25, 33.75], [37.75, 75.25]]) ** 3}
+SE_TRUE = {'11': 2 * np.array([[1, np.exp(-406.25/2)], [np.exp(-406.25/2), 1]]),
+           '22': 2 * np.array([[1, np.exp(-404/2)], [np.exp(-404/2), 1]]),
+           '12': 2 * np.array([[1, np.exp(-404/2)], [np.exp(-406.25/2), np.exp(-0.25/2)]])}
+PAIRS = {'11': (DATA_1, DATA_1), '22': (DATA_2, DATA_2), '12': (DATA_1, DATA_2)}
+
+
+def test_oracle_poly_and_combined_known_answers():
+  """ gp/unittest_kernel.py:126-151: the polynomial kernel, and the product of an SE and a polynomial
+      kernel over the SAME two coordinates (overlapping groups) """
+  poly = O.KernelSpec('poly', 2, 2, np.array([0.5, 2]), nu=3)
+  comb = O.KernelSpec('product', 2, 4.3, groups=[[0, 1], [0, 1]],
+                      subs=[O.KernelSpec('se', 2, 2, np.array([0.1, 1])), poly])
+  for key, (A, B) in PAIRS.items():
+    assert np.linalg.norm(POLY_TRUE[key] - poly(A, B)) < 1e-10
+    assert np.linalg.norm(4.3 * SE_TRUE[key] * POLY_TRUE[key] - comb(A, B)) < 1e-10
+
+
+def test_mirror_poly_and_combined_known_answers(monkeypatch):
+  from oracle_engine import patch_engine
+  from dragonfly_amd import kernel as K
+  patch_engine(monkeypatch)
+  known_answers(K)
+
+
+def known_answers(K):
+  """ the same known answers through the mirror classes (shared with the MI355X test) """
+  poly = K.PolyKernel(2, 3, 2, [0.5, 2])
+  comb = K.CoordinateProductKernel(2, 4.3, [K.SEKernel(2, 2, [0.1, 1]), poly], [[0, 1], [0, 1]])
+  for key, (A, B) in PAIRS.items():
+    assert np.linalg.norm(POLY_TRUE[key] - (poly(A) if A is B else poly(A, B))) < 1e-10
+    assert np.linalg.norm(4.3 * SE_TRUE[key] * POLY_TRUE[key] - (comb(A) if A is B else comb(A, B))) < 1e-10
+
+
 def test_mirrors_over_the_stand_in_engine(monkeypatch):
   from oracle_engine import patch_engine
   from dragonfly_amd import mf_gp    # noqa: F401  (imports gp_core before patching)
