@@ -19,7 +19,7 @@ def test_reference_known_answers_on_device(engine):
   """ gp/unittest_kernel.py:126-151 (polynomial kernel; SE x polynomial over the same coordinates) """
   from dragonfly_amd import kernel as K
   from test_polyexp_cpu import known_answers
-  known_answers(K)
+  known_answers(K, comb_rel_tol=1e-15)
 
 
 @pytest.mark.parametrize('n1,n2,d', [(1, 1, 1), (130, 67, 5), (300, 515, 8)])
