@@ -708,6 +708,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     attr_set = true;
   }
   const int64_t nblk = (n + NB - 1) / NB;
+  static const bool pair_on = []() { const char* e = getenv("DFH_CHOL_PAIR"); return e ? atoi(e) != 0 : true; }();
+  static const long pair_min_rem = []() { const char* e = getenv("DFH_CHOL_PAIR_MIN_REM"); return e ? atol(e) : 6144L; }();
   DFH_ARG(3 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
   hipEvent_t ev_start, ev_done;
   DFH_TRY(ctx_event(ctx, 0, &ev_start));
@@ -723,6 +725,9 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     double* D = A + k0 * lda + k0;
     double* Lscr = Lscr_all + (kb & 1) * (NB / PB) * PB * PB;
     const int64_t rem = n - k0 - nbk;
+    // paired trailing updates while the trailing matrix is large (decided per pair, on the rows left
+    // below its FIRST panel, so that both panels of a pair see the same answer)
+    const bool paired = pair_on && ((kb & 1) ? rem + NB : rem) > pair_min_rem;
     hipEvent_t e_panel, e_trail, e_aux, e_trail_prev = nullptr, e_aux_prev2 = nullptr;
     DFH_TRY(ctx_event(ctx, 2 + 3 * kb, &e_panel));
     DFH_TRY(ctx_event(ctx, 3 + 3 * kb, &e_trail));
@@ -754,11 +759,14 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       DFH_HIP(hipEventRecord(e_panel, P));
       // ---- the next block column, so that the next panel can start before the trailing update ----
       if (rem > 0) {
-        const double* A21 = A + (k0 + nbk) * lda + k0;    // rem x nbk, final
+        // kw = width of the panels whose contribution is still missing to the right of this one:
+        // this panel alone, or -- in paired mode, after the second panel of a pair -- both
+        const int64_t kw = (paired && (kb & 1)) ? nbk + NB : nbk;
+        const double* A21 = A + (k0 + nbk) * lda + (k0 + nbk - kw);    // rem x kw, final
         if (e_trail_prev) DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
         const int64_t nb1 = rem < NB ? rem : NB;
         double* C1 = A + (k0 + nbk) * lda + (k0 + nbk);   // rows k+1.., block column k+1
-        DFH_TRY(gemm_f64(ctx, 0, rem, nb1, nbk, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
+        DFH_TRY(gemm_f64(ctx, 0, rem, nb1, kw, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
       }
     }
     {
@@ -779,9 +787,17 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       }
       DFH_HIP(hipEventRecord(e_aux, X));
     }
-    if (rem > NB) {
+    // Paired mode: the trailing update runs after every SECOND panel, 1024 wide (the K = 512 update
+    // reads and writes the C tile once per 512 columns of operand: 54 TF/s at n = 15872 against 63 for
+    // K = 1024, tools/syrk_k.py).  The first panel of a pair only updates the next block column (the
+    // look-ahead product above).  Its pivot chain then has no trailing update to run beside, which
+    // costs most of what the wider update wins: n = 16384 35.2 -> 34.6 ms, n = 4096 2.82 -> 2.90 ms
+    // -- hence only while more than DFH_CHOL_PAIR_MIN_REM rows are left.
+    const bool trail_now = !paired || (kb & 1) || rem <= NB;
+    if (rem > NB && trail_now) {
       const int64_t rem2 = rem - NB;
-      const double* A31 = A + (k0 + nbk + NB) * lda + k0;                // rows k+2.. of the panel
+      const int64_t kw = (paired && (kb & 1)) ? nbk + NB : nbk;
+      const double* A31 = A + (k0 + nbk + NB) * lda + (k0 + nbk - kw);   // rows k+2.. of the panel(s)
       double* A33 = A + (k0 + nbk + NB) * lda + (k0 + nbk + NB);
       DFH_HIP(hipStreamWaitEvent(M, e_panel, 0));
       {
@@ -790,7 +806,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
         static const bool half = []() { const char* e = getenv("DFH_CHOL_HALF_OCC"); return e && atoi(e) != 0; }();
         const bool old = ctx->gemm_half_occupancy;
         if (half) ctx->gemm_half_occupancy = true;
-        const int rc_t = gemm_f64(ctx, GEMM_LOWER, rem2, rem2, nbk, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda, &bA);
+        const int rc_t = gemm_f64(ctx, GEMM_LOWER, rem2, rem2, kw, -1.0, A31, lda, A31, lda, 1.0, A33, lda, A33, lda, &bA);
         ctx->gemm_half_occupancy = old;
         DFH_TRY(rc_t);
       }
