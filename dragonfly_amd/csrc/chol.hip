@@ -354,10 +354,12 @@ constexpr int SPP = 66;      // row stride of the column-permuted factor image (
 __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D, long lda, int nb,
                                                           int rows_below, long pivot_base,
                                                           long long* info, double* __restrict__ Lout,
-                                                          long strideD, long strideL) {
+                                                          long strideD, long strideL,
+                                                          double* __restrict__ LinvOut, long strideI) {
   // batch element = blockIdx.y
   D += (long)blockIdx.y * strideD;
   Lout += (long)blockIdx.y * strideL;
+  if (LinvOut) LinvOut += (long)blockIdx.y * strideI;
   long long* const info_dbg = info + CHOL_MAX_BATCH;   // debug words follow the pivot flags
   info += blockIdx.y;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
@@ -435,6 +437,9 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     const int pk = perm16(k);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Lout[(w + 4 * r) * PB + k] = Sp[(w + 4 * r) * SPP + pk];
+    // ... and the inverses of its four 16 x 16 diagonal blocks, for the strip kernel (same layout as in LDS)
+    if (LinvOut)
+      for (int i = tid; i < 4 * 16 * 17; i += 256) LinvOut[i] = linv[i];
     return;
   }
   {
@@ -490,6 +495,165 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
 }
 static_assert(SPP == SPP_STAGE, "staging stride");
 constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17 + 8 * 16 * 17) * 8;   // image, panel rows, rdiag, ring, layout buffers, 16-blocks + inverses
+
+// ---------------------------------------------------------------------------------------------
+// Panel strips.  Once the 512 x 512 diagonal block of a panel is factored, the rows below it are
+//     L21 = A21 L11^-T ,
+// and a strip of 64 of those rows needs nothing from any other strip: workgroup s keeps its
+// 64 x 512 strip in the MFMA accumulators (16 rows x 512 columns per wave, 128 doubles per lane)
+// and runs the eight 64-column steps locally --
+//     X_j = (A_j - sum_{i<j} X_i L_ji^T) L_jj^-T      (the sum is already in the accumulators)
+//     A_c -= X_j L_cj^T  for the later blocks c > j   (right-looking inside the strip)
+// -- with the SAME row solve as diag_step64_kernel (16-column sub-blocks, the inverses of the
+// 16 x 16 diagonal blocks exported by the workgroup that factored L_jj).  One launch replaces the
+// eight (pivot step + K=64 panel update) pairs whose launch gaps and HBM round trips of the
+// rows x 448 panel were the factorisation's dependent chain.  Fully unrolled over (j, c): the
+// accumulator index has to be static.
+// LDS strides: an MFMA operand read takes element (row l15, column 4 st + kq) of a tile; with a
+// row stride = 4 mod 32 doubles the 64 lanes cover all banks exactly twice (the minimum for 8 B).
+constexpr int SK_LD = 68;      // 64-column tiles
+constexpr int SK_TD = 20;      // 16-column tiles
+constexpr int STRIP_SMEM = (2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD + 4 * 16 * SK_TD) * 8;
+
+// The 36 tiles of L a strip consumes, in order: for j = 0..7 the diagonal factor block L_jj (with the
+// inverses of its 16 x 16 diagonal blocks), then the sub-diagonal blocks L_cj, c = j+1..7.  They are
+// fetched two tiles ahead into registers and handed over through two LDS buffers, one barrier per
+// tile: the blocks were written by other XCDs a moment ago, every fetch is a full fabric round trip.
+constexpr int SK_TILES = 36;
+constexpr int sk_tile_j(int q) { int j = 0; while (q >= 8 - j) { q -= 8 - j; ++j; } return j; }
+constexpr int sk_tile_c(int q) { int j = 0; while (q >= 8 - j) { q -= 8 - j; ++j; } return j + q; }
+
+struct StripCtx {
+  const double* Dblk; long lda; const double* Lfac; const double* Linv16;
+  double* Pw; long rows_left;
+  double* buf;        // 2 x [64][SK_LD]
+  double* Xw; double* Tt; double* li;
+};
+
+template <int Q>
+__device__ __forceinline__ void strip_fetch(const StripCtx& s, double (&pre)[16], double (&prei)[4]) {
+  constexpr int J = sk_tile_j(Q), C = sk_tile_c(Q);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if constexpr (C == J) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = s.Lfac[J * PB * PB + (w + 4 * r) * PB + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = tid + 256 * r;                   // element of the [4][16][16] inverses
+      prei[r] = s.Linv16[J * (4 * 16 * 17) + (i >> 8) * (16 * 17) + ((i >> 4) & 15) * 17 + (i & 15)];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = s.Dblk[(long)(C * PB + w + 4 * r) * s.lda + J * PB + lane];
+  }
+}
+
+template <int Q>
+__device__ __forceinline__ void strip_tile(const StripCtx& s, double4_t (&acc)[32], double (&xa)[16],
+                                           double (&pre)[2][16], double (&prei)[2][4]) {
+  constexpr int J = sk_tile_j(Q), C = sk_tile_c(Q);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+  double* L = s.buf + (Q & 1) * (PB * SK_LD);
+  // hand the prefetched tile over (the buffer was last read two tiles ago: one barrier in between)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) L[(w + 4 * r) * SK_LD + lane] = pre[Q & 1][r];
+  if constexpr (C == J) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = tid + 256 * r;
+      s.li[(i >> 8) * (16 * SK_TD) + ((i >> 4) & 15) * SK_TD + (i & 15)] = prei[Q & 1][r];
+    }
+  }
+  if constexpr (Q + 2 < SK_TILES) strip_fetch<Q + 2>(s, pre[Q & 1], prei[Q & 1]);
+  __syncthreads();
+  if constexpr (C == J) {
+    // ---- row solve of block J: X_b = (T_b - sum_{b'<b} X_b' L[b][b']^T) Linv_bb^T, b = 0..3 ----
+    double* Xw = s.Xw; double* Tt = s.Tt;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double4_t a1 = acc[4 * J + b], a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const double av = Xw[l15 * SK_LD + 16 * bp + 4 * st + kq];
+          const double bv = -L[(16 * b + l15) * SK_LD + 16 * bp + 4 * st + kq];
+          if (st & 1) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a2, 0, 0, 0);
+          else a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a1, 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tt[(kq + 4 * r) * SK_TD + l15] = a1[r] + a2[r];
+      COMPILER_BARRIER();                            // same wave: LDS executes its operations in order
+      double4_t x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const double av = Tt[l15 * SK_TD + 4 * st + kq];
+        const double bv = s.li[b * (16 * SK_TD) + l15 * SK_TD + 4 * st + kq];
+        if (st & 1) x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x2, 0, 0, 0);
+        else x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+      }
+      COMPILER_BARRIER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xw[(kq + 4 * r) * SK_LD + 16 * b + l15] = x[r] + x2[r];
+      COMPILER_BARRIER();
+    }
+    // ---- the solved block is final: out to HBM, a full 512-byte row segment per store ----
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < s.rows_left) s.Pw[(long)i * s.lda + J * PB + lane] = Xw[i * SK_LD + lane];
+    if constexpr (J < 7) {
+#pragma unroll
+      for (int st = 0; st < 16; ++st) xa[st] = -Xw[l15 * SK_LD + 4 * st + kq];   // -X_j: A operand of the later blocks
+    }
+  } else {
+    // one wave per SIMD: nothing else hides the LDS latency, so the B operands are read sixteen
+    // MFMAs ahead of their use (software pipeline pinned with scheduling groups)
+    constexpr int AHEAD = 4;
+    double bq[64];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) bq[i] = L[(16 * (i & 3) + l15) * SK_LD + 4 * (i >> 2) + kq];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i + AHEAD < 64) bq[i + AHEAD] = L[(16 * ((i + AHEAD) & 3) + l15) * SK_LD + 4 * ((i + AHEAD) >> 2) + kq];
+      acc[4 * C + (i & 3)] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i >> 2], bq[i], acc[4 * C + (i & 3)], 0, 0, 0);
+      if (i + AHEAD < 64) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one DS read ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // ... one MFMA
+    }
+  }
+  if constexpr (Q + 1 < SK_TILES) strip_tile<Q + 1>(s, acc, xa, pre, prei);
+}
+
+__global__ __launch_bounds__(256, 1) void panel_strip_kernel(const double* __restrict__ Dblk, long lda,
+                                                             const double* __restrict__ Lfac,
+                                                             const double* __restrict__ Linv16,
+                                                             double* __restrict__ P, int rows, long strideD,
+                                                             long strideL, long strideI) {
+  extern __shared__ __attribute__((aligned(16))) double ssm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+  StripCtx s;
+  s.Dblk = Dblk + (long)blockIdx.y * strideD; s.lda = lda;
+  s.Lfac = Lfac + (long)blockIdx.y * strideL;
+  s.Linv16 = Linv16 + (long)blockIdx.y * strideI;
+  const long r0 = (long)blockIdx.x * PB + 16 * w;    // this wave's first row
+  s.Pw = P + (long)blockIdx.y * strideD + r0 * lda;
+  s.rows_left = (long)rows - r0;
+  s.buf = ssm;                                                       // 2 x [64][SK_LD] tiles of L
+  s.Xw = ssm + 2 * PB * SK_LD + w * (16 * SK_LD);                    // per wave: [16][SK_LD] the solved block X_j
+  s.Tt = ssm + 2 * PB * SK_LD + 4 * 16 * SK_LD + w * (16 * SK_TD);   // per wave: [16][SK_TD]
+  s.li = ssm + 2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD;     // [4][16][SK_TD] inverses
+  double pre[2][16], prei[2][4], xa[16];
+  strip_fetch<0>(s, pre[0], prei[0]);
+  strip_fetch<1>(s, pre[1], prei[1]);
+  double4_t acc[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[t][r] = (kq + 4 * r < s.rows_left) ? s.Pw[(long)(kq + 4 * r) * lda + 16 * t + l15] : 0.0;
+  strip_tile<0>(s, acc, xa, pre, prei);
+}
 
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
@@ -690,8 +854,17 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   const int64_t strideInv = keep_inv ? strideKeep : 0;          // between the batch matrices' inverse blocks
   const int64_t strideL = 2 * (NB / PB) * PB * PB;               // factor scratch: [parity][8][64][64] per matrix
   const int64_t strideT = NB * NB;
+  const int64_t strideI = 2 * (NB / PB) * (4 * 16 * 17);         // 16 x 16 inverses of those blocks, same parity scheme
   double* Lscr_all = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * strideL * 8, (void**)&Lscr_all));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * (strideL + strideI) * 8, (void**)&Lscr_all));
+  double* Iscr_all = Lscr_all + (int64_t)nbatch * strideL;
+  // Panel strips (panel_strip_kernel) for lock-step batches: there the pivot steps are throughput-bound
+  // (64 matrices x 64 workgroups, each re-factoring the pivot block, one workgroup per CU) and the
+  // K = 64 panel updates HBM-bound (1.85 GB per step).  A single matrix keeps the pivot-step / GEMM
+  // pairs: its chain is bound by launch latency, which the strips do not shorten.
+  static const int strips_on = []() { const char* e = getenv("DFH_CHOL_STRIPS"); return e ? atoi(e) : 1; }();
+  static const int strips_max_wg = []() { const char* e = getenv("DFH_CHOL_STRIPS_MAX_WG"); return e ? atoi(e) : (1 << 30); }();
+  static const int strips_min_wg = []() { const char* e = getenv("DFH_CHOL_STRIPS_MIN_WG"); return e ? atoi(e) : 513; }();
   double* T = nullptr;
   if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
   const int64_t nblk_all = (n + NB - 1) / NB;
@@ -705,6 +878,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   if (!attr_set) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(diag_step64_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strip_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_SMEM));
     attr_set = true;
   }
   const int64_t nblk = (n + NB - 1) / NB;
@@ -724,10 +899,13 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     double* Linv = keep_inv ? keep_inv + kb * NB * NB : nullptr;
     double* D = A + k0 * lda + k0;
     double* Lscr = Lscr_all + (kb & 1) * (NB / PB) * PB * PB;
+    double* Iscr = Iscr_all + (kb & 1) * (NB / PB) * (4 * 16 * 17);
     const int64_t rem = n - k0 - nbk;
     // paired trailing updates while the trailing matrix is large (decided per pair, on the rows left
     // below its FIRST panel, so that both panels of a pair see the same answer)
     const bool paired = pair_on && ((kb & 1) ? rem + NB : rem) > pair_min_rem;
+    const bool strips = strips_on && rem > 0 && nbk == NB && (int64_t)nbatch * ((rem + PB - 1) / PB) <= strips_max_wg &&
+                        (int64_t)nbatch * ((rem + PB - 1) / PB) >= strips_min_wg;
     hipEvent_t e_panel, e_trail, e_aux, e_trail_prev = nullptr, e_aux_prev2 = nullptr;
     DFH_TRY(ctx_event(ctx, 2 + 3 * kb, &e_panel));
     DFH_TRY(ctx_event(ctx, 3 + 3 * kb, &e_trail));
@@ -742,11 +920,13 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
         const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
         double* Djj = D + j0 * lda + j0;
         const int64_t cols_left = nbk - j0 - w;            // panel columns still to be factored
-        const int64_t rows = cols_left + rem;              // every row below the pivot block
+        // every row below the pivot block -- or, with strips, only those inside the diagonal block
+        const int64_t rows = cols_left + (strips ? 0 : rem);
         const unsigned nwg = 1 + (unsigned)((rows + PB - 1) / PB);
         hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg, (unsigned)nbatch), dim3(256), DIAG_STEP_SMEM, P, Djj,
                            (long)lda, w, (int)rows, (long)(k0 + j0), d_info, Lscr + (j0 / PB) * PB * PB,
-                           (long)strideA, (long)strideL);
+                           (long)strideA, (long)strideL, strips ? Iscr + (j0 / PB) * (4 * 16 * 17) : (double*)nullptr,
+                           (long)strideI);
         DFH_LAUNCH_CHECK();
         if (cols_left > 0) {
           // A[r, c] -= L[r, j] L[c, j]^T for the rows below and the panel columns to the right
@@ -755,6 +935,13 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
           double* D22 = D + (j0 + w) * lda + (j0 + w);
           DFH_TRY(gemm_f64(ctx, 0, rows, cols_left, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda, &bA));
         }
+      }
+      if (strips) {
+        // ---- the rows below the diagonal block: L21 = A21 L11^-T, 64 rows per workgroup, one launch ----
+        hipLaunchKernelGGL(panel_strip_kernel, dim3((unsigned)((rem + PB - 1) / PB), (unsigned)nbatch), dim3(256),
+                           STRIP_SMEM, P, D, (long)lda, Lscr, Iscr, A + (k0 + nbk) * lda + k0, (int)rem,
+                           (long)strideA, (long)strideL, (long)strideI);
+        DFH_LAUNCH_CHECK();
       }
       DFH_HIP(hipEventRecord(e_panel, P));
       // ---- the next block column, so that the next panel can start before the trailing update ----
@@ -1050,7 +1237,7 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   for (int r = 0; r < reps; ++r) {
     // the block is re-factored from its own output (still SPD: L has a dominant diagonal)
     hipLaunchKernelGGL(diag_step64_kernel, dim3(nwg), dim3(256), DIAG_STEP_SMEM, ctx->stream, A, (long)nn, 64,
-                       rows_below, 0L, d_info, A + 256 * nn, 0L, 0L);
+                       rows_below, 0L, d_info, A + 256 * nn, 0L, 0L, (double*)nullptr, 0L);
   }
   DFH_HIP(hipEventRecord(e1, ctx->stream));
   DFH_HIP(hipEventSynchronize(e1));
