@@ -505,10 +505,15 @@ constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17
 //     X_j = (A_j - sum_{i<j} X_i L_ji^T) L_jj^-T      (the sum is already in the accumulators)
 //     A_c -= X_j L_cj^T  for the later blocks c > j   (right-looking inside the strip)
 // -- with the SAME row solve as diag_step64_kernel (16-column sub-blocks, the inverses of the
-// 16 x 16 diagonal blocks exported by the workgroup that factored L_jj).  One launch replaces the
-// eight (pivot step + K=64 panel update) pairs whose launch gaps and HBM round trips of the
-// rows x 448 panel were the factorisation's dependent chain.  Fully unrolled over (j, c): the
-// accumulator index has to be static.
+// 16 x 16 diagonal blocks exported by the workgroup that factored L_jj).  One launch replaces, for
+// the rows below the diagonal block, the eight pivot steps (each workgroup re-factoring the pivot
+// block) and the eight K = 64 updates that stream the rows x 448 panel through HBM.  Used for
+// lock-step batches, where those two are what the pivot steps cost (cholesky_device); for a single
+// matrix the chain is bound by launch latency and the strips do not pay.
+// One wave per SIMD (the strip fills the register file): the 28 updates run at the fp64 matrix
+// pipe's rate (64 cycles per MFMA), the row solves and the tile hand-over are latency -- 134 us per
+// strip against 61 us of MFMA time.  Fully unrolled over (j, c): the accumulator index has to be
+// static.
 // LDS strides: an MFMA operand read takes element (row l15, column 4 st + kq) of a tile; with a
 // row stride = 4 mod 32 doubles the 64 lanes cover all banks exactly twice (the minimum for 8 B).
 constexpr int SK_LD = 68;      // 64-column tiles
@@ -607,8 +612,9 @@ __device__ __forceinline__ void strip_tile(const StripCtx& s, double4_t (&acc)[3
       for (int st = 0; st < 16; ++st) xa[st] = -Xw[l15 * SK_LD + 4 * st + kq];   // -X_j: A operand of the later blocks
     }
   } else {
-    // one wave per SIMD: nothing else hides the LDS latency, so the B operands are read sixteen
-    // MFMAs ahead of their use (software pipeline pinned with scheduling groups)
+    // one wave per SIMD: nothing else hides the LDS latency, so the B operands are read a few MFMAs
+    // ahead of their use (software pipeline pinned with scheduling groups; reading further ahead
+    // only adds spills: 152 spilled VGPRs at sixteen ahead, 61 at four, same time)
     constexpr int AHEAD = 4;
     double bq[64];
 #pragma unroll
