@@ -248,3 +248,33 @@ def test_hallucination_when_the_augmented_matrix_needs_the_ladder(engine, noise_
   _, cov_o = og.eval_with_hallucinated_observations(Xs, Xh, 'covar')
   _, cov_d = gp.predict_covar(Xs, X_halluc=Xh)
   assert relerr(cov_d, cov_o) < 1e-3
+
+
+def test_thompson_blocks_in_the_panel_strip_regime(engine):
+  """ 64 blocks of 1100 candidates factored in lock step: 588 rows below each block's first 512-panel =
+      10 row strips per block, 640 in the batch -> panel_strip_kernel (csrc/chol.hip), last strip
+      ragged (588 = 9*64 + 12); against the oracle's blocked draw, block by block """
+  rs = np.random.RandomState(77)
+  n, d, blk, nblk = 300, 4, 1100, 64
+  spec, ospec = _spec_pair('se', d, rs, scale=1.0)
+  X = rs.rand(n, d)
+  Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 20)
+  og = O.GPOracle(X, Y, ospec, mean_c, noise)
+  gp = engine.gp_fit(spec, X, Y - mean_c, noise)
+  m = blk * nblk
+  Xs, U = rs.rand(m, d), rs.randn(m)
+  bv, bi, samp, jps = gp.thompson(Xs, U, block=blk, mean_const=mean_c, return_samples=True)
+  assert samp.shape == (m,) and len(jps) == nblk
+  for b in (0, 1, 31, 63):                       # a few blocks against the oracle (one 1100 x 1100 Cholesky each)
+    sl = slice(b * blk, (b + 1) * blk)
+    want = og.draw_samples_blocked(Xs[sl], U[sl], blk)
+    assert relerr(samp[sl], want) < 1e-4
+    assert int(np.argmax(samp[sl])) == int(np.argmax(want))
+  assert bi == int(np.argmax(samp)) and bv == samp[bi]
+  # the same call with the strips switched off is checked in tools (DFH_CHOL_STRIPS=0): here, blocks
+  # drawn one per call (a batch of one: pivot-step path) must agree with the lock-step batch
+  for b in (5, 40):
+    sl = slice(b * blk, (b + 1) * blk)
+    _, _, one, _ = gp.thompson(Xs[sl], U[sl], block=blk, mean_const=mean_c, return_samples=True)
+    assert relerr(one, samp[sl]) < 1e-6
