@@ -1,0 +1,30 @@
+"""MI355X: the factorisation's schedule variants -- trailing updates after every second panel
+(DFH_CHOL_PAIR), panel strips (DFH_CHOL_STRIPS) -- are chosen by problem size; here each is forced on
+(and off) for small sizes too, in a subprocess (the switches are read once per process), so that
+every path sees ragged sizes, odd and even panel counts and lock-step batches."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+VARIANTS = {
+  'defaults': {},
+  'paired-everywhere': {'DFH_CHOL_PAIR': '1', 'DFH_CHOL_PAIR_MIN_REM': '0'},
+  'unpaired': {'DFH_CHOL_PAIR': '0'},
+  'strips-everywhere': {'DFH_CHOL_STRIPS': '1', 'DFH_CHOL_STRIPS_MIN_WG': '1'},
+  'no-strips': {'DFH_CHOL_STRIPS': '0'},
+  'paired+strips-everywhere': {'DFH_CHOL_PAIR_MIN_REM': '0', 'DFH_CHOL_STRIPS_MIN_WG': '1'},
+}
+
+
+@pytest.mark.parametrize('name', sorted(VARIANTS))
+def test_schedule_variant(engine, name):
+  env = dict(os.environ)
+  env.update(VARIANTS[name])
+  res = subprocess.run([sys.executable, os.path.join(HERE, 'chol_paths_check.py')], env=env, capture_output=True,
+                       text=True, timeout=600)
+  assert res.returncode == 0 and res.stdout.strip().endswith('OK'), (res.stdout[-2000:], res.stderr[-4000:])
