@@ -661,6 +661,213 @@ __global__ __launch_bounds__(256, 1) void panel_strip_kernel(const double* __res
   strip_tile<0>(s, acc, xa, pre, prei);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One launch per panel (single matrices).  Workgroup g < 8 owns the 64-row strip g of the 512 x 512
+// diagonal block, workgroup g >= 8 a strip of the rows below it; every strip lives in the MFMA
+// accumulators as in panel_strip_kernel.  The eight diagonal strips form the dependent chain,
+//   strip s:  for j < s: wait for L_jj, X_sj = (A_sj - ...) L_jj^-T, update the blocks (j, s];
+//             then factor its own 64 x 64 diagonal block (factor64_waves) and publish L_ss,
+// handing data on through HBM with two sets of per-matrix counters: flag[s] = epoch once L_ss and
+// the inverses of its 16 x 16 blocks are out, prog[s] = j + 1 once X_sj is.  Readers spin on the
+// counter (relaxed agent-scope loads, then one acquire fence), writers publish with a barrier and a
+// release store.  Workgroups only ever wait for workgroups with a smaller index of the same launch,
+// which the dispatcher starts first.  This replaces the sixteen dependent launches of a panel
+// (eight pivot steps, eight K = 64 updates) whose gaps and HBM round trips were the factorisation's
+// chain.
+struct FusedArgs {
+  double* D; long lda;
+  double* Lfac; double* Linv16;
+  int* sync;                 // per matrix: flag[8], prog[8]
+  int epoch;
+  int rows_below;
+  long long* info; long pivot_base;
+  long strideD, strideL, strideI;
+};
+
+__device__ __forceinline__ void fused_wait(const int* p, int target) {
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);            // agent scope: later loads see what the writer released
+}
+
+__device__ __forceinline__ void fused_publish(int* p, int value) {
+  __syncthreads();                                    // every wave's stores are issued and acknowledged
+  if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int J>
+__device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[32], int s, bool diag, double* Rw,
+                                           long rows_left, double* ssm) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+  double* Lj = ssm;                                                // [64][SK_LD]
+  double* Lc = ssm + PB * SK_LD;                                   // [64][SK_LD]
+  double* Xall = ssm + 2 * PB * SK_LD;                             // [64][SK_LD]: the four waves' solved rows
+  double* Xw = Xall + w * (16 * SK_LD);
+  double* Tt = ssm + 2 * PB * SK_LD + 4 * 16 * SK_LD + w * (16 * SK_TD);
+  double* li = ssm + 2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD;
+  int* flag = a.sync; int* prog = a.sync + 8;
+  if (J < s) {
+    fused_wait(flag + J, a.epoch);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Lj[(w + 4 * r) * SK_LD + lane] = a.Lfac[J * PB * PB + (w + 4 * r) * PB + lane];
+    for (int i = tid; i < 4 * 16 * 16; i += 256)
+      li[(i >> 8) * (16 * SK_TD) + ((i >> 4) & 15) * SK_TD + (i & 15)] =
+          a.Linv16[J * (4 * 16 * 17) + (i >> 8) * (16 * 17) + ((i >> 4) & 15) * 17 + (i & 15)];
+    __syncthreads();
+    // ---- row solve of block J (as in panel_strip_kernel) ----
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double4_t a1 = acc[4 * J + b], a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const double av = Xw[l15 * SK_LD + 16 * bp + 4 * st + kq];
+          const double bv = -Lj[(16 * b + l15) * SK_LD + 16 * bp + 4 * st + kq];
+          if (st & 1) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a2, 0, 0, 0);
+          else a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a1, 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tt[(kq + 4 * r) * SK_TD + l15] = a1[r] + a2[r];
+      COMPILER_BARRIER();
+      double4_t x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const double av = Tt[l15 * SK_TD + 4 * st + kq];
+        const double bv = li[b * (16 * SK_TD) + l15 * SK_TD + 4 * st + kq];
+        if (st & 1) x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x2, 0, 0, 0);
+        else x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+      }
+      COMPILER_BARRIER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xw[(kq + 4 * r) * SK_LD + 16 * b + l15] = x[r] + x2[r];
+      COMPILER_BARRIER();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < rows_left) Rw[(long)i * a.lda + J * PB + lane] = Xw[i * SK_LD + lane];
+    if (diag) fused_publish(prog + s, a.epoch * 16 + J + 1);   // X_sJ is out (later diagonal strips and the rows below read it)
+    double xa[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) xa[st] = -Xw[l15 * SK_LD + 4 * st + kq];
+    const int c_hi = diag ? s : 7;                     // last block this strip still needs
+#pragma unroll
+    for (int c = J + 1; c < 8; ++c) {
+      if (c > c_hi) break;
+      const double* L;
+      if (diag && c == s) {
+        __syncthreads();                               // all four waves' rows of X_sJ are in Xall
+        L = Xall;                                      // own diagonal block: A_ss -= X_sJ X_sJ^T
+      } else {
+        fused_wait(prog + c, a.epoch * 16 + J + 1);    // strip c has published X_cJ (its barrier also frees Lc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Lc[(w + 4 * r) * SK_LD + lane] = a.D[(long)(c * PB + w + 4 * r) * a.lda + J * PB + lane];
+        __syncthreads();
+        L = Lc;
+      }
+#pragma unroll
+      for (int i = 0; i < 64; ++i)
+        acc[4 * c + (i & 3)] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i >> 2], L[(16 * (i & 3) + l15) * SK_LD + 4 * (i >> 2) + kq],
+                                                                    acc[4 * c + (i & 3)], 0, 0, 0);
+    }
+    __syncthreads();                                   // Xall / Lj / li are free for the next step
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double ssm[];
+  a.D += (long)blockIdx.y * a.strideD;
+  a.Lfac += (long)blockIdx.y * a.strideL;
+  a.Linv16 += (long)blockIdx.y * a.strideI;
+  a.sync += (long)blockIdx.y * 16;
+  a.info += blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int g = blockIdx.x;
+  const bool diag = g < 8;
+  const int s = diag ? g : 8;
+  double* Rw = a.D + ((long)g * PB + 16 * w) * a.lda;               // this wave's 16 rows of the panel
+  const long rows_left = (long)(8 * PB + a.rows_below) - ((long)g * PB + 16 * w);
+  double4_t acc[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * w + kq + 4 * r, c = t >> 2, col = 16 * (t & 3) + l15;
+      // a diagonal strip needs its blocks up to its own, of that one only the lower triangle
+      const bool want = (kq + 4 * r < rows_left) && (!diag || c < s || (c == s && col <= row));
+      acc[t][r] = want ? Rw[(long)(kq + 4 * r) * a.lda + 16 * t + l15] : 0.0;
+    }
+  fused_step<0>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<1>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<2>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<3>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<4>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<5>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<6>(a, acc, s, diag, Rw, rows_left, ssm);
+  fused_step<7>(a, acc, s, diag, Rw, rows_left, ssm);
+  if (!diag) return;
+  // ---- factor the strip's own diagonal block and publish it (LDS of the strip machinery is free) ----
+  double* Sp = ssm;                                  // [64][SPP] staged block, then the factor image
+  double* colbuf = ssm + PB * SPP;                   // [64]
+  double* ring = colbuf + PB;                        // [64][64]
+  double* tbuf0 = ring + PB * PB;                    // 3 x [64][17]
+  double* lbb = tbuf0 + 3 * PB * 17;                 // 4 x [16][17]
+  double* linv = lbb + 4 * 16 * 17;                  // 4 x [16][17]
+  double* rdiag = colbuf;
+  __shared__ int s_badv[4];
+  // the 64 x 64 block s of the accumulators -> staged block (lower triangle, zero above)
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    double4_t v;
+    // accumulator index has to be static: select the block by a chain of uniform branches
+    switch (s) {
+      case 0: v = acc[0 + t4]; break; case 1: v = acc[4 + t4]; break; case 2: v = acc[8 + t4]; break;
+      case 3: v = acc[12 + t4]; break; case 4: v = acc[16 + t4]; break; case 5: v = acc[20 + t4]; break;
+      case 6: v = acc[24 + t4]; break; default: v = acc[28 + t4]; break;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * w + kq + 4 * r, col = 16 * t4 + l15;
+      Sp[row * SPP + col] = (col <= row) ? v[r] : 0.0;
+    }
+  }
+  if (tid < PB) ring[tid * PB] = 0.0;
+  __syncthreads();
+  double av[16];
+  double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
+  const int bad = factor64_waves(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag);
+  if (lane == 0) s_badv[w] = bad;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) Sp[lane * SPP + perm16(16 * w + j)] = av[j];
+  __syncthreads();
+  const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
+  if (s_bad >= 0 && tid == 0) {
+    // first failing pivot of the matrix: strips run in order, so the first writer wins
+    unsigned long long expect = 0ull;
+    __hip_atomic_compare_exchange_strong((unsigned long long*)a.info, &expect,
+                                         (unsigned long long)(a.pivot_base + (long)s * PB + s_bad + 1), __ATOMIC_RELAXED,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    double* Lout = a.Lfac + (long)s * PB * PB;
+    const int pk = perm16(lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Lout[(w + 4 * r) * PB + lane] = Sp[(w + 4 * r) * SPP + pk];
+    double* Iout = a.Linv16 + (long)s * (4 * 16 * 17);
+    for (int i = tid; i < 4 * 16 * 17; i += 256) Iout[i] = linv[i];
+  }
+  fused_publish(a.sync + s, a.epoch);                 // published even after a failed pivot: nobody may hang
+}
+
+constexpr int FUSED_SMEM_STRIP = (2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD + 4 * 16 * SK_TD) * 8;
+constexpr int FUSED_SMEM_FACTOR = (PB * SPP + PB + PB * PB + 3 * PB * 17 + 8 * 16 * 17) * 8;
+constexpr int FUSED_SMEM = FUSED_SMEM_STRIP > FUSED_SMEM_FACTOR ? FUSED_SMEM_STRIP : FUSED_SMEM_FACTOR;
+
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
 // Padded rows/cols are identity so the full 64-loop is safe.
@@ -862,8 +1069,16 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   const int64_t strideT = NB * NB;
   const int64_t strideI = 2 * (NB / PB) * (4 * 16 * 17);         // 16 x 16 inverses of those blocks, same parity scheme
   double* Lscr_all = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * (strideL + strideI) * 8, (void**)&Lscr_all));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * (strideL + strideI + 8) * 8, (void**)&Lscr_all));
   double* Iscr_all = Lscr_all + (int64_t)nbatch * strideL;
+  int* fsync_all = reinterpret_cast<int*>(Iscr_all + (int64_t)nbatch * strideI);     // [nbatch][16] counters of the fused panels
+  // One launch per panel (panel_fused_kernel) for single matrices / small batches: n = 4096 2.92 -> 2.50 ms,
+  // 8192 8.05 -> 7.07, 16384 34.8 -> 33.4.  Large lock-step batches keep the pivot steps + strips: their
+  // workgroups would spend the diagonal chain's 190 us spinning.
+  static const int fused_on = []() { const char* e = getenv("DFH_CHOL_FUSED"); return e ? atoi(e) : 1; }();
+  static const int fused_max_batch = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : 2; }();
+  const bool fused_mode = fused_on && nbatch <= fused_max_batch;
+  if (fused_mode) DFH_HIP(hipMemsetAsync(fsync_all, 0, (size_t)nbatch * 16 * sizeof(int), ctx->stream));
   // Panel strips (panel_strip_kernel) for lock-step batches: there the pivot steps are throughput-bound
   // (64 matrices x 64 workgroups, each re-factoring the pivot block, one workgroup per CU) and the
   // K = 64 panel updates HBM-bound (1.85 GB per step).  A single matrix keeps the pivot-step / GEMM
@@ -886,6 +1101,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strip_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_SMEM));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM));
     attr_set = true;
   }
   const int64_t nblk = (n + NB - 1) / NB;
@@ -921,8 +1138,19 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     {
       StreamSwap on_p(ctx, P);
       if (e_aux_prev2) DFH_HIP(hipStreamWaitEvent(P, e_aux_prev2, 0));     // factor scratch of this parity is free again
+      const bool fused = fused_mode && nbk == NB;
+      if (fused) {
+        // ---- the whole panel in one launch: diagonal block by eight flag-synchronised strips, rows below alongside ----
+        FusedArgs fa;
+        fa.D = D; fa.lda = lda; fa.Lfac = Lscr; fa.Linv16 = Iscr; fa.sync = fsync_all; fa.epoch = (int)kb + 1;
+        fa.rows_below = (int)rem; fa.info = d_info; fa.pivot_base = (long)k0;
+        fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
+        hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(8 + (rem + PB - 1) / PB), (unsigned)nbatch), dim3(256),
+                           FUSED_SMEM, P, fa);
+        DFH_LAUNCH_CHECK();
+      }
       // ---- 64-wide pivot steps: factor, solve every row below, update the rest of the panel ----
-      for (int64_t j0 = 0; j0 < nbk; j0 += PB) {
+      for (int64_t j0 = 0; j0 < (fused ? 0 : nbk); j0 += PB) {
         const int w = (int)((nbk - j0 < PB) ? nbk - j0 : PB);
         double* Djj = D + j0 * lda + j0;
         const int64_t cols_left = nbk - j0 - w;            // panel columns still to be factored
@@ -942,7 +1170,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
           DFH_TRY(gemm_f64(ctx, 0, rows, cols_left, w, -1.0, Pn, lda, Pn, lda, 1.0, D22, lda, D22, lda, &bA));
         }
       }
-      if (strips) {
+      if (strips && !fused) {
         // ---- the rows below the diagonal block: L21 = A21 L11^-T, 64 rows per workgroup, one launch ----
         hipLaunchKernelGGL(panel_strip_kernel, dim3((unsigned)((rem + PB - 1) / PB), (unsigned)nbatch), dim3(256),
                            STRIP_SMEM, P, D, (long)lda, Lscr, Iscr, A + (k0 + nbk) * lda + k0, (int)rem,

@@ -27,6 +27,26 @@ def main():
     L = G.stable_cholesky(M)
     Lr = np.linalg.cholesky(M)
     assert relerr(L, Lr) < 1e-11 and np.array_equal(np.triu(L, 1), np.zeros_like(L)), n
+  # failures inside full 512-panels: a negative pivot in the second strip of the third panel, a NaN
+  # further down; the jitter ladder on a rank-deficient 1300 x 1300 matrix picks NumPy's power
+  rs = np.random.RandomState(5)
+  n = 1700
+  X = rs.rand(n, 3)
+  M = O.se_kernel(X, X, 1.0, np.full(3, 0.4)) + 0.05 * np.eye(n)
+  for bad_at, bad_val in ((1100, -1.0), (40, -1.0), (1300, np.nan)):
+    Mb = M.copy(); Mb[bad_at, bad_at] = bad_val
+    try:
+      G.stable_cholesky(Mb, add_to_diag_till_psd=False)
+      raise AssertionError('no error for a bad pivot at %d' % bad_at)
+    except np.linalg.LinAlgError as e:
+      # the first failing pivot, 1-based; a NaN entry makes the first pivot whose column it reaches fail
+      if bad_val < 0:
+        assert 'pivot %d' % (bad_at + 1) in str(e), str(e)
+  A = rs.randn(1300, 40)
+  Mr = A.dot(A.T)
+  L, p = eng.stable_cholesky(Mr, return_power=True)
+  _, pr = O.stable_cholesky(Mr, return_power=True)
+  assert p == pr and relerr(L.dot(L.T), Mr) < 1e-7, (p, pr)
   # lock-step batches: 9 candidate kernels on n = 1300 / 2200 points against single fits
   for n in (1300, 2200):
     rs = np.random.RandomState(n)

@@ -1,5 +1,6 @@
 """MI355X: the factorisation's schedule variants -- trailing updates after every second panel
-(DFH_CHOL_PAIR), panel strips (DFH_CHOL_STRIPS) -- are chosen by problem size; here each is forced on
+(DFH_CHOL_PAIR), panel strips (DFH_CHOL_STRIPS), one launch per panel (DFH_CHOL_FUSED) -- are chosen by
+problem size and batch size; here each is forced on
 (and off) for small sizes too, in a subprocess (the switches are read once per process), so that
 every path sees ragged sizes, odd and even panel counts and lock-step batches."""
 import os
@@ -18,6 +19,9 @@ VARIANTS = {
   'strips-everywhere': {'DFH_CHOL_STRIPS': '1', 'DFH_CHOL_STRIPS_MIN_WG': '1'},
   'no-strips': {'DFH_CHOL_STRIPS': '0'},
   'paired+strips-everywhere': {'DFH_CHOL_PAIR_MIN_REM': '0', 'DFH_CHOL_STRIPS_MIN_WG': '1'},
+  'fused-panels-in-batches': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_FUSED_MAX_BATCH': '64'},
+  'fused-panels+paired': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_PAIR_MIN_REM': '0'},
+  'pivot-steps-only': {'DFH_CHOL_FUSED': '0', 'DFH_CHOL_STRIPS': '0', 'DFH_CHOL_PAIR': '0'},
 }
 
 
