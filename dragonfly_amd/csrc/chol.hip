@@ -689,7 +689,7 @@ __device__ __forceinline__ void fused_wait(const int* p, int target) {
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
   }
   __syncthreads();
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);            // agent scope: later loads see what the writer released
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // later loads see what the writer released
 }
 
 __device__ __forceinline__ void fused_publish(int* p, int value) {
