@@ -679,7 +679,8 @@ struct FusedArgs {
   double* Lfac; double* Linv16;
   int* sync;                 // per matrix: flag[8], prog[8]
   int epoch;
-  int rows_below;
+  int nbk;                   // order of the diagonal block (512, or less for the last panel: identity padding)
+  int rows_below;            // rows under the diagonal block (only below a full one)
   long long* info; long pivot_base;
   long strideD, strideL, strideI;
 };
@@ -788,19 +789,22 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.x;
-  const bool diag = g < 8;
-  const int s = diag ? g : 8;
+  const int nd = (a.nbk + PB - 1) / PB;              // diagonal strips (8 for a full panel)
+  const bool diag = g < nd;
+  const int s = diag ? g : nd;
   double* Rw = a.D + ((long)g * PB + 16 * w) * a.lda;               // this wave's 16 rows of the panel
-  const long rows_left = (long)(8 * PB + a.rows_below) - ((long)g * PB + 16 * w);
+  const long rows_left = (long)(a.nbk + a.rows_below) - ((long)g * PB + 16 * w);
   double4_t acc[32];
 #pragma unroll
   for (int t = 0; t < 32; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * w + kq + 4 * r, c = t >> 2, col = 16 * (t & 3) + l15;
-      // a diagonal strip needs its blocks up to its own, of that one only the lower triangle
-      const bool want = (kq + 4 * r < rows_left) && (!diag || c < s || (c == s && col <= row));
-      acc[t][r] = want ? Rw[(long)(kq + 4 * r) * a.lda + 16 * t + l15] : 0.0;
+      // a diagonal strip needs its blocks up to its own, of that one only the lower triangle; rows and
+      // columns beyond the block's order (last panel) are identity padding
+      const bool want = (kq + 4 * r < rows_left) && (16 * t + l15 < a.nbk) && (!diag || c < s || (c == s && col <= row));
+      const bool pad_one = diag && c == s && col == row && (kq + 4 * r >= rows_left);
+      acc[t][r] = want ? Rw[(long)(kq + 4 * r) * a.lda + 16 * t + l15] : (pad_one ? 1.0 : 0.0);
     }
   fused_step<0>(a, acc, s, diag, Rw, rows_left, ssm);
   fused_step<1>(a, acc, s, diag, Rw, rows_left, ssm);
@@ -1138,15 +1142,15 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     {
       StreamSwap on_p(ctx, P);
       if (e_aux_prev2) DFH_HIP(hipStreamWaitEvent(P, e_aux_prev2, 0));     // factor scratch of this parity is free again
-      const bool fused = fused_mode && nbk == NB;
+      const bool fused = fused_mode;                  // full panels, and the (last) partial one: identity padding
       if (fused) {
         // ---- the whole panel in one launch: diagonal block by eight flag-synchronised strips, rows below alongside ----
         FusedArgs fa;
         fa.D = D; fa.lda = lda; fa.Lfac = Lscr; fa.Linv16 = Iscr; fa.sync = fsync_all; fa.epoch = (int)kb + 1;
-        fa.rows_below = (int)rem; fa.info = d_info; fa.pivot_base = (long)k0;
+        fa.nbk = (int)nbk; fa.rows_below = (int)rem; fa.info = d_info; fa.pivot_base = (long)k0;
         fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
-        hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(8 + (rem + PB - 1) / PB), (unsigned)nbatch), dim3(256),
-                           FUSED_SMEM, P, fa);
+        hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)((nbk + PB - 1) / PB + (rem + PB - 1) / PB), (unsigned)nbatch),
+                           dim3(256), FUSED_SMEM, P, fa);
         DFH_LAUNCH_CHECK();
       }
       // ---- 64-wide pivot steps: factor, solve every row below, update the rest of the panel ----
