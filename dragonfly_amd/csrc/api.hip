@@ -906,6 +906,72 @@ __global__ void k_centre(const double* __restrict__ y, double c, double* __restr
   if (i < n) { const double v = y[i] - c; out[i] = v; out2[i] = v; }
 }
 
+// ---- the solve stage of a lock-step group, all candidates per launch (n > CHOL_NB) --------------------
+// The log marginal likelihood needs sum(log L_ii) and (y - m)^T alpha = ||L^-1 (y - m)||^2: one FORWARD
+// solve per candidate, no backward solve (what k_lml_tiny does in LDS).  Right-looking block
+// substitution as in trsv_forward, but every launch carries all candidates (blockIdx.y): 3 launches
+// per 512-block for the whole group instead of ~50 per candidate.
+__global__ void k_centre_batch(const double* __restrict__ y, const double* __restrict__ means, double* __restrict__ vecs,
+                               long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vecs[(long)blockIdx.y * 2 * n + i] = y[i] - means[blockIdx.y];     // r = y - m  (z is written block by block)
+}
+
+// yout[c][row] = beta * yin[c][row] + alpha * A[c][row, 0:n] . x[c][0:n]; one wave per row (n <= 1024), four rows per
+// workgroup, blockIdx.y = candidate c; operands sA / sx / sy doubles apart between candidates
+__global__ void k_gemv_rows_wave_batch(const double* __restrict__ A, long sA, long m, long n, long lda,
+                                       const double* __restrict__ x, long sx, double alpha, const double* yin, double beta,
+                                       double* yout, long sy) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const int lane = threadIdx.x & 63;
+  const double* a = A + (long)blockIdx.y * sA + row * lda;
+  const double* xv = x + (long)blockIdx.y * sx;
+  double s0 = 0.0, s1 = 0.0;
+  const bool vec = ((lda & 1) == 0) && ((sA & 1) == 0) && ((sx & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec) {
+    const long n2 = n >> 1;
+    for (long j = lane; j < n2; j += 64) {
+      const double2_t av = reinterpret_cast<const double2_t*>(a)[j];
+      const double2_t xx = reinterpret_cast<const double2_t*>(xv)[j];
+      s0 = fma(av.x, xx.x, s0);
+      s1 = fma(av.y, xx.y, s1);
+    }
+    if ((n & 1) && lane == 0) s0 = fma(a[n - 1], xv[n - 1], s0);
+  } else {
+    for (long j = lane; j < n; j += 64) s0 = fma(a[j], xv[j], s0);
+  }
+  double sum = s0 + s1;
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) {
+    double v = alpha * sum;
+    if (beta != 0.0) v += beta * yin[(long)blockIdx.y * sy + row];
+    yout[(long)blockIdx.y * sy + row] = v;
+  }
+}
+
+// out[2c] = sum(log L_c[i][i]), out[2c+1] = z_c . z_c      (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void k_logdet_sumsq_batch(const double* __restrict__ L, long sL, long n, long ldl,
+                                                            const double* __restrict__ z, long sz, double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  const double* Lc = L + (long)blockIdx.x * sL;
+  const double* zc = z + (long)blockIdx.x * sz;
+  double ld = 0.0, dt = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    ld += log(Lc[i * ldl + i]);
+    dt = fma(zc[i], zc[i], dt);
+  }
+  s1[threadIdx.x] = ld;
+  s2[threadIdx.x] = dt;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = s1[0]; out[2 * blockIdx.x + 1] = s2[0]; }
+}
+
 // n <= CHOL_NB (one diagonal block): the whole solve stage of a candidate in one workgroup --
 // yc = y - m, z = L^-1 yc, alpha = L^-T z through the explicit block inverse M (each followed by
 // steps[c] steps of iterative refinement against the clean copy Ld of the block, chol.hip:
@@ -1095,15 +1161,42 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
                            dy, dpar + g, (int)n, dsteps, red);
         DFH_LAUNCH_CHECK();
       } else {
-        for (int c = 0; c < g; ++c) {
-          double* yc = vecs + (int64_t)c * 2 * n;
-          double* alpha = yc + n;
-          hipLaunchKernelGGL(k_centre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dy, hpar[g + c], yc, alpha, (long)n);
+        bool any_refine = false;
+        for (size_t i = 0; i < (size_t)g * nblk; ++i) any_refine = any_refine || refine[i] > 0;
+        static const bool batch_solve = []() { const char* e = getenv("DFH_LML_BATCH_SOLVE"); return e ? atoi(e) != 0 : true; }();
+        if (!any_refine && batch_solve) {
+          // all candidates per launch: r = y - m; for each 512-block z_b = M_b r_b, r_below -= L[below, b] z_b
+          const long sv = 2 * (long)n;                 // candidate c: r at vecs + c*sv, z behind it
+          hipLaunchKernelGGL(k_centre_batch, dim3((unsigned)((n + 255) / 256), (unsigned)g), dim3(256), 0, ctx->stream, dy,
+                             dpar + g, vecs, (long)n);
           DFH_LAUNCH_CHECK();
-          // alpha = L^T \ (L \ (y - m))      (gp_core.py:161-163)
-          DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
-          DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
-          DFH_TRY(logdet_and_dot_device(ctx, Kb + c * strideK, n, ldK, yc, alpha, red + 2 * c));
+          for (int64_t b0 = 0; b0 < n; b0 += NB) {
+            const int64_t w = std::min<int64_t>(NB, n - b0), below = n - b0 - w;
+            hipLaunchKernelGGL(k_gemv_rows_wave_batch, dim3((unsigned)((w + 3) / 4), (unsigned)g), dim3(256), 0, ctx->stream,
+                               invb + (b0 / NB) * NB * NB, (long)strideInv, (long)w, (long)w, (long)NB, vecs + b0, sv, 1.0,
+                               (const double*)nullptr, 0.0, vecs + n + b0, sv);
+            DFH_LAUNCH_CHECK();
+            if (below > 0) {
+              hipLaunchKernelGGL(k_gemv_rows_wave_batch, dim3((unsigned)((below + 3) / 4), (unsigned)g), dim3(256), 0,
+                                 ctx->stream, Kb + (b0 + w) * ldK + b0, (long)strideK, (long)below, (long)w, (long)ldK,
+                                 vecs + n + b0, sv, -1.0, vecs + b0 + w, 1.0, vecs + b0 + w, sv);
+              DFH_LAUNCH_CHECK();
+            }
+          }
+          hipLaunchKernelGGL(k_logdet_sumsq_batch, dim3((unsigned)g), dim3(256), 0, ctx->stream, Kb, (long)strideK, (long)n,
+                             (long)ldK, vecs + n, sv, red);
+          DFH_LAUNCH_CHECK();
+        } else {
+          for (int c = 0; c < g; ++c) {
+            double* yc = vecs + (int64_t)c * 2 * n;
+            double* alpha = yc + n;
+            hipLaunchKernelGGL(k_centre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dy, hpar[g + c], yc, alpha, (long)n);
+            DFH_LAUNCH_CHECK();
+            // alpha = L^T \ (L \ (y - m))      (gp_core.py:161-163)
+            DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
+            DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
+            DFH_TRY(logdet_and_dot_device(ctx, Kb + c * strideK, n, ldK, yc, alpha, red + 2 * c));
+          }
         }
       }
       DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
