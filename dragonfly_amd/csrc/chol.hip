@@ -1080,7 +1080,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   // 8192 8.05 -> 7.07, 16384 34.8 -> 33.4.  Large lock-step batches keep the pivot steps + strips: their
   // workgroups would spend the diagonal chain's 190 us spinning.
   static const int fused_on = []() { const char* e = getenv("DFH_CHOL_FUSED"); return e ? atoi(e) : 1; }();
-  static const int fused_max_batch = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : 2; }();
+  // (lock-step batches of up to 16 gain 5-14 % from it as well -- tools/time_lml_batch.py --, 32 and more lose)
+  static const int fused_max_batch = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : 16; }();
   const bool fused_mode = fused_on && nbatch <= fused_max_batch;
   if (fused_mode) DFH_HIP(hipMemsetAsync(fsync_all, 0, (size_t)nbatch * 16 * sizeof(int), ctx->stream));
   // Panel strips (panel_strip_kernel) for lock-step batches: there the pivot steps are throughput-bound

@@ -20,6 +20,7 @@ VARIANTS = {
   'no-strips': {'DFH_CHOL_STRIPS': '0'},
   'paired+strips-everywhere': {'DFH_CHOL_PAIR_MIN_REM': '0', 'DFH_CHOL_STRIPS_MIN_WG': '1'},
   'fused-panels-in-batches': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_FUSED_MAX_BATCH': '64'},
+  'fused-panels-single-only': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_FUSED_MAX_BATCH': '1'},
   'fused-panels+paired': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_PAIR_MIN_REM': '0'},
   'pivot-steps-only': {'DFH_CHOL_FUSED': '0', 'DFH_CHOL_STRIPS': '0', 'DFH_CHOL_PAIR': '0'},
 }
