@@ -973,15 +973,15 @@ __global__ __launch_bounds__(256) void k_logdet_sumsq_batch(const double* __rest
 }
 
 // n <= CHOL_NB (one diagonal block): the whole solve stage of a candidate in one workgroup --
-// yc = y - m, z = L^-1 yc, alpha = L^-T z through the explicit block inverse M (each followed by
-// steps[c] steps of iterative refinement against the clean copy Ld of the block, chol.hip:
-// refine_steps), then out = {sum log L_ii, yc . alpha}.  blockIdx.x = candidate.
+// yc = y - m, z = L^-1 yc through the explicit block inverse M (followed by steps[c] steps of
+// iterative refinement against the clean copy Ld of the block, chol.hip: refine_steps), then
+// out = {sum log L_ii, z . z}  (= yc . alpha: the backward solve is not needed).  blockIdx.x = candidate.
 __global__ __launch_bounds__(256) void k_lml_finish_small(const double* __restrict__ inv, long sInv,
                                                           const double* __restrict__ y,
                                                           const double* __restrict__ means, int n,
                                                           const int* __restrict__ steps,
                                                           double* __restrict__ out2) {
-  __shared__ double yc[CHOL_NB], z[CHOL_NB], r[CHOL_NB], a[CHOL_NB], red[8];
+  __shared__ double yc[CHOL_NB], z[CHOL_NB], r[CHOL_NB], red[8];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   inv += (long)c * sInv;
   const double* Ld = inv + CHOL_NB * CHOL_NB;                // clean copy of the factor (one block: nblk = 1)
@@ -1000,28 +1000,15 @@ __global__ __launch_bounds__(256) void k_lml_finish_small(const double* __restri
     }
     __syncthreads();
   };
-  // dst_j (+)= sum_{i >= j} A[i][j] src[i], a thread per column
-  auto lower_tmv = [&](const double* A, const double* src, double* dst, double sign, const double* base) {
-    for (int j = tid; j < n; j += 256) {
-      double s = 0.0;
-      for (int i = j; i < n; ++i) s = fma(A[(long)i * CHOL_NB + j], src[i], s);
-      dst[j] = (base ? base[j] : 0.0) + sign * s;
-    }
-    __syncthreads();
-  };
   lower_mv(inv, yc, z, 1.0, nullptr);                       // z = M yc
   for (int s = 0; s < nsteps; ++s) {
     lower_mv(Ld, z, r, -1.0, yc);                           // r = yc - L z
     lower_mv(inv, r, z, 1.0, z);                            // z += M r
   }
-  lower_tmv(inv, z, a, 1.0, nullptr);                       // alpha = M^T z
-  for (int s = 0; s < nsteps; ++s) {
-    lower_tmv(Ld, a, r, -1.0, z);                           // r = z - L^T alpha
-    lower_tmv(inv, r, a, 1.0, a);                           // alpha += M^T r
-  }
+  // (y - m)^T alpha = ||L^-1 (y - m)||^2 = z . z: the backward solve is not needed for the likelihood
   double ld = 0.0, dt = 0.0;
   for (int j = tid; j < n; j += 256) {
-    dt = fma(yc[j], a[j], dt);
+    dt = fma(z[j], z[j], dt);
     ld += log(Ld[(long)j * CHOL_NB + j]);
   }
   for (int off = 32; off > 0; off >>= 1) { ld += __shfl_down(ld, off, 64); dt += __shfl_down(dt, off, 64); }

@@ -872,6 +872,12 @@ constexpr int FUSED_SMEM_STRIP = (2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_
 constexpr int FUSED_SMEM_FACTOR = (PB * SPP + PB + PB * PB + 3 * PB * 17 + 8 * 16 * 17) * 8;
 constexpr int FUSED_SMEM = FUSED_SMEM_STRIP > FUSED_SMEM_FACTOR ? FUSED_SMEM_STRIP : FUSED_SMEM_FACTOR;
 
+// p[b * stride + i] = 0 for i < count, b = blockIdx.y: one launch instead of one memset per batch matrix
+__global__ void k_zero_strided(double* __restrict__ p, long count, long stride) {
+  double* q = p + (long)blockIdx.y * stride;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) q[i] = 0.0;
+}
+
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
 // workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
 // Padded rows/cols are identity so the full 64-loop is safe.
@@ -1028,7 +1034,8 @@ int block_inverse_quality(dfh_ctx* ctx, const double* D, int64_t lda, int64_t nb
   GemmBatch b;
   b.count = nbatch; b.sA = strideInv; b.sB = strideInv; b.sCout = strideT;
   DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, nbk, nbk, nbk, 1.0, Linv, NB, Ldiag, NB, 0.0, nullptr, 0, T, NB, &b));
-  for (int b = 0; b < nbatch; ++b) DFH_HIP(hipMemsetAsync(d_delta + (long)b * strideDelta, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_zero_strided, dim3(1, (unsigned)nbatch), dim3(64), 0, ctx->stream, d_delta, 1L, (long)strideDelta);
+  DFH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_inv_delta, dim3((unsigned)nbatch, DELTA_SLICES), dim3(256), 0, ctx->stream, T, (int)nbk,
                      (long)strideT, d_delta, (long)strideDelta);
   DFH_LAUNCH_CHECK();
@@ -1200,7 +1207,11 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       StreamSwap on_x(ctx, X);
       DFH_HIP(hipStreamWaitEvent(X, e_panel, 0));
       if (Linv)
-        for (int b = 0; b < nbatch; ++b) DFH_HIP(hipMemsetAsync(Linv + b * strideInv, 0, (size_t)NB * NB * 8, X));
+        if (nbatch == 1) DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, X));
+        else {
+          hipLaunchKernelGGL(k_zero_strided, dim3(64, (unsigned)nbatch), dim3(256), 0, X, Linv, (long)(NB * NB), (long)strideInv);
+          DFH_LAUNCH_CHECK();
+        }
       hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, X,
                          D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
                          (long)strideL);
