@@ -1020,6 +1020,56 @@ __global__ __launch_bounds__(256) void k_lml_finish_small(const double* __restri
   }
 }
 
+// The same stage without the 512-block inverse: forward substitution over 64-blocks with the factor
+// itself and the inverses of its 64 x 64 diagonal blocks (what trtri64_kernel leaves on the diagonal
+// of the inverse buffer) -- z_b = Linv_bb (r_b - sum_{i<b} L_bi z_i).  Saves the inverse assembly
+// (six GEMM launches) and its quality measurement per call; a 64-block inverse needs no refinement.
+__global__ __launch_bounds__(256) void k_lml_finish_small64(const double* __restrict__ L, long sL, long ldl,
+                                                            const double* __restrict__ inv, long sInv,
+                                                            const double* __restrict__ y,
+                                                            const double* __restrict__ means, int n,
+                                                            double* __restrict__ out2) {
+  __shared__ double r[CHOL_NB], z[CHOL_NB], t[64], red[8];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  L += (long)c * sL;
+  inv += (long)c * sInv;
+  const double mean = means[c];
+  for (int i = tid; i < n; i += 256) r[i] = y[i] - mean;
+  __syncthreads();
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    const int w = min(64, n - b0);
+    // t = r_b - L[b, 0:b0] z[0:b0], a wave per row
+    for (int i = wave; i < w; i += 4) {
+      const double* row = L + (long)(b0 + i) * ldl;
+      double s = 0.0;
+      for (int j = lane; j < b0; j += 64) s = fma(row[j], z[j], s);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if (lane == 0) t[i] = r[b0 + i] - s;
+    }
+    __syncthreads();
+    // z_b = Linv_bb t (lower triangular 64 x 64, row stride CHOL_NB)
+    for (int i = wave; i < w; i += 4) {
+      const double* row = inv + (long)(b0 + i) * CHOL_NB + b0;
+      double s = (lane <= i) ? row[lane] * t[lane] : 0.0;
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if (lane == 0) z[b0 + i] = s;
+    }
+    __syncthreads();
+  }
+  double ld = 0.0, dt = 0.0;
+  for (int j = tid; j < n; j += 256) {
+    dt = fma(z[j], z[j], dt);
+    ld += log(L[(long)j * ldl + j]);
+  }
+  for (int off = 32; off > 0; off >>= 1) { ld += __shfl_down(ld, off, 64); dt += __shfl_down(dt, off, 64); }
+  if (lane == 0) { red[wave] = ld; red[4 + wave] = dt; }
+  __syncthreads();
+  if (tid == 0) {
+    out2[2 * c] = (red[0] + red[1]) + (red[2] + red[3]);
+    out2[2 * c + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+
 extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* X,
                                 int64_t n, int64_t d, const double* y, const double* mean_consts,
                                 const double* noise_vars, int flags, double* lml_out,
@@ -1121,7 +1171,10 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
     {
       SectionTimer t(ctx, DFH_T_CHOL);
       int64_t piv[CHOL_MAX_BATCH] = {0};
-      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv, refine.data());
+      // n <= 512: the finish kernel substitutes with 64-blocks, so the 512-block inverse is not built
+      static const bool small64 = []() { const char* e = getenv("DFH_LML_SMALL64"); return e ? atoi(e) != 0 : true; }();
+      const bool inv64_only = small64 && n <= NB;
+      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv, refine.data(), inv64_only);
       if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
       for (int c = 0; c < g; ++c) {
         if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;
@@ -1140,7 +1193,14 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
     }
     {
       SectionTimer t(ctx, DFH_T_SOLVE);
-      if (n <= NB) {
+      static const bool small64b = []() { const char* e = getenv("DFH_LML_SMALL64"); return e ? atoi(e) != 0 : true; }();
+      if (n <= NB && small64b) {
+        // (a candidate that went through the jitter ladder has the full inverse in its slot: its diagonal
+        //  64-blocks are the inverses of the factor's diagonal blocks all the same)
+        hipLaunchKernelGGL(k_lml_finish_small64, dim3((unsigned)g), dim3(256), 0, ctx->stream, Kb, (long)strideK, (long)ldK,
+                           invb, (long)strideInv, dy, dpar + g, (int)n, red);
+        DFH_LAUNCH_CHECK();
+      } else if (n <= NB) {
         // one block per candidate (nblk = 1): its refinement steps ride behind {noise, mean} in dpar
         int* dsteps = reinterpret_cast<int*>(dpar + 2 * g);
         DFH_HIP(hipMemcpyAsync(dsteps, refine.data(), (size_t)g * sizeof(int), hipMemcpyHostToDevice, ctx->stream));

@@ -1061,7 +1061,8 @@ int refine_steps(double delta) {
 // latency-bound diagonal work leaves the critical path while the trailing update is long enough
 // to cover it.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out) {
+                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out,
+                    bool inv64_only) {
   DFH_ARG(nbatch >= 1 && nbatch <= CHOL_MAX_BATCH);
   if (info_pivot) for (int b = 0; b < nbatch; ++b) info_pivot[b] = 0;
   if (n <= 0) return DFH_OK;
@@ -1206,17 +1207,19 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       // ---- off the chain: factor blocks into place, 64-block inverses, 512-block inverse ----
       StreamSwap on_x(ctx, X);
       DFH_HIP(hipStreamWaitEvent(X, e_panel, 0));
-      if (Linv)
-        if (nbatch == 1) DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, X));
-        else {
+      if (Linv) {
+        if (nbatch == 1) {
+          DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, X));
+        } else {
           hipLaunchKernelGGL(k_zero_strided, dim3(64, (unsigned)nbatch), dim3(256), 0, X, Linv, (long)(NB * NB), (long)strideInv);
           DFH_LAUNCH_CHECK();
         }
+      }
       hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, X,
                          D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
                          (long)strideL);
       DFH_LAUNCH_CHECK();
-      if (Linv) {
+      if (Linv && !inv64_only) {
         DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
         // clean copy of the block behind the inverses (keep_inv + nblk*NB*NB + ...) and delta = max|I - M L_bb|
         DFH_TRY(block_inverse_quality(ctx, D, lda, nbk, Linv, Linv + nblk_all * NB * NB, T, d_delta + kb, nbatch,
@@ -1263,7 +1266,9 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
 
   DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8 * (size_t)nbatch, hipMemcpyDeviceToHost, M));
   std::vector<double> deltas;
-  if (keep_inv && refine_out) {
+  if (keep_inv && refine_out && inv64_only) {
+    for (size_t i = 0; i < (size_t)nbatch * nblk_all; ++i) refine_out[i] = 0;
+  } else if (keep_inv && refine_out) {
     deltas.resize((size_t)nbatch * nblk_all);
     DFH_HIP(hipMemcpyAsync(deltas.data(), d_delta, deltas.size() * 8, hipMemcpyDeviceToHost, M));
   }

@@ -270,9 +270,12 @@ constexpr int64_t CHOL_NB = 512;
 // refine_out (host, [nbatch][nblk], optional): iterative-refinement steps a solve should take with
 // each block, from the measured quality max|I - inv L_bb| of its inverse (chol.hip: refine_steps).
 inline int64_t inv_buffer_doubles(int64_t n) { return 2 * ((n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+// inv64_only: keep_inv receives only the inverses of the 64 x 64 diagonal blocks (on the diagonal of
+// each 512-block slot, zero elsewhere) -- no 512-block assembly, no quality measurement, refine_out
+// all zero: for callers that substitute with 64-blocks themselves (the small tuning objective).
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
                     int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0, int64_t strideKeep = 0,
-                    int* refine_out = nullptr);
+                    int* refine_out = nullptr, bool inv64_only = false);
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x

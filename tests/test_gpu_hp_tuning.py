@@ -75,7 +75,9 @@ def test_lml_batch_jitter_ladder_per_candidate(engine):
     tol = TOL if powers[c] is None else 1e-4
     assert abs(lml[c] - ref) <= tol * abs(ref), (c, lml[c], ref)
     one = engine.gp_fit(specs[c], X, Y, noises[c])
-    assert one.jitter_power == powers[c] and abs(one.lml - lml[c]) <= 1e-12 * abs(one.lml)
+    # the batch evaluates y^T alpha as ||L^-1 y||^2 (forward solve only), the single fit through both
+    # solves: identical to 1e-12 for well-conditioned candidates, to the conditioning's share of it after the ladder
+    assert one.jitter_power == powers[c] and abs(one.lml - lml[c]) <= (1e-12 if powers[c] is None else 1e-9) * abs(one.lml)
   with pytest.raises(np.linalg.LinAlgError):
     engine.gp_lml_batch(specs, X, Y, None, noises, allow_jitter=False)
 
