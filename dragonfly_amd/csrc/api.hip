@@ -446,7 +446,12 @@ extern "C" int dfh_cholesky(dfh_ctx* ctx, double* A, int64_t n, int64_t* info_pi
   int rc;
   {
     SectionTimer t(ctx, DFH_T_CHOL);
-    rc = cholesky_device(ctx, dA, n, n, nullptr, info_pivot);
+    // a host matrix can be uploaded again: the schedules that may need a second attempt are open to it
+    const std::function<int()> reupload = [&]() -> int {
+      DFH_HIP(hipMemcpyAsync(dA, A, (size_t)n * n * 8, hipMemcpyHostToDevice, ctx->stream));
+      return DFH_OK;
+    };
+    rc = cholesky_device(ctx, dA, n, n, nullptr, info_pivot, 1, 0, 0, nullptr, false, dev ? nullptr : &reupload);
   }
   if (rc != DFH_OK) return rc;
   DFH_TRY(zero_upper(ctx, dA, n, n));
@@ -465,7 +470,8 @@ static int stable_cholesky_device(dfh_ctx* ctx, double* dL, int64_t n, double* k
   if (jitter_power) *jitter_power = INT32_MIN;
   if (jitter_added) *jitter_added = 0.0;
   int64_t piv = 0;
-  int rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv, 1, 0, 0, refine_out);
+  const std::function<int()> rebuild_fn = [&]() -> int { return rebuild(); };
+  int rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv, 1, 0, 0, refine_out, false, &rebuild_fn);
   if (rc != DFH_ERR_NOT_PD || !allow_jitter) return rc;
   // general_utils.py:183-203
   DFH_TRY(rebuild());
@@ -478,7 +484,8 @@ static int stable_cholesky_device(dfh_ctx* ctx, double* dL, int64_t n, double* k
     if (!first) DFH_TRY(rebuild());
     first = false;
     DFH_TRY(add_diag(ctx, dL, n, ld, diag_noise));      // M + diag_noise * np.eye(n)
-    rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv, 1, 0, 0, refine_out);
+    const std::function<int()> rebuild_jit = [&]() -> int { DFH_TRY(rebuild()); return add_diag(ctx, dL, n, ld, diag_noise); };
+    rc = cholesky_device(ctx, dL, n, ld, keep_inv, &piv, 1, 0, 0, refine_out, false, &rebuild_jit);
     if (rc == DFH_OK) {
       if (jitter_power) *jitter_power = p;
       if (jitter_added) *jitter_added = diag_noise;
@@ -1174,7 +1181,11 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
       // n <= 512: the finish kernel substitutes with 64-blocks, so the 512-block inverse is not built
       static const bool small64 = []() { const char* e = getenv("DFH_LML_SMALL64"); return e ? atoi(e) != 0 : true; }();
       const bool inv64_only = small64 && n <= NB;
-      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv, refine.data(), inv64_only);
+      const std::function<int()> rebuild_all = [&]() -> int {
+        for (int c = 0; c < g; ++c) DFH_TRY(build_M(c));
+        return DFH_OK;
+      };
+      int rc = cholesky_device(ctx, Kb, n, ldK, invb, piv, g, strideK, strideInv, refine.data(), inv64_only, &rebuild_all);
       if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
       for (int c = 0; c < g; ++c) {
         if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;

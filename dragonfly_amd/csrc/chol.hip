@@ -16,6 +16,7 @@
 //   solve (trsm_rows) and the alpha solves (trsv_*) reuse them, which turns every triangular
 //   solve on the hot path into GEMM / GEMV work.
 #include "common.h"
+#include <functional>
 #include <utility>
 #include <math.h>
 #include <stdlib.h>
@@ -24,6 +25,14 @@ namespace {
 
 constexpr int PB = 64;       // pivot block
 constexpr int PBP = 65;      // LDS row stride
+
+// Hand-off status word of a factorisation (d_info[CHOL_MAX_BATCH + 8], zeroed per call): set when a
+// bounded wait expired.  The host then repeats the factorisation on the schedule without
+// inter-workgroup hand-offs (cholesky_device), or reports DFH_ERR_HIP when the input is gone.
+constexpr unsigned SYNC_ST_RING = 1;      // an LDS column ring flag never came up (factor64_waves)
+constexpr unsigned SYNC_ST_FUSED = 2;     // a strip of the one-launch panel waited too long for another strip
+constexpr unsigned SYNC_ST_GATE = 4;      // a gate kernel / resident diagonal kernel waited too long for another launch
+constexpr int SPIN_LIMIT_DEFAULT = 1 << 23;   // polls of ~1 us each: seconds, far beyond any legitimate wait
 
 // ---------------------------------------------------------------------------------------------
 // 64 x 64 pivot-block kernels.  The block is factored by the four waves of a workgroup without
@@ -200,11 +209,12 @@ __device__ __forceinline__ void f64_owner_block(double (&a)[16], int lane, int w
 // an earlier block never waits on anything, in practice a flag is up within a few hundred cycles.
 template <int NV>
 __device__ __forceinline__ void f64_consume_mfma(double4_t (&acc)[4], int lane, int w, int k0, int kvalid0,
-                                                 const double* ring) {
+                                                 const double* ring, int* ring_timeout) {
   // columns k0 + kvalid0 .. k0 + kvalid0 + NV - 1 are applied (the ones before were applied earlier)
   const int kq = lane >> 4, l15 = lane & 15;
   const double* col = ring + (k0 + kq) * PB;
   double rcv = 0.0, bu = 0.0, au[4] = {0.0, 0.0, 0.0, 0.0};
+  bool up = false;
   for (int spins = 0; spins < (1 << 22); ++spins) {
     COMPILER_BARRIER();                                // LDS is re-read in every iteration
     const double flag = ring[(k0 + kvalid0 + NV - 1) * PB];
@@ -213,9 +223,11 @@ __device__ __forceinline__ void f64_consume_mfma(double4_t (&acc)[4], int lane, 
     bu = col[16 * w + l15];
 #pragma unroll
     for (int t = 0; t < 4; ++t) au[t] = col[16 * t + l15];
-    if (flag != 0.0) break;
+    if (flag != 0.0) { up = true; break; }
     __builtin_amdgcn_s_sleep(1);
   }
+  // (never seen: the owner of an earlier block waits on nothing) -- reported, not silently computed with
+  if (!up && lane == 0) *ring_timeout = 1;
   const bool valid = (kq >= kvalid0) && (kq < kvalid0 + NV);
   const double bneg = valid ? -(bu * rcv) : 0.0;
 #pragma unroll
@@ -223,22 +235,24 @@ __device__ __forceinline__ void f64_consume_mfma(double4_t (&acc)[4], int lane, 
     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(valid ? au[t] : 0.0, bneg, acc[t], 0, 0, 0);
 }
 
-__device__ __forceinline__ void f64_consume_block(double4_t (&acc)[4], int lane, int w, int kb, const double* ring) {
+__device__ __forceinline__ void f64_consume_block(double4_t (&acc)[4], int lane, int w, int kb, const double* ring,
+                                                  int* ring_timeout) {
   const int kb0 = 16 * kb;
-  f64_consume_mfma<4>(acc, lane, w, kb0, 0, ring);
-  f64_consume_mfma<4>(acc, lane, w, kb0 + 4, 0, ring);
-  f64_consume_mfma<4>(acc, lane, w, kb0 + 8, 0, ring);
+  f64_consume_mfma<4>(acc, lane, w, kb0, 0, ring, ring_timeout);
+  f64_consume_mfma<4>(acc, lane, w, kb0 + 4, 0, ring, ring_timeout);
+  f64_consume_mfma<4>(acc, lane, w, kb0 + 8, 0, ring, ring_timeout);
   // (taking the last four columns one at a time for the wave that owns the next block does not
   //  pay: every batch costs a full LDS round trip plus the MFMA latency, ~450 cycles)
-  f64_consume_mfma<4>(acc, lane, w, kb0 + 12, 0, ring);
+  f64_consume_mfma<4>(acc, lane, w, kb0 + 12, 0, ring, ring_timeout);
 }
 
 // On return a[] holds this wave's 16 columns of L in the row-per-lane layout (zero above the
 // diagonal); returns the first bad column of the wave's own block or -1.  stage: the pivot block as staged in LDS (row stride
 // SPP); tbuf: 64 x 17 doubles of LDS private to this wave (layout change consumer -> owner).
+// ring_timeout: a word of LDS, zeroed by the caller before its barrier, set if a column never came up.
 __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
                                               double* ring, double* lbb, double* linv, double* rdiag,
-                                              long long* dbg_stamp = nullptr) {
+                                              int* ring_timeout, long long* dbg_stamp = nullptr) {
   int bad = -1;
   if (w == 0) {
 #pragma unroll
@@ -252,7 +266,7 @@ __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = stage[(16 * t + kq + 4 * r) * SPP_STAGE + 16 * w + l15];
     __syncthreads();
-    for (int kb = 0; kb < w; ++kb) f64_consume_block(acc, lane, w, kb, ring);
+    for (int kb = 0; kb < w; ++kb) f64_consume_block(acc, lane, w, kb, ring, ring_timeout);
     // accumulator layout -> row per lane, through this wave's private LDS block
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -380,12 +394,14 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     Sp[i * SPP + k] = v;
   }
   __shared__ int s_badv[4];
+  __shared__ int s_ring_timeout;
   double* ring = colbuf + PB;                      // [64][64] published (unscaled) columns
   double* tbuf0 = ring + PB * PB;                  // 3 x [64][17] layout buffers (later 4 x [16][17] solve tiles)
   double* lbb = tbuf0 + 3 * PB * 17;               // 4 x [16][17] diagonal 16-blocks of the factor
   double* linv = lbb + 4 * 16 * 17;                // 4 x [16][17] their inverses
   double* rdiag = colbuf;                          // [64] 1 / L[c][c]
   if (tid < PB) ring[tid * PB] = 0.0;              // row-0 entries double as the "published" flags
+  if (tid == 0) s_ring_timeout = 0;
   __syncthreads();
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   const int r0 = ((int)blockIdx.x - 1) * PB;
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
     long long stamp[4] = {0, 0, 0, 0};
     const bool dbg = info_dbg[7] != 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0;
     double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
-    const int bad = factor64_waves(a, k, w, Sp, tbuf, ring, lbb, linv, rdiag, dbg ? stamp : nullptr);
+    const int bad = factor64_waves(a, k, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout, dbg ? stamp : nullptr);
     if (k == 0) s_badv[w] = bad;
     if (dbg && k == 0) {
       // wave 3: start / end of its own 16 columns, end of scaling, end of the 16 x 16 inverse (debug hook only)
@@ -426,6 +442,7 @@ __global__ __launch_bounds__(256) void diag_step64_kernel(double* __restrict__ D
   const unsigned long long t2 = __builtin_amdgcn_s_memtime();
   if (info_dbg[7] != 0 && tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) { info_dbg[2] = (long long)(t1 - t0); info_dbg[3] = (long long)(t2 - t1); }
   const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
+  if (s_ring_timeout && tid == 0) atomicOr((unsigned long long*)(info_dbg + 8), (unsigned long long)SYNC_ST_RING);
   if (s_bad >= 0) {
     if (blockIdx.x == 0 && tid == 0 && info[0] == 0) info[0] = pivot_base + s_bad + 1;
     return;
@@ -683,11 +700,25 @@ struct FusedArgs {
   int rows_below;            // rows under the diagonal block (only below a full one)
   long long* info; long pivot_base;
   long strideD, strideL, strideI;
+  unsigned long long* status;   // hand-off status word (SYNC_ST_*)
+  int spin_limit;               // polls before a wait gives up (and reports)
+  // resident look-ahead schedule (cholesky_device): the launch announces every workgroup that has
+  // started in *resident, and -- wait_ptr != null -- only then waits for *wait_ptr >= wait_target
+  // (the trailing update of another stream has written the diagonal block) before touching the matrix
+  int* resident; const int* wait_ptr; int wait_target;
 };
 
-__device__ __forceinline__ void fused_wait(const int* p, int target) {
+// Bounded: a workgroup only ever waits for workgroups of the same launch with a smaller index (started
+// before it by the dispatcher as observed, not by contract) or for another launch that needs none of
+// its resources; should a wait expire all the same, the status word says so, the strip goes on with
+// whatever it finds (nobody hangs) and the host repeats the factorisation without hand-offs.
+__device__ __forceinline__ void fused_wait(const int* p, int target, const FusedArgs& a, unsigned what = SYNC_ST_FUSED) {
   if (threadIdx.x == 0) {
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    int spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > a.spin_limit) { atomicOr(a.status, (unsigned long long)what); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // later loads see what the writer released
@@ -711,7 +742,7 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
   double* li = ssm + 2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD;
   int* flag = a.sync; int* prog = a.sync + 8;
   if (J < s) {
-    fused_wait(flag + J, a.epoch);
+    fused_wait(flag + J, a.epoch, a);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Lj[(w + 4 * r) * SK_LD + lane] = a.Lfac[J * PB * PB + (w + 4 * r) * PB + lane];
     for (int i = tid; i < 4 * 16 * 16; i += 256)
@@ -763,7 +794,7 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
         __syncthreads();                               // all four waves' rows of X_sJ are in Xall
         L = Xall;                                      // own diagonal block: A_ss -= X_sJ X_sJ^T
       } else {
-        fused_wait(prog + c, a.epoch * 16 + J + 1);    // strip c has published X_cJ (its barrier also frees Lc)
+        fused_wait(prog + c, a.epoch * 16 + J + 1, a); // strip c has published X_cJ (its barrier also frees Lc)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           Lc[(w + 4 * r) * SK_LD + lane] = a.D[(long)(c * PB + w + 4 * r) * a.lda + J * PB + lane];
@@ -790,6 +821,10 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   const int kq = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.x;
   const int nd = (a.nbk + PB - 1) / PB;              // diagonal strips (8 for a full panel)
+  if (a.resident) {
+    if (tid == 0) __hip_atomic_fetch_add(a.resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.wait_ptr) fused_wait(a.wait_ptr, a.wait_target, a, SYNC_ST_GATE);
+  }
   const bool diag = g < nd;
   const int s = diag ? g : nd;
   double* Rw = a.D + ((long)g * PB + 16 * w) * a.lda;               // this wave's 16 rows of the panel
@@ -824,6 +859,8 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   double* linv = lbb + 4 * 16 * 17;                  // 4 x [16][17]
   double* rdiag = colbuf;
   __shared__ int s_badv[4];
+  __shared__ int s_ring_timeout;
+  if (tid == 0) s_ring_timeout = 0;
   // the 64 x 64 block s of the accumulators -> staged block (lower triangle, zero above)
 #pragma unroll
   for (int t4 = 0; t4 < 4; ++t4) {
@@ -844,12 +881,13 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   __syncthreads();
   double av[16];
   double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
-  const int bad = factor64_waves(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag);
+  const int bad = factor64_waves(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout);
   if (lane == 0) s_badv[w] = bad;
 #pragma unroll
   for (int j = 0; j < 16; ++j) Sp[lane * SPP + perm16(16 * w + j)] = av[j];
   __syncthreads();
   const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
+  if (s_ring_timeout && tid == 0) atomicOr(a.status, (unsigned long long)SYNC_ST_RING);
   if (s_bad >= 0 && tid == 0) {
     // first failing pivot of the matrix: strips run in order, so the first writer wins
     unsigned long long expect = 0ull;
@@ -872,6 +910,19 @@ constexpr int FUSED_SMEM_STRIP = (2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_
 constexpr int FUSED_SMEM_FACTOR = (PB * SPP + PB + PB * PB + 3 * PB * 17 + 8 * 16 * 17) * 8;
 constexpr int FUSED_SMEM = FUSED_SMEM_STRIP > FUSED_SMEM_FACTOR ? FUSED_SMEM_STRIP : FUSED_SMEM_FACTOR;
 
+// Stream gate: the launches behind it in its stream start only once *p >= target -- another stream's
+// kernel has reached the point that raises the word.  One wave, polling politely; bounded like every
+// wait of the factorisation (status word, then the host's fallback).
+__global__ __launch_bounds__(64) void k_gate(const int* __restrict__ p, int target, unsigned long long* status, int spin_limit) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > spin_limit) { atomicOr(status, (unsigned long long)SYNC_ST_GATE); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+
 // p[b * stride + i] = 0 for i < count, b = blockIdx.y: one launch instead of one memset per batch matrix
 __global__ void k_zero_strided(double* __restrict__ p, long count, long stride) {
   double* q = p + (long)blockIdx.y * stride;
@@ -879,15 +930,19 @@ __global__ void k_zero_strided(double* __restrict__ p, long count, long stride) 
 }
 
 // Inverses of the 64 x 64 lower-triangular diagonal blocks of an nbk x nbk factor block (one
-// workgroup per block): back substitution on rows, x_r L = e_r, lane r of wave 0 owns row r.
-// Padded rows/cols are identity so the full 64-loop is safe.
+// workgroup per block).  Padded rows/cols are identity so the full 64-block is safe.
 // Lscr != null: block b's factor is read from Lscr + b*64*64 (ld 64) and also copied into its
 // place on the diagonal of D (upper part zero); Lscr == null: the factor is read from D.
-__global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, long lda, int nbk,
+// (two waves per SIMD in the bounds: at most 256 registers, so that a workgroup fits beside ONE resident
+//  GEMM workgroup -- with 340 registers it had to wait for a CU to drain completely: 1 - 1.8 ms behind a
+//  running trailing update, against 36 us alone)
+__global__ __launch_bounds__(256, 2) void trtri64_kernel(double* __restrict__ D, long lda, int nbk,
                                                       double* __restrict__ inv, long ldinv,
                                                       const double* __restrict__ Lscr, long strideD,
-                                                      long strideInv, long strideL) {
+                                                      long strideInv, long strideL, int zero_rest) {
   __shared__ double S[PB * PBP];
+  __shared__ double Tt[32 * 33];
+  __builtin_amdgcn_s_setprio(3);      // beside a GEMM wave on the same SIMD the chain's kernel goes first
   D += (long)blockIdx.y * strideD;
   if (inv) inv += (long)blockIdx.y * strideInv;
   if (Lscr) Lscr += (long)blockIdx.y * strideL;
@@ -896,6 +951,13 @@ __global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, lo
   const int j0 = blockIdx.x * PB;
   const int nb = min(PB, nbk - j0);
   double* A = D + (long)j0 * lda + j0;
+  if (zero_rest && inv) {
+    // this block's 64 rows of the 512-wide inverse, except the diagonal block written below
+    for (int idx = tid; idx < PB * (int)CHOL_NB; idx += 256) {
+      const int i = idx / (int)CHOL_NB, c = idx - i * (int)CHOL_NB;
+      if (c < j0 || c >= j0 + PB) inv[(long)(j0 + i) * ldinv + c] = 0.0;
+    }
+  }
   double a[16];
   if (Lscr) {
     const double* src = Lscr + (long)blockIdx.x * PB * PB;
@@ -912,22 +974,55 @@ __global__ __launch_bounds__(256) void trtri64_kernel(double* __restrict__ D, lo
 #pragma unroll
   for (int r = 0; r < 16; ++r) S[(w + 4 * r) * PBP + k] = a[r];
   __syncthreads();
+  // [[A, 0], [B, C]]^-1 = [[A^-1, 0], [-C^-1 B A^-1, C^-1]] with 32 x 32 blocks: the two triangular
+  // inverses by back substitution on rows (x_r L = e_r) in the two halves of wave 0 -- 32 values per
+  // lane instead of 64: the kernel stays far below 256 registers --, the off-diagonal block by two
+  // 32^3 products of the whole workgroup; everything in place in S.
   if (tid < 64) {
-    const int r = tid;
-    double x[PB];
+    const int r = tid & 31, o = 32 * (tid >> 5);
+    double x[32];
 #pragma unroll
-    for (int c = PB - 1; c >= 0; --c) {
+    for (int c = 31; c >= 0; --c) {
       double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int kk = c + 1; kk < PB; ++kk) s = fma(-x[kk], S[kk * PBP + c], s);
-      x[c] = s / S[c * PBP + c];
+      for (int kk = c + 1; kk < 32; ++kk) s = fma(-x[kk], S[(o + kk) * PBP + o + c], s);
+      x[c] = s / S[(o + c) * PBP + o + c];
     }
-    double* out = inv + (long)j0 * ldinv + j0;
-    if (r < nb) {
+    // (one wave, identical trip counts: every lane has read the factor entries before any is overwritten)
 #pragma unroll
-      for (int c = 0; c < PB; ++c)
-        if (c < nb) out[r * ldinv + c] = (c <= r) ? x[c] : 0.0;
+    for (int c = 0; c < 32; ++c) S[(o + r) * PBP + o + c] = (c <= r) ? x[c] : 0.0;
+  }
+  __syncthreads();
+  {
+    double t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                     // T = B A^-1  (A^-1 lower: k >= j)
+      const int idx = tid + 256 * q, i = idx >> 5, j = idx & 31;
+      double acc = 0.0;
+      for (int kk = j; kk < 32; ++kk) acc = fma(S[(32 + i) * PBP + kk], S[kk * PBP + j], acc);
+      t[q] = acc;
     }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, i = idx >> 5, j = idx & 31;
+      Tt[i * 33 + j] = t[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                     // X = -C^-1 T  (C^-1 lower: k <= i)
+      const int idx = tid + 256 * q, i = idx >> 5, j = idx & 31;
+      double acc = 0.0;
+      for (int kk = 0; kk <= i; ++kk) acc = fma(-S[(32 + i) * PBP + 32 + kk], Tt[kk * 33 + j], acc);
+      S[(32 + i) * PBP + j] = acc;
+    }
+  }
+  __syncthreads();
+  double* out = inv + (long)j0 * ldinv + j0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = w + 4 * r;
+    if (i < nb && k < nb) out[(long)i * ldinv + k] = (k <= i) ? S[i * PBP + k] : 0.0;
   }
 }
 
@@ -988,6 +1083,7 @@ int assemble_block_inverse(dfh_ctx* ctx, const double* D, int64_t lda, int64_t n
 // ---------------------------------------------------------------------------------------------
 __global__ void k_copy_lower_block(const double* __restrict__ D, long lda, int nbk, double* __restrict__ out,
                                    long strideD, long strideOut) {
+  __builtin_amdgcn_s_setprio(3);
   D += (long)blockIdx.z * strideD;
   out += (long)blockIdx.z * strideOut;
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
@@ -1002,6 +1098,7 @@ constexpr int DELTA_SLICES = 32;
 __global__ __launch_bounds__(256) void k_inv_delta(const double* __restrict__ E, int nbk, long strideE,
                                                     double* __restrict__ delta, long strideDelta) {
   __shared__ double sm[256];
+  __builtin_amdgcn_s_setprio(3);
   E += (long)blockIdx.x * strideE;
   double m = 0.0;
   bool bad = false;
@@ -1044,6 +1141,9 @@ int block_inverse_quality(dfh_ctx* ctx, const double* D, int64_t lda, int64_t nb
 
 int refine_steps(double delta) {
   static const double tol = []() { const char* e = getenv("DFH_REFINE_TOL"); double v = e ? atof(e) : 1e-13; return v; }();
+  // test hook (tests/test_gpu_refine_steps.py): every block takes this many steps whatever its inverse is like
+  static const int forced = []() { const char* e = getenv("DFH_REFINE_FORCE_STEPS"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced > 8 ? 8 : forced;
   if (!(delta > tol)) return 0;
   if (!(delta < 0.25)) return 8;                    // the inverse is barely an inverse: as many steps as we allow
   const int k = (int)ceil(log(1e-15) / log(delta)) - 1;
@@ -1060,14 +1160,47 @@ int refine_steps(double delta) {
 // P therefore factors panel k+1 while M is still busy with the big SYRK of panel k: the
 // latency-bound diagonal work leaves the critical path while the trailing update is long enough
 // to cover it.
-int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
-                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out,
-                    bool inv64_only) {
+//
+// Resident look-ahead (round 3; single matrices while at least DFH_CHOL_LR_MIN_REM rows are left).
+// The schedule above does not overlap in practice: a panel kernel needs whole CUs (122 KB of LDS, all
+// 512 registers of its lanes) and the trailing update refills every slot the moment it frees, so
+// the panel of k+1 used to start when the update of k had drained.  Now
+//   * the diagonal block of panel k+1 is factored by a launch of its own (panel_fused_kernel with no
+//     rows below: eight workgroups) that is enqueued BEFORE the trailing update of panel k may start:
+//     a one-wave gate kernel holds stream M until all eight have announced themselves (resident
+//     counter).  They then wait -- bounded -- for the update's first sixteen tiles, the next
+//     diagonal block, which the update computes first (look-ahead tile order, gemm_f64.hip) and
+//     announces through a counter; 3 % of the CUs idle for ~0.1 ms per panel;
+//   * the rows below the diagonal block are solved by GEMM with the explicit 512-block inverse the
+//     posterior keeps anyway, L21 = A21 M^T, refined in working precision when the inverse's measured
+//     quality asks for it (device-side condition: the refinement launches exit at once for a
+//     well-conditioned block) -- GEMM workgroups share the CUs with the update's, which the panel
+//     strips (one per CU) could not;
+//   * the update of panel k is ONE launch over the whole trailing matrix (the look-ahead block
+//     column is its first tiles instead of a launch of its own behind a stream barrier).
+// The chain diag(k+1) -> inverse -> solve then runs beside update(k), and the updates follow each
+// other on M as long as one lasts longer than the chain (~0.6 ms: n - k0 > ~8000).  Below that the
+// schedule above takes over (it is the faster one when the chain is all there is).
+namespace {
+
+// refinement step s (1-based) of a solve with a block inverse of quality delta is due iff
+// refine_steps(delta) >= s  <=>  delta > LR_REFINE_THR[s - 1]   (a NaN delta runs every step)
+constexpr int LR_REFINE_MAX = 1;   // (each step is two launches on the chain, usually no-ops of ~45 us beside the update)
+const double LR_REFINE_THR[3] = {0.0 /* = the tolerance, filled in at run time */, 3.1622776601683794e-8, 1e-5};
+
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+}  // namespace
+
+static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
+                                int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out,
+                                bool inv64_only, bool allow_lr, bool safe, int64_t clean_blocks = 0) {
   DFH_ARG(nbatch >= 1 && nbatch <= CHOL_MAX_BATCH);
   if (info_pivot) for (int b = 0; b < nbatch; ++b) info_pivot[b] = 0;
   if (n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
   long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
+  unsigned long long* d_status = reinterpret_cast<unsigned long long*>(d_info + CHOL_MAX_BATCH + 8);
   // Three streams.  P (high priority): the dependent chain -- 64-wide pivot steps over the panel,
   // each solving ALL rows below it by substitution, then the update of the next block column.
   // M (the caller's stream): the big trailing updates.  X (aux): everything the chain does not
@@ -1075,6 +1208,16 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   // for the triangular solves of the posterior.
   hipStream_t M = ctx->stream, P = ctx->side, X = ctx->aux;
   DFH_HIP(hipMemsetAsync(d_info, 0, 8 * (size_t)nbatch, M));
+  DFH_HIP(hipMemsetAsync(d_status, 0, 8, M));
+  // test hook: DFH_TEST_SPIN_LIMIT=0 makes every inter-workgroup wait expire at once (the fallback's test)
+  static const int spin_limit = env_int("DFH_TEST_SPIN_LIMIT", SPIN_LIMIT_DEFAULT);
+  static const int lr_on = env_int("DFH_CHOL_LR", 1);
+  static const long lr_min_rem = env_int("DFH_CHOL_LR_MIN_REM", 7680);
+  if (!keep_inv && !inv64_only && lr_on && allow_lr && !safe && nbatch == 1 && n - NB >= (lr_min_rem > 640 ? lr_min_rem : 640)) {
+    // the resident schedule solves the panels with the 512-block inverses: a caller that keeps none gets them from scratch
+    DFH_TRY(scratch_get(ctx, SCR_CHOLKEEP, (size_t)inv_buffer_doubles(n) * 8, (void**)&keep_inv));
+    refine_out = nullptr;
+  }
 
   const int64_t strideInv = keep_inv ? strideKeep : 0;          // between the batch matrices' inverse blocks
   const int64_t strideL = 2 * (NB / PB) * PB * PB;               // factor scratch: [parity][8][64][64] per matrix
@@ -1090,7 +1233,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   static const int fused_on = []() { const char* e = getenv("DFH_CHOL_FUSED"); return e ? atoi(e) : 1; }();
   // (lock-step batches of up to 16 gain 5-14 % from it as well -- tools/time_lml_batch.py --, 32 and more lose)
   static const int fused_max_batch = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : 16; }();
-  const bool fused_mode = fused_on && nbatch <= fused_max_batch;
+  const bool fused_mode = fused_on && nbatch <= fused_max_batch && !safe;   // safe: no inter-workgroup hand-offs
   if (fused_mode) DFH_HIP(hipMemsetAsync(fsync_all, 0, (size_t)nbatch * 16 * sizeof(int), ctx->stream));
   // Panel strips (panel_strip_kernel) for lock-step batches: there the pivot steps are throughput-bound
   // (64 matrices x 64 workgroups, each re-factoring the pivot block, one workgroup per CU) and the
@@ -1102,6 +1245,9 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   double* T = nullptr;
   if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
   const int64_t nblk_all = (n + NB - 1) / NB;
+  // blocks between an inverse and the clean copy of its diagonal block: the block count of the matrix
+  // keep_inv was laid out for (this one, unless the call factors a diagonal sub-block of a larger one)
+  if (clean_blocks <= 0) clean_blocks = nblk_all;
   double* d_delta = nullptr;                  // [nbatch][nblk] quality of the kept block inverses
   if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_DELTA, (size_t)nbatch * nblk_all * 8, (void**)&d_delta));
   GemmBatch bA;                               // every operand inside the batch matrices
@@ -1121,13 +1267,33 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   const int64_t nblk = (n + NB - 1) / NB;
   static const bool pair_on = []() { const char* e = getenv("DFH_CHOL_PAIR"); return e ? atoi(e) != 0 : true; }();
   static const long pair_min_rem = []() { const char* e = getenv("DFH_CHOL_PAIR_MIN_REM"); return e ? atol(e) : 6144L; }();
-  DFH_ARG(3 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
+  DFH_ARG(5 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
+
+  // ---- resident look-ahead: which panels, and what it needs (nothing may allocate inside the loop:
+  //      hipMalloc can wait for the device, and a gate kernel may be waiting for a launch not yet enqueued) ----
+  int64_t kb_lr = 0;                          // panels [0, kb_lr) take the resident schedule
+  if (lr_on && allow_lr && !safe && nbatch == 1 && keep_inv && !inv64_only && fused_mode) {
+    const int64_t floor_rem = lr_min_rem > 640 ? lr_min_rem : 640;     // >= 5 tile rows for the look-ahead order
+    while (n - (kb_lr + 1) * NB >= floor_rem) ++kb_lr;
+    kb_lr &= ~(int64_t)1;                     // the schedule below pairs panels from an even index on
+  }
+  int* lr_sync = nullptr;                     // per panel {diag workgroups resident, next diagonal block's tiles done, next block column's tiles done, -}
+  double *lr_X = nullptr, *lr_R = nullptr;    // the solved rows (two buffers, alternating), their residual (rows below the first panel x 512 each)
+  const int64_t lr_xstride = (n - NB) * NB;
+  if (kb_lr > 0) {
+    DFH_TRY(scratch_get(ctx, SCR_CHOLSYNC, (size_t)kb_lr * 4 * sizeof(int), (void**)&lr_sync));
+    DFH_HIP(hipMemsetAsync(lr_sync, 0, (size_t)kb_lr * 4 * sizeof(int), M));
+    DFH_TRY(scratch_get(ctx, SCR_CHOLX, (size_t)2 * lr_xstride * 8, (void**)&lr_X));
+    DFH_TRY(scratch_get(ctx, SCR_CHOLR, (size_t)(n - NB) * NB * 8, (void**)&lr_R));
+  }
+  static const double refine_tol = []() { const char* e = getenv("DFH_REFINE_TOL"); return e ? atof(e) : 1e-13; }();
   hipEvent_t ev_start, ev_done;
   DFH_TRY(ctx_event(ctx, 0, &ev_start));
   DFH_TRY(ctx_event(ctx, 1, &ev_done));
   DFH_HIP(hipEventRecord(ev_start, M));
   DFH_HIP(hipStreamWaitEvent(P, ev_start, 0));
   DFH_HIP(hipStreamWaitEvent(X, ev_start, 0));
+  if (ctx->bulk_normal) DFH_HIP(hipStreamWaitEvent(ctx->bulk_normal, ev_start, 0));
 
   for (int64_t kb = 0; kb < nblk; ++kb) {
     const int64_t k0 = kb * NB;
@@ -1142,22 +1308,151 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     const bool paired = pair_on && ((kb & 1) ? rem + NB : rem) > pair_min_rem;
     const bool strips = strips_on && rem > 0 && nbk == NB && (int64_t)nbatch * ((rem + PB - 1) / PB) <= strips_max_wg &&
                         (int64_t)nbatch * ((rem + PB - 1) / PB) >= strips_min_wg;
-    hipEvent_t e_panel, e_trail, e_aux, e_trail_prev = nullptr, e_aux_prev2 = nullptr;
-    DFH_TRY(ctx_event(ctx, 2 + 3 * kb, &e_panel));
-    DFH_TRY(ctx_event(ctx, 3 + 3 * kb, &e_trail));
-    DFH_TRY(ctx_event(ctx, 4 + 3 * kb, &e_aux));
-    if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 3 * (kb - 1), &e_trail_prev));
-    if (kb >= 2) DFH_TRY(ctx_event(ctx, 4 + 3 * (kb - 2), &e_aux_prev2));
+    hipEvent_t e_panel, e_trail, e_aux, e_diag, e_trail_prev = nullptr, e_aux_prev2 = nullptr;
+    hipEvent_t e_copy, e_copy_prev = nullptr, e_copy_prev2 = nullptr;
+    DFH_TRY(ctx_event(ctx, 2 + 5 * kb, &e_panel));
+    DFH_TRY(ctx_event(ctx, 3 + 5 * kb, &e_trail));
+    DFH_TRY(ctx_event(ctx, 4 + 5 * kb, &e_aux));
+    DFH_TRY(ctx_event(ctx, 5 + 5 * kb, &e_diag));
+    DFH_TRY(ctx_event(ctx, 6 + 5 * kb, &e_copy));
+    if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 5 * (kb - 1), &e_trail_prev));
+    if (kb >= 2) DFH_TRY(ctx_event(ctx, 4 + 5 * (kb - 2), &e_aux_prev2));
+    if (kb >= 1) DFH_TRY(ctx_event(ctx, 6 + 5 * (kb - 1), &e_copy_prev));
+    if (kb >= 2) DFH_TRY(ctx_event(ctx, 6 + 5 * (kb - 2), &e_copy_prev2));
+    // ---- off the chain (stream X): factor blocks into place, 64-block inverses, 512-block inverse, its quality ----
+    auto aux_block = [&](hipEvent_t after, hipStream_t X) -> int {     // (X: the stream it runs on)
+      StreamSwap on_x(ctx, X);
+      if (after) DFH_HIP(hipStreamWaitEvent(X, after, 0));
+      const bool zero_in_trtri = X != ctx->aux && nbk == NB;     // resident panels: one launch less on the chain
+      if (Linv && !zero_in_trtri) {
+        if (nbatch == 1) {
+          DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, X));
+        } else {
+          hipLaunchKernelGGL(k_zero_strided, dim3(64, (unsigned)nbatch), dim3(256), 0, X, Linv, (long)(NB * NB), (long)strideInv);
+          DFH_LAUNCH_CHECK();
+        }
+      }
+      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, X,
+                         D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
+                         (long)strideL, zero_in_trtri ? 1 : 0);
+      DFH_LAUNCH_CHECK();
+      if (Linv && !inv64_only) {
+        DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
+        // clean copy of the block behind the inverses (keep_inv + nblk*NB*NB + ...) and delta = max|I - M L_bb|
+        DFH_TRY(block_inverse_quality(ctx, D, lda, nbk, Linv, Linv + clean_blocks * NB * NB, T, d_delta + kb, nbatch,
+                                      strideA, strideInv, strideT, nblk_all));
+      }
+      DFH_HIP(hipEventRecord(e_aux, X));
+      return DFH_OK;
+    };
+    if (kb < kb_lr) {
+      // =============== resident look-ahead panel (see the comment above cholesky_device_impl) ===============
+      int* sy = lr_sync + 4 * kb;
+      static const bool lr_chain_normal_prio = env_int("DFH_CHOL_LR_NORMAL_PRIO", 0) != 0;
+      hipStream_t Pc = lr_chain_normal_prio ? ctx->bulk_normal : P;
+      double* A21 = A + (k0 + NB) * lda + k0;          // rem x 512: the rows below the diagonal block
+      double* Xk = lr_X + (kb & 1) * lr_xstride;
+      {
+        StreamSwap on_p(ctx, Pc);
+        if (e_aux_prev2) DFH_HIP(hipStreamWaitEvent(Pc, e_aux_prev2, 0));     // factor scratch of this parity is free again
+        // Not before update(kb-2) has finished: the eight workgroups need whole CUs, and a high-priority
+        // launch that is PENDING because it does not fit throttles the dispatch of the running update
+        // (measured: update(0) 2.42 ms with this launch enqueued after it, 2.52 / 2.71 ms with it pending
+        // for the last 0.45 / 1.2 ms).  update(kb-1) cannot start before update(kb-2) has ended anyway.
+        if (kb >= 2) {
+          hipEvent_t e_trail_prev2;
+          DFH_TRY(ctx_event(ctx, 3 + 5 * (kb - 2), &e_trail_prev2));
+          DFH_HIP(hipStreamWaitEvent(Pc, e_trail_prev2, 0));
+        }
+        FusedArgs fa;
+        fa.D = D; fa.lda = lda; fa.Lfac = Lscr; fa.Linv16 = Iscr; fa.sync = fsync_all; fa.epoch = (int)kb + 1;
+        fa.nbk = (int)NB; fa.rows_below = 0; fa.info = d_info; fa.pivot_base = (long)k0;
+        fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
+        fa.status = d_status; fa.spin_limit = spin_limit;
+        fa.resident = sy;
+        fa.wait_ptr = kb > 0 ? sy - 4 + 1 : nullptr;   // the sixteen... ten lower tiles of this diagonal block, out of update(kb-1)
+        fa.wait_target = 10;
+        hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(NB / PB), 1), dim3(256), FUSED_SMEM, Pc, fa);
+        DFH_LAUNCH_CHECK();
+        DFH_HIP(hipEventRecord(e_diag, Pc));
+      }
+      // the inverse is ON the chain here (the panel solve multiplies by it): it runs on the priority
+      // stream -- on the auxiliary stream its small kernels wait for a slot behind the trailing update's
+      // pending workgroups (trtri64: 36 us alone, 1.3 - 1.8 ms beside the update)
+      DFH_TRY(aux_block(nullptr, Pc));
+      {
+        StreamSwap on_p(ctx, Pc);
+        if (kb > 0) {
+          // the whole block column has to be out of update(kb-1): 4 T - 6 look-ahead tiles over T tile rows
+          const int64_t Tprev = (rem + NB + 127) / 128;
+          hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, Pc, (const int*)(sy - 4 + 2), (int)(4 * Tprev - 6), d_status, spin_limit);
+          DFH_LAUNCH_CHECK();
+        }
+        const double* Mi = Linv;                               // inverse of the diagonal block (lower, ld NB)
+        const double* Lbb = Linv + clean_blocks * NB * NB;      // its clean copy
+        // the solved rows go to a panel buffer of their own (two, alternating): the trailing update reads
+        // them from there (contiguous, ld 512) and the copy into the factor happens off the chain
+        if (e_copy_prev2) DFH_HIP(hipStreamWaitEvent(Pc, e_copy_prev2, 0));      // the buffer's previous contents are in place
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, rem, NB, NB, 1.0, A21, lda, Mi, NB, 0.0, nullptr, 0, Xk, NB));
+        for (int st = 0; st < LR_REFINE_MAX; ++st) {
+          // X <- X + (A21 - X L_bb^T) M^T, the right-hand side untouched; skipped on the device unless due
+          ctx->gemm_cond = d_delta + kb;
+          ctx->gemm_cond_thr = st == 0 ? refine_tol : LR_REFINE_THR[st];
+          int rc_r = gemm_f64(ctx, GEMM_KTRI_B, rem, NB, NB, -1.0, Xk, NB, Lbb, NB, 1.0, A21, lda, lr_R, NB);
+          if (rc_r == DFH_OK) rc_r = gemm_f64(ctx, GEMM_KTRI_B, rem, NB, NB, 1.0, lr_R, NB, Mi, NB, 1.0, Xk, NB, Xk, NB);
+          ctx->gemm_cond = nullptr;
+          DFH_TRY(rc_r);
+        }
+        DFH_HIP(hipEventRecord(e_panel, Pc));
+      }
+      {
+        StreamSwap on_x(ctx, X);
+        DFH_HIP(hipStreamWaitEvent(X, e_panel, 0));
+        DFH_TRY(copy_matrix(ctx, Xk, NB, A21, lda, rem, NB));
+        DFH_HIP(hipEventRecord(e_copy, X));
+      }
+      // ---- M: the whole trailing update with this panel, next block column first ----
+      DFH_HIP(hipStreamWaitEvent(M, e_panel, 0));
+      const bool next_resident = kb + 1 < kb_lr;
+      if (next_resident) {
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, M, (const int*)(sy + 4), (int)(NB / PB), d_status, spin_limit);
+        DFH_LAUNCH_CHECK();
+      }
+      {
+        double* C = A + (k0 + NB) * lda + (k0 + NB);
+        ctx->gemm_la_cnt = next_resident ? sy + 1 : nullptr;
+        const int rc_u = gemm_f64(ctx, GEMM_LOWER, rem, rem, NB, -1.0, Xk, NB, Xk, NB, 1.0, C, lda, C, lda);
+        ctx->gemm_la_cnt = nullptr;
+        DFH_TRY(rc_u);
+      }
+      DFH_HIP(hipEventRecord(e_trail, M));
+      continue;
+    }
     {
       StreamSwap on_p(ctx, P);
       if (e_aux_prev2) DFH_HIP(hipStreamWaitEvent(P, e_aux_prev2, 0));     // factor scratch of this parity is free again
+      // the last resident panel's update covered this block column too: it has to be complete, and
+      // the last two resident panels' solved rows have to be in place
+      if (kb == kb_lr && kb > 0 && e_trail_prev) {
+        DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
+        if (e_copy_prev) DFH_HIP(hipStreamWaitEvent(P, e_copy_prev, 0));
+        if (e_copy_prev2) DFH_HIP(hipStreamWaitEvent(P, e_copy_prev2, 0));
+      }
       const bool fused = fused_mode;                  // full panels, and the (last) partial one: identity padding
+      // Experiment switch (off): no look-ahead at all above DFH_CHOL_SERIAL_MIN_REM rows -- the one-launch
+      // panel cannot be placed while the update runs and, pending, slows it (K = 1024 updates at 52 TF/s
+      // against 64 alone); starting it only when the update has finished nevertheless LOSES (n = 16384
+      // 34.5 -> 35.1 ms, 8192 7.06 -> 7.9): the panel does overlap the update's last wave of tiles.
+      static const long serial_min_rem = env_int("DFH_CHOL_SERIAL_MIN_REM", 1 << 30);
+      if (fused && kb > 0 && e_trail_prev && rem + nbk > serial_min_rem) DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
       if (fused) {
         // ---- the whole panel in one launch: diagonal block by eight flag-synchronised strips, rows below alongside ----
         FusedArgs fa;
         fa.D = D; fa.lda = lda; fa.Lfac = Lscr; fa.Linv16 = Iscr; fa.sync = fsync_all; fa.epoch = (int)kb + 1;
         fa.nbk = (int)nbk; fa.rows_below = (int)rem; fa.info = d_info; fa.pivot_base = (long)k0;
         fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
+        fa.status = d_status; fa.spin_limit = spin_limit;
+        fa.resident = nullptr; fa.wait_ptr = nullptr; fa.wait_target = 0;
         hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)((nbk + PB - 1) / PB + (rem + PB - 1) / PB), (unsigned)nbatch),
                            dim3(256), FUSED_SMEM, P, fa);
         DFH_LAUNCH_CHECK();
@@ -1203,30 +1498,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
         DFH_TRY(gemm_f64(ctx, 0, rem, nb1, kw, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
       }
     }
-    {
-      // ---- off the chain: factor blocks into place, 64-block inverses, 512-block inverse ----
-      StreamSwap on_x(ctx, X);
-      DFH_HIP(hipStreamWaitEvent(X, e_panel, 0));
-      if (Linv) {
-        if (nbatch == 1) {
-          DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, X));
-        } else {
-          hipLaunchKernelGGL(k_zero_strided, dim3(64, (unsigned)nbatch), dim3(256), 0, X, Linv, (long)(NB * NB), (long)strideInv);
-          DFH_LAUNCH_CHECK();
-        }
-      }
-      hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB), (unsigned)nbatch), dim3(256), 0, X,
-                         D, (long)lda, (int)nbk, Linv, (long)NB, Lscr, (long)strideA, (long)strideInv,
-                         (long)strideL);
-      DFH_LAUNCH_CHECK();
-      if (Linv && !inv64_only) {
-        DFH_TRY(assemble_block_inverse(ctx, D, lda, nbk, Linv, T, nbatch, strideA, strideInv, strideT));
-        // clean copy of the block behind the inverses (keep_inv + nblk*NB*NB + ...) and delta = max|I - M L_bb|
-        DFH_TRY(block_inverse_quality(ctx, D, lda, nbk, Linv, Linv + nblk_all * NB * NB, T, d_delta + kb, nbatch,
-                                      strideA, strideInv, strideT, nblk_all));
-      }
-      DFH_HIP(hipEventRecord(e_aux, X));
-    }
+    DFH_TRY(aux_block(e_panel, X));
     // Paired mode: the trailing update runs after every SECOND panel, 1024 wide (the K = 512 update
     // reads and writes the C tile once per 512 columns of operand: 54 TF/s at n = 15872 against 63 for
     // K = 1024, tools/syrk_k.py).  The first panel of a pair only updates the next block column (the
@@ -1260,20 +1532,27 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   DFH_HIP(hipStreamWaitEvent(M, ev_done, 0));
   {
     hipEvent_t e_aux_last;
-    DFH_TRY(ctx_event(ctx, 4 + 3 * (nblk - 1), &e_aux_last));
+    DFH_TRY(ctx_event(ctx, 4 + 5 * (nblk - 1), &e_aux_last));
     DFH_HIP(hipStreamWaitEvent(M, e_aux_last, 0));
   }
 
   DFH_HIP(hipMemcpyAsync(ctx->h_info, d_info, 8 * (size_t)nbatch, hipMemcpyDeviceToHost, M));
+  DFH_HIP(hipMemcpyAsync(ctx->h_info + CHOL_MAX_BATCH + 8, d_status, 8, hipMemcpyDeviceToHost, M));
   std::vector<double> deltas;
   if (keep_inv && refine_out && inv64_only) {
     for (size_t i = 0; i < (size_t)nbatch * nblk_all; ++i) refine_out[i] = 0;
-  } else if (keep_inv && refine_out) {
+  } else if (keep_inv && (refine_out || kb_lr > 0)) {
     deltas.resize((size_t)nbatch * nblk_all);
     DFH_HIP(hipMemcpyAsync(deltas.data(), d_delta, deltas.size() * 8, hipMemcpyDeviceToHost, M));
   }
   DFH_HIP(hipStreamSynchronize(M));
-  for (size_t i = 0; i < deltas.size(); ++i) refine_out[i] = refine_steps(deltas[i]);
+  if (refine_out) for (size_t i = 0; i < deltas.size(); ++i) refine_out[i] = refine_steps(deltas[i]);
+  const unsigned long long sync_status = (unsigned long long)ctx->h_info[CHOL_MAX_BATCH + 8];
+  if (sync_status != 0) {
+    // a bounded wait expired: whatever was computed after it is not to be trusted
+    dfh_set_error("Cholesky: an inter-workgroup hand-off timed out (status %llx)", sync_status);
+    return DFH_INTERNAL_RETRY;
+  }
   int rc = DFH_OK;
   for (int b = 0; b < nbatch; ++b) {
     const int64_t piv = ctx->h_info[b];
@@ -1283,7 +1562,82 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
       rc = DFH_ERR_NOT_PD;
     }
   }
+  if (rc == DFH_OK) {
+    // a resident panel solved its rows with the block inverse and at most LR_REFINE_MAX refinement steps
+    // on the device; an inverse so poor that more are due sends the matrix through the substitution schedule
+    for (int64_t kb = 0; kb < kb_lr; ++kb)
+      if (refine_steps(deltas[(size_t)kb]) > LR_REFINE_MAX) {
+        dfh_set_error("Cholesky: diagonal block %lld too ill-conditioned for the inverse-based panel solve", (long long)kb);
+        return DFH_INTERNAL_RETRY;
+      }
+  }
   return rc;
+}
+
+// rebuild (optional): re-creates the input matrix in A (a failed or abandoned factorisation destroys
+// it).  With it the call may use the schedules whose rare failure modes need a second attempt -- the
+// resident look-ahead with its inverse-based panel solve; a hand-off timeout -- and repeats itself on
+// the conservative schedule (no inter-workgroup waits, substitution only) when one occurs.  Without
+// it such a failure is DFH_ERR_HIP.
+// rebuild (optional): re-creates the input matrix in A (a failed or abandoned factorisation destroys
+// it).  With it the call may use the schedules whose rare failure modes need a second attempt -- the
+// resident look-ahead with its inverse-based panel solve; a hand-off timeout -- and repeats itself on
+// the conservative schedule (no inter-workgroup waits, substitution only) when one occurs.  Without
+// it such a failure is DFH_ERR_HIP.
+// Two-way recursion for large single matrices:
+//     A = [[A11, .], [A21, A22]] :  L11 = chol(A11) ;  L21 = A21 L11^-T ;  A22 -= L21 L21^T ;  L22 = chol(A22)
+// with the panel solve as the posterior's GEMM-based row solve (trsm_rows: block inverses + refinement
+// where the measured quality asks for it) and the update as ONE lower-triangular product of depth
+// K = n/2.  Half of the flops of the factorisation move from K = 512 trailing updates (52 - 60 TF/s
+// inside the look-ahead schedules) to products of depth n/2 (66 - 68 TF/s), and the two halves
+// are factorised by whatever schedule suits their size.  n = 16384: 32.1 (resident look-ahead) /
+// 34.5 (round 2) -> see DESIGN.md section 7 for the measured numbers.
+static int chol_recursive(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* inv_base, int64_t kb0,
+                          int64_t nblk_total, int64_t* info_pivot, int* refine_all, bool allow_lr, bool safe,
+                          int64_t rec_min) {
+  const int64_t NB = CHOL_NB;
+  double* keep = inv_base + kb0 * NB * NB;
+  if (n <= rec_min) {
+    return cholesky_device_impl(ctx, A, n, lda, keep, info_pivot, 1, 0, 0, refine_all + kb0, false, allow_lr, safe,
+                                nblk_total);
+  }
+  const int64_t n1 = (((n + 1) / 2 + NB - 1) / NB) * NB, n2 = n - n1;
+  DFH_TRY(chol_recursive(ctx, A, n1, lda, inv_base, kb0, nblk_total, info_pivot, refine_all, allow_lr, safe, rec_min));
+  double* A21 = A + n1 * lda;
+  DFH_TRY(trsm_rows(ctx, A, n1, lda, keep, A21, n2, lda, refine_all + kb0, keep + nblk_total * NB * NB));
+  double* A22 = A + n1 * lda + n1;
+  DFH_TRY(gemm_f64(ctx, GEMM_LOWER, n2, n2, n1, -1.0, A21, lda, A21, lda, 1.0, A22, lda, A22, lda));
+  int64_t piv2 = 0;
+  const int rc = chol_recursive(ctx, A22, n2, lda, inv_base, kb0 + n1 / NB, nblk_total, &piv2, refine_all, allow_lr, safe,
+                                rec_min);
+  if (piv2 != 0 && info_pivot) *info_pivot = piv2 + n1;
+  if (rc == DFH_ERR_NOT_PD) dfh_set_error("Matrix is not positive definite (pivot %lld)", (long long)(piv2 + n1));
+  return rc;
+}
+
+// rebuild (optional): re-creates the input matrix in A (a failed or abandoned factorisation destroys
+// it).  With it the call may use the schedules whose rare failure modes need a second attempt -- the
+// resident look-ahead with its inverse-based panel solve; a hand-off timeout -- and repeats itself on
+// the conservative schedule (no inter-workgroup waits, substitution only) when one occurs.  Without
+// it such a failure is DFH_ERR_HIP.
+int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
+                    int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out,
+                    bool inv64_only, const std::function<int()>* rebuild) {
+  static const bool force_safe = env_int("DFH_CHOL_SAFE", 0) != 0;
+  // (Tried and dropped, round 3: a two-way recursion -- L11, the posterior's GEMM-based row solve for
+  //  L21, ONE update of depth n/2, L22.  The deep update does run at 66 TF/s, but the row solve of only
+  //  n/2 rows is a chain of 256-tile launches at half occupancy: n = 16384 34.6 ms against 31.8 with
+  //  the resident look-ahead, n = 8192 8.7 against 7.0.)
+  auto attempt = [&](bool allow_lr, bool safe) -> int {
+    return cholesky_device_impl(ctx, A, n, lda, keep_inv, info_pivot, nbatch, strideA, strideKeep, refine_out,
+                                inv64_only, allow_lr, safe);
+  };
+  int rc = attempt(rebuild != nullptr, force_safe);
+  if (rc != DFH_INTERNAL_RETRY) return rc;
+  if (!rebuild || force_safe) return DFH_ERR_HIP;
+  DFH_TRY((*rebuild)());
+  rc = attempt(false, true);
+  return rc == DFH_INTERNAL_RETRY ? DFH_ERR_HIP : rc;
 }
 
 // Right-looking block substitution: once x_i is final it is pushed into every remaining row
@@ -1344,16 +1698,26 @@ int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const d
   return DFH_OK;
 }
 
+// residual buffer of the refined row solves (m x NB), only when some block takes a step
+static int refine_scratch(dfh_ctx* ctx, const int* refine, int64_t nblk, int64_t m, double** out) {
+  *out = nullptr;
+  bool any = false;
+  for (int64_t b = 0; refine && b < nblk; ++b) any = any || refine[b] > 0;
+  if (any) DFH_TRY(scratch_get(ctx, SCR_REFINE, (size_t)m * CHOL_NB * 8, (void**)out));
+  return DFH_OK;
+}
+
 // at most this many right-hand rows take the right-looking (wide, shallow) form of trsm_rows
 constexpr int64_t TRSM_FEW_ROWS = 256;
 
 int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-              double* Kct, int64_t m, int64_t ldk, const int* refine) {
+              double* Kct, int64_t m, int64_t ldk, const int* refine, const double* diag_override) {
   if (m <= 0 || n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
-  const double* diag = inv + ((n + NB - 1) / NB) * NB * NB;      // clean copies of the diagonal blocks
-  double* T = nullptr;
+  const double* diag = diag_override ? diag_override : inv + ((n + NB - 1) / NB) * NB * NB;      // clean copies of the diagonal blocks
+  double *T = nullptr, *R2 = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TMP, (size_t)m * NB * 8, (void**)&T));
+  DFH_TRY(refine_scratch(ctx, refine, (n + NB - 1) / NB, m, &R2));
   if (m <= TRSM_FEW_ROWS) {
     // A handful of rows (single-point GP.eval calls, tree-search frontiers, hallucinated batches):
     // the left-looking form below would run each block as ONE tile row with a K loop over every
@@ -1375,11 +1739,12 @@ int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const doubl
       else
         DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 0.0, nullptr, 0, T, NB));
       for (int s = 0; s < (refine ? refine[c0 / NB] : 0); ++s) {
-        // residual in place of the right-hand side (it is overwritten by the solution below anyway):
-        // R <- R - X L_bb^T ; X <- X + R Linv^T
+        // R <- B - X L_bb^T from the untouched right-hand side (it is only overwritten by the solution
+        // below) ; X <- X + R Linv^T.  (Round 2 kept the residual IN PLACE of the right-hand side, which
+        // is right for one step only: the second would subtract X0 L^T twice.)
         const double* Lbb = diag + (c0 / NB) * NB * NB;
-        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, -1.0, T, NB, Lbb, NB, 1.0, Kct + c0, ldk, Kct + c0, ldk));
-        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, Kct + c0, ldk, Linv, NB, 1.0, T, NB, T, NB));
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, -1.0, T, NB, Lbb, NB, 1.0, Kct + c0, ldk, R2, NB));
+        DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, R2, NB, Linv, NB, 1.0, T, NB, T, NB));
       }
       if (skinny_update) {
         DFH_TRY(gemm_skinny_nt(ctx, m, rest, w, -1.0, T, NB, Lpanel, ldl, 1.0, Kct + c0 + w, ldk,
@@ -1401,10 +1766,10 @@ int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const doubl
     const double* Linv = inv + (c0 / NB) * NB * NB;
     DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, T, NB, Linv, NB, 0.0, nullptr, 0, Kct + c0, ldk));
     for (int s = 0; s < (refine ? refine[c0 / NB] : 0); ++s) {
-      // T <- T - X L_bb^T (the residual) ; X <- X + T Linv^T
+      // R <- T - X L_bb^T (the residual of the right-hand side T, which stays) ; X <- X + R Linv^T
       const double* Lbb = diag + (c0 / NB) * NB * NB;
-      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, -1.0, Kct + c0, ldk, Lbb, NB, 1.0, T, NB, T, NB));
-      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, T, NB, Linv, NB, 1.0, Kct + c0, ldk, Kct + c0, ldk));
+      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, -1.0, Kct + c0, ldk, Lbb, NB, 1.0, T, NB, R2, NB));
+      DFH_TRY(gemm_f64(ctx, GEMM_KTRI_B, m, w, w, 1.0, R2, NB, Linv, NB, 1.0, Kct + c0, ldk, Kct + c0, ldk));
     }
   }
   return DFH_OK;
@@ -1425,7 +1790,7 @@ int tri_block_inverses(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, do
     DFH_HIP(hipMemsetAsync(Linv, 0, (size_t)NB * NB * 8, ctx->stream));
     const double* D = L + k0 * ldl + k0;
     hipLaunchKernelGGL(trtri64_kernel, dim3((unsigned)((nbk + PB - 1) / PB)), dim3(256), 0, ctx->stream,
-                       const_cast<double*>(D), (long)ldl, (int)nbk, Linv, (long)NB, (const double*)nullptr, 0L, 0L, 0L);
+                       const_cast<double*>(D), (long)ldl, (int)nbk, Linv, (long)NB, (const double*)nullptr, 0L, 0L, 0L, 0);
     DFH_LAUNCH_CHECK();
     DFH_TRY(assemble_block_inverse(ctx, D, ldl, nbk, Linv, T));
     DFH_TRY(block_inverse_quality(ctx, D, ldl, nbk, Linv, diag + (k0 / NB) * NB * NB, T, d_delta + k0 / NB));
@@ -1444,9 +1809,10 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
   if (m <= 0 || n <= 0) return DFH_OK;
   const int64_t NB = CHOL_NB;
   const double* diag = inv + ((n + NB - 1) / NB) * NB * NB;
-  double* T = nullptr;
+  double *T = nullptr, *R2 = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_TMP, (size_t)m * NB * 8, (void**)&T));
   const int64_t nblk = (n + NB - 1) / NB;
+  DFH_TRY(refine_scratch(ctx, refine, nblk, m, &R2));
   for (int64_t b = nblk - 1; b >= 0; --b) {
     const int64_t c0 = b * NB;
     const int64_t w = (n - c0 < NB) ? n - c0 : NB;
@@ -1458,9 +1824,9 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
     DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, T, NB, inv + b * NB * NB, NB, 0.0, nullptr, 0,
                      Bt + c0, ldb));
     for (int s = 0; s < (refine ? refine[b] : 0); ++s) {
-      // T <- T - X L_bb (the residual) ; X <- X + T Linv
-      DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, -1.0, Bt + c0, ldb, diag + b * NB * NB, NB, 1.0, T, NB, T, NB));
-      DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, T, NB, inv + b * NB * NB, NB, 1.0, Bt + c0, ldb, Bt + c0, ldb));
+      // R <- T - X L_bb (the residual of the right-hand side T, which stays) ; X <- X + R Linv
+      DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, -1.0, Bt + c0, ldb, diag + b * NB * NB, NB, 1.0, T, NB, R2, NB));
+      DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, R2, NB, inv + b * NB * NB, NB, 1.0, Bt + c0, ldb, Bt + c0, ldb));
     }
   }
   return DFH_OK;

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <functional>
 #include "../../include/dfhip.h"
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -56,11 +57,12 @@ struct dfh_ctx {
   hipStream_t side = nullptr;        // high-priority panel stream of the look-ahead Cholesky
   hipStream_t bulk = nullptr;        // low-priority stream: next chunk's cross kernel + TRSM (TS)
   hipStream_t aux = nullptr;         // off-critical-path work of the factorisation (block inverses)
+  hipStream_t bulk_normal = nullptr; // normal-priority twin of `side` (experiments: DFH_CHOL_LR_NORMAL_PRIO)
   std::vector<hipEvent_t> evpool;    // untimed events for cross-stream ordering
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
   std::vector<DevBuf> scratch;
-  int64_t* d_info = nullptr;                         // device int64[CHOL_MAX_BATCH + 8]: pivot flag per batch matrix, then debug words
+  int64_t* d_info = nullptr;                         // device int64[CHOL_MAX_BATCH + 16]: pivot flag per batch matrix, 8 debug words, hand-off status
   int64_t* h_info = nullptr;                         // pinned mirror
   void* h_stage = nullptr; size_t h_stage_bytes = 0; // pinned, grow-only: small per-call blobs and results
   // section timing
@@ -73,6 +75,11 @@ struct dfh_ctx {
   // When set, 128x128 GEMM launches request > 80 KB of LDS so that only ONE workgroup fits per
   // CU: the other half of every CU stays available to latency-critical kernels of another stream.
   bool gemm_half_occupancy = false;
+  // Extended GEMM launches of the factorisation (gemm_f64.hip, chol.hip), consumed by the next
+  // gemm_f64 call(s) while set: a device-side skip condition (the launch exits unless *gemm_cond >
+  // gemm_cond_thr) and the look-ahead tile order with its completion counters.
+  const double* gemm_cond = nullptr; double gemm_cond_thr = 0.0;
+  int* gemm_la_cnt = nullptr;
   bool gemm_prof = false;
   struct GemmRec { hipEvent_t e0, e1; double flops, bytes; int variant; };
   std::vector<GemmRec> gemm_recs;
@@ -115,6 +122,11 @@ enum ScratchSlot {
   SCR_OUT,          // device result staging for host outputs
   SCR_OUT2,
   SCR_DELTA,        // quality of the kept block inverses (one double per diagonal block)
+  SCR_CHOLSYNC,     // resident look-ahead Cholesky: per-panel counters
+  SCR_CHOLX,        // ... its inverse-based panel solve: solution
+  SCR_CHOLR,        // ... and residual
+  SCR_REFINE,       // residual of the refined row solves (trsm_rows*)
+  SCR_CHOLKEEP,     // ... block inverses when the caller keeps none
   SCR_COUNT
 };
 
@@ -273,9 +285,13 @@ inline int64_t inv_buffer_doubles(int64_t n) { return 2 * ((n + CHOL_NB - 1) / C
 // inv64_only: keep_inv receives only the inverses of the 64 x 64 diagonal blocks (on the diagonal of
 // each 512-block slot, zero elsewhere) -- no 512-block assembly, no quality measurement, refine_out
 // all zero: for callers that substitute with 64-blocks themselves (the small tuning objective).
+// rebuild (optional): restores the input in A; enables the schedules that may need a second attempt
+// (chol.hip: resident look-ahead, hand-off timeouts) -- without it those failures are DFH_ERR_HIP.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
                     int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0, int64_t strideKeep = 0,
-                    int* refine_out = nullptr, bool inv64_only = false);
+                    int* refine_out = nullptr, bool inv64_only = false,
+                    const std::function<int()>* rebuild = nullptr);
+constexpr int DFH_INTERNAL_RETRY = 1000;   // chol.hip internal: never crosses the C-ABI
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x
@@ -286,8 +302,9 @@ int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const d
                   double* x, const int* refine = nullptr);
 // Rows-as-RHS solve used by the posterior:  Vt[m x n] <- Kct[m x n] * L^{-T}  (in place),
 // i.e. each row v of Vt satisfies L v = k  (solve_lower_triangular(L, K_tetr.T), gp_core.py:180)
+// diag_override: where the clean copies of L's diagonal blocks are, when not right behind its inverses
 int trsm_rows(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
-              double* Kct, int64_t m, int64_t ldk, const int* refine = nullptr);
+              double* Kct, int64_t m, int64_t ldk, const int* refine = nullptr, const double* diag_override = nullptr);
 // Xt[m x n] <- Bt[m x n] * L^{-1} (in place): each row x satisfies L^T x = b
 int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
                        double* Bt, int64_t m, int64_t ldb, const int* refine = nullptr);

@@ -44,6 +44,8 @@ template <int WT> struct Geo {
   static constexpr int NN_PASSES = BK / NN_ROWS;
 };
 
+constexpr unsigned COND_GRID = 64;     // workgroups of a conditional (usually no-op) launch
+
 #ifndef DFH_GEMM_GROUP_M
 #define DFH_GEMM_GROUP_M 8      // row tiles per group of the plain tile order (map_tile)
 #endif
@@ -60,11 +62,18 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int bm, bn;
 };
+// extended launches only (gemm_f64_ext_kernel): a second kernel argument, so that the plain kernels'
+// argument block -- and with it their code -- is what it has always been
+struct GemmExt {
+  const double* cond; double cond_thr;   // skip the whole launch unless *cond > cond_thr (NaN runs)
+  int* la_cnt;                           // look-ahead order (LOWER): {diagonal-block tiles done, block-column tiles done}
+  int la_pad;                            // workgroups reserved for the look-ahead tiles (multiple of 8)
+  int vgrid;                             // tiles (incl. look-ahead padding) the launch walks
+};
 
-__device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
+__device__ __forceinline__ void map_tile(const GemmArgs& p, unsigned b, unsigned nb, int& tm, int& tn) {
   // XCD-aware remap: hardware places block b on XCD b%8; give each XCD a contiguous span of
   // the linear tile order so neighbouring tiles (sharing A/B panels) share one L2.
-  const unsigned nb = gridDim.x, b = blockIdx.x;
   const unsigned q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   if (p.flags & GEMM_LOWER) {
@@ -92,17 +101,41 @@ __device__ __forceinline__ void map_tile(const GemmArgs& p, int& tm, int& tn) {
   }
 }
 
-template <bool TRANSB, bool EDGE, int WT>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+// Look-ahead tile order of the factorisation's trailing update (extended launches, LOWER): the first
+// block column (four tile columns = the next panel) comes first -- workgroup b < la_pad takes tile
+// row 8 (b >> 5) + (b & 7), tile column (b >> 3) & 3, so the four tiles of a row share an XCD (and its
+// L2 copy of the row's A panel) and the sixteen tiles of the next diagonal block are the very first
+// -- and raises the counters in la_cnt when it is done; the remaining tiles are the lower triangle
+// of the (tiles_m - 4)-tile matrix behind it, in the plain row-by-row order with the same
+// XCD-contiguous spans.  Returns false for a padding workgroup.
+__device__ __forceinline__ bool map_tile_lookahead(const GemmArgs& p, int la_pad, unsigned b, unsigned vgrid, int& tm,
+                                                   int& tn, bool& is_la) {
+  if (b < (unsigned)la_pad) {
+    const unsigned xcd = b & 7, idx = b >> 3;
+    const unsigned i = (idx >> 2) * 8 + xcd, j = idx & 3;
+    is_la = true;
+    tm = (int)i; tn = (int)j;
+    return i < (unsigned)p.tiles_m && j <= i;
+  }
+  is_la = false;
+  const unsigned nb = vgrid - (unsigned)la_pad, bb = b - (unsigned)la_pad;
+  const unsigned q = nb >> 3, r = nb & 7, xcd = bb & 7, idx = bb >> 3;
+  const unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  unsigned i = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+  while ((unsigned long long)i * (i + 1) / 2 > lin) --i;
+  while ((unsigned long long)(i + 1) * (i + 2) / 2 <= lin) ++i;
+  tm = (int)i + 4;
+  tn = (int)(lin - (unsigned)((unsigned long long)i * (i + 1) / 2)) + 4;
+  return true;
+}
+
+template <bool TRANSB, bool EDGE, int WT, bool EXT>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tm, int tn, bool is_la, int* la_cnt, double* smem) {
   using G = Geo<WT>;
   constexpr int BM = G::BM, BN = G::BN, BNP = G::BNP, TILE_A = G::TILE_A, TILE_B = G::TILE_B;
   constexpr int WS = WT * 16;                          // wave tile edge
-  extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                  // [2][TILE_A]
   double* Bs = smem + 2 * TILE_A;     // [2][TILE_B]
-
-  int tm, tn;
-  map_tile(p, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -296,22 +329,90 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         if (EDGE && (row >= p.M || col >= p.N)) continue;
         double v = alpha * acc[i][j][r];
         if (!c_in_acc && beta != 0.0) v += beta * Cin[(long)row * p.ldcin + col];
-        Cout[(long)row * p.ldc + col] = v;
+        // a look-ahead tile is handed to the panel kernel of another CU (possibly another XCD): it goes
+        // out with write-through (sc1) stores -- a release fence per tile instead writes back the XCD's
+        // whole L2, full of the other workgroups' freshly written C tiles (496 tiles per launch: the
+        // look-ahead order cost 5 % of the update that way)
+        if (EXT && is_la) __hip_atomic_store(&Cout[(long)row * p.ldc + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else Cout[(long)row * p.ldc + col] = v;
       }
+    }
+  }
+  if (EXT && is_la) {
+    // the tile is out (the barrier waits for every wave's stores): announce it
+    __syncthreads();
+    if (tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tm < 4) __hip_atomic_fetch_add(la_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(la_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
+// Plain launches: one tile per workgroup.  Extended launches (EXT, the factorisation's): a device-side
+// condition decides whether the launch does anything -- such a launch is a small persistent grid
+// walking the tiles (vgrid of them), because even a workgroup that exits at once needs a free 74 KB LDS
+// slot to START: a full-size grid of no-ops would queue behind the trailing update it runs beside;
+// look-ahead launches have one workgroup per tile as usual.
 template <bool TRANSB, bool EDGE, int WT>
-int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
-  static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
-  bool& attr_set = attr_set_dev[ctx->device];
-  auto kern = gemm_f64_kernel<TRANSB, EDGE, WT>;
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // the 64 x 64-tile instantiation serves small, latency-bound products -- the factorisation's chain
+  // among them, whose waves share SIMDs with the trailing update's: they go first
+  if (WT == 2) __builtin_amdgcn_s_setprio(3);
+  int tm, tn;
+  map_tile(p, blockIdx.x, gridDim.x, tm, tn);
+  gemm_tile<TRANSB, EDGE, WT, false>(p, tm, tn, false, nullptr, smem);
+}
+
+// look-ahead order: one tile per workgroup, exactly like the plain kernel but for the tile map and the
+// completion counters (a tile-walking loop around the tile body cost 8 % on its own: 22.2 instead of
+// 20.6 ms over the sixteen largest trailing updates of n = 16384)
+template <bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm_f64_la_kernel(GemmArgs p, GemmExt x) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  int tm, tn;
+  bool is_la = false;
+  if (x.vgrid == -1) {                 // diagnostics: plain order inside this kernel
+    if (blockIdx.x >= gridDim.x - (unsigned)x.la_pad + 0u * 0) { }
+    map_tile(p, blockIdx.x, gridDim.x, tm, tn);
+    if (tm >= p.tiles_m || tn > tm) return;
+  } else {
+    if (!map_tile_lookahead(p, x.la_pad, blockIdx.x, gridDim.x, tm, tn, is_la)) return;
+    if (x.vgrid == -2) is_la = false;  // diagnostics: look-ahead order without the hand-off
+  }
+  // two copies of the tile body: the (few) look-ahead tiles take the one with the hand-off epilogue,
+  // all others exactly the plain kernel's (with the hand-off merely compiled in, every tile was 4 % slower)
+  if (is_la) gemm_tile<false, EDGE, 4, true>(p, tm, tn, true, x.la_cnt, smem);
+  else gemm_tile<false, EDGE, 4, false>(p, tm, tn, false, nullptr, smem);
+}
+
+// conditional launch: a small grid walking the tiles, or nothing at all
+template <bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm_f64_cond_kernel(GemmArgs p, GemmExt x) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const double dv = *x.cond;
+  if (dv <= x.cond_thr) return;                        // (a NaN runs)
+  for (unsigned vb = blockIdx.x; vb < (unsigned)x.vgrid; vb += gridDim.x) {
+    int tm, tn;
+    map_tile(p, vb, (unsigned)x.vgrid, tm, tn);
+    gemm_tile<false, EDGE, 4, false>(p, tm, tn, false, nullptr, smem);
+    __syncthreads();                                   // the LDS images are free for the next tile
+  }
+}
+
+template <bool TRANSB, bool EDGE, int WT, bool EXT = false>
+int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid, const GemmExt* x = nullptr) {
+  static bool attr_set_dev[2][DFH_MAX_DEVICES] = {{false}, {false}};
+  bool& attr_set = attr_set_dev[(EXT && x->la_cnt != nullptr) ? 1 : 0][ctx->device];
+  const bool la = EXT && x->la_cnt != nullptr;
+  const void* kern = !EXT ? reinterpret_cast<const void*>(gemm_f64_kernel<TRANSB, EDGE, WT>)
+                          : (la ? reinterpret_cast<const void*>(gemm_f64_la_kernel<EDGE>)
+                                : reinterpret_cast<const void*>(gemm_f64_cond_kernel<EDGE>));
   constexpr int HALF_OCC_SMEM = 84 * 1024;            // two of these do not fit in 160 KB
   constexpr int MAX_SMEM = (WT == 4) ? HALF_OCC_SMEM : Geo<WT>::SMEM_BYTES;
   if (!attr_set) {
-    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM));
+    DFH_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM));
     attr_set = true;
   }
   // Optional half occupancy (> 80 KB of LDS keeps a second workgroup off the CU): used for bulk
@@ -337,23 +438,49 @@ int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid) {
     const double b_elems = (p.flags & GEMM_KTRI_B) ? 0.5 * (double)p.N * ((double)p.N + 1.0) : (double)p.N * (double)p.K;
     rec->bytes = 8.0 * (double)grid.z * ((double)p.M * (double)p.K + (p.B == p.A ? 0.0 : b_elems) +
                                          c_elems * ((p.Cin != nullptr && p.beta != 0.0) ? 2.0 : 1.0));
-    rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);
+    rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);   // (extended launches count with their plain twin)
+    // diagnostics: DFH_GEMM_PROF_SPLIT_LA=1 books the look-ahead trailing updates under variant 7 (tools/chol_gemm_prof.py)
+    static const bool split_la = getenv("DFH_GEMM_PROF_SPLIT_LA") && atoi(getenv("DFH_GEMM_PROF_SPLIT_LA")) != 0;
+    if (split_la && la) rec->variant = 7;
     DFH_HIP(hipEventRecord(rec->e0, ctx->stream));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->stream, p);
+  if constexpr (EXT) {
+    if (la) hipLaunchKernelGGL(gemm_f64_la_kernel<EDGE>, grid, dim3(256), smem, ctx->stream, p, *x);
+    else hipLaunchKernelGGL(gemm_f64_cond_kernel<EDGE>, grid, dim3(256), smem, ctx->stream, p, *x);
+  } else hipLaunchKernelGGL((gemm_f64_kernel<TRANSB, EDGE, WT>), grid, dim3(256), smem, ctx->stream, p);
   DFH_LAUNCH_CHECK();
   if (rec) DFH_HIP(hipEventRecord(rec->e1, ctx->stream));
   return DFH_OK;
 }
 
 template <int WT>
-int dispatch(dfh_ctx* ctx, GemmArgs& p, int count, bool edge) {
+int dispatch(dfh_ctx* ctx, GemmArgs& p, int count, bool edge, const GemmExt* ext = nullptr) {
   constexpr int BM = Geo<WT>::BM, BN = Geo<WT>::BN;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const long ntiles = (p.flags & GEMM_LOWER) ? (long)p.tiles_m * (p.tiles_m + 1) / 2 : (long)p.tiles_m * p.tiles_n;
   dim3 grid((unsigned)ntiles, 1, (unsigned)count);
   edge = edge || (p.M % BM) || (p.N % BN);
+  if constexpr (WT == 4) {
+    if (ext) {
+      // extended launch (factorisation only): device-side skip condition and / or look-ahead order
+      GemmExt x = *ext;
+      if ((p.flags & GEMM_TRANSB) || count != 1) { dfh_set_error("extended GEMM launch: NT, unbatched only"); return DFH_ERR_BAD_ARG; }
+      if (x.la_cnt) {
+        if (!(p.flags & GEMM_LOWER) || p.tiles_m < 5) { dfh_set_error("look-ahead GEMM order needs a LOWER product of >= 5 tile rows"); return DFH_ERR_BAD_ARG; }
+        x.la_pad = 32 * ((p.tiles_m + 7) / 8);
+        const long rest = (long)(p.tiles_m - 4) * (p.tiles_m - 3) / 2;
+        grid.x = (unsigned)(x.la_pad + rest);
+      }
+      x.vgrid = (int)grid.x;
+      static const int la_debug = getenv("DFH_LA_DEBUG") ? atoi(getenv("DFH_LA_DEBUG")) : 0;
+      if (x.la_cnt && la_debug == 1) { grid.x = (unsigned)ntiles; x.vgrid = -1; }
+      if (x.la_cnt && la_debug == 2) x.vgrid = -2;
+      if (x.cond && x.la_cnt) { dfh_set_error("extended GEMM launch: condition and look-ahead order exclude each other"); return DFH_ERR_BAD_ARG; }
+      if (x.cond && grid.x > COND_GRID) grid.x = COND_GRID;
+      return edge ? launch<false, true, 4, true>(ctx, p, grid, &x) : launch<false, false, 4, true>(ctx, p, grid, &x);
+    }
+  }
   if (p.flags & GEMM_TRANSB)
     return edge ? launch<true, true, WT>(ctx, p, grid) : launch<true, false, WT>(ctx, p, grid);
   return edge ? launch<false, true, WT>(ctx, p, grid) : launch<false, false, WT>(ctx, p, grid);
@@ -553,12 +680,24 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
     p.sA2 = batch->sA2; p.sB2 = batch->sB2; p.sCin2 = batch->sCin2; p.sCout2 = batch->sCout2;
   }
   p.alpha = alpha; p.beta = beta; p.flags = flags;
+  GemmExt ext;
+  ext.cond = ctx->gemm_cond; ext.cond_thr = ctx->gemm_cond_thr; ext.la_cnt = ctx->gemm_la_cnt; ext.la_pad = 0; ext.vgrid = 0;
+  // diagnostics (tools/chol_gemm_prof.py): DFH_GEMM_FORCE_LA=1 sends every eligible LOWER product through the
+  // look-ahead tile order (counters in scratch) so that the extended kernel can be timed on its own
+  static const bool force_la = getenv("DFH_GEMM_FORCE_LA") && atoi(getenv("DFH_GEMM_FORCE_LA")) != 0;
+  if (force_la && !ext.la_cnt && (flags & GEMM_LOWER) && !batch && M >= 5 * 128) {
+    int* dummy = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_RED, 64, (void**)&dummy));
+    ext.la_cnt = dummy;
+  }
+  const bool use_ext = ext.cond != nullptr || ext.la_cnt != nullptr;
   auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool edge = (K % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B) ||
                     ((p.sA | p.sB | p.sA2 | p.sB2) & 1);
   // Small problems are latency-bound on a single 128x128 tile per CU: use 64x64 tiles when the
   // 128-tiling would leave most of the 256 CUs idle.
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * (long)count;
+  if (use_ext) return dispatch<4>(ctx, p, count, edge, &ext);
   if (t128 < 192) return dispatch<2>(ctx, p, count, edge);
   // Tuning knob (tools/gemm_rows.py): cut a tall product into launches of this many rows.  Measured
   // on the posterior shape 262144 x 512 x 8192: L2 misses fall from 1.9x to 1.5x the operand bytes

@@ -71,6 +71,7 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     DFH_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
     DFH_HIP(hipStreamCreateWithPriority(&ctx->bulk, hipStreamNonBlocking, least));
     DFH_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    DFH_HIP(hipStreamCreateWithFlags(&ctx->bulk_normal, hipStreamNonBlocking));
   }
   DFH_HIP(hipEventCreate(&ctx->ev0));
   DFH_HIP(hipEventCreate(&ctx->ev1));
@@ -79,9 +80,9 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     DFH_HIP(hipEventCreate(&ctx->tev1[i]));
   }
   ctx->scratch.resize(SCR_COUNT);
-  DFH_HIP(hipMalloc(&ctx->d_info, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
-  DFH_HIP(hipMemset(ctx->d_info, 0, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
-  DFH_HIP(hipHostMalloc(&ctx->h_info, (CHOL_MAX_BATCH + 8) * sizeof(int64_t)));
+  DFH_HIP(hipMalloc(&ctx->d_info, (CHOL_MAX_BATCH + 16) * sizeof(int64_t)));
+  DFH_HIP(hipMemset(ctx->d_info, 0, (CHOL_MAX_BATCH + 16) * sizeof(int64_t)));
+  DFH_HIP(hipHostMalloc(&ctx->h_info, (CHOL_MAX_BATCH + 16) * sizeof(int64_t)));
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live_ctx.insert(ctx);
@@ -116,6 +117,7 @@ extern "C" void dfh_ctx_destroy(dfh_ctx* ctx) {
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->bulk) (void)hipStreamDestroy(ctx->bulk);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+  if (ctx->bulk_normal) (void)hipStreamDestroy(ctx->bulk_normal);
   (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
 }

@@ -23,6 +23,17 @@ VARIANTS = {
   'fused-panels-single-only': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_FUSED_MAX_BATCH': '1'},
   'fused-panels+paired': {'DFH_CHOL_FUSED': '1', 'DFH_CHOL_PAIR_MIN_REM': '0'},
   'pivot-steps-only': {'DFH_CHOL_FUSED': '0', 'DFH_CHOL_STRIPS': '0', 'DFH_CHOL_PAIR': '0'},
+  # round 3: the resident look-ahead schedule (diagonal block resident before the trailing update starts,
+  # rows below by GEMM with the block inverse) from the second panel row on instead of above 7680 rows
+  'resident-lookahead-everywhere': {'DFH_CHOL_LR_MIN_REM': '640'},
+  'resident-lookahead+every-refinement-step': {'DFH_CHOL_LR_MIN_REM': '640', 'DFH_REFINE_TOL': '0'},
+  'no-resident-lookahead': {'DFH_CHOL_LR': '0'},
+  # more refinement steps due than the resident panels run on the device: second attempt by substitution
+  'resident-lookahead-abandoned': {'DFH_CHOL_LR_MIN_REM': '640', 'DFH_REFINE_FORCE_STEPS': '5'},
+  # every inter-workgroup wait expires at once: the status word sends the host to the schedule without hand-offs
+  'forced-handoff-timeout': {'DFH_TEST_SPIN_LIMIT': '0'},
+  'forced-handoff-timeout+resident': {'DFH_TEST_SPIN_LIMIT': '0', 'DFH_CHOL_LR_MIN_REM': '640'},
+  'no-handoffs': {'DFH_CHOL_SAFE': '1'},
 }
 
 

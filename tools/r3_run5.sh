@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out
+L=gpurun_out/r3_run5.log
+: > $L
+for env in "DFH_CHOL_LR=0" "DFH_CHOL_LR=1" "DFH_CHOL_LR_MIN_REM=9728" "DFH_CHOL_LR_MIN_REM=5632" "DFH_CHOL_LR_MIN_REM=3584"; do
+  echo "== n=16384 $env" >> $L
+  env $env timeout 300 python tools/time_chol.py 16384 >> $L 2>&1
+done
+bash tools/r3_trace.sh lr1 16384 DFH_CHOL_LR=1 >> $L 2>&1
+grep -v "^W2026\|^E2026" $L | tail -60

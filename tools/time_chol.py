@@ -12,7 +12,7 @@ Xd, yd = eng.to_device(X), eng.to_device(Y - np.median(Y))
 noise = float(Y.var() / 20)
 eng.gp_fit(spec, Xd, yd, noise).free()
 ts = []
-for _ in range(6):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
   eng.timings(True)
   gp = eng.gp_fit(spec, Xd, yd, noise)
   t = eng.timings(False)
