@@ -39,6 +39,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 import bench_configs as BC      # noqa: E402  pylint: disable=wrong-import-position
+import bench_extras as BX       # noqa: E402  pylint: disable=wrong-import-position
 
 N_TRAIN, DIM, TS_BLOCK, CANDS_PER_GPU = BC.N_TRAIN, BC.DIM, BC.TS_BLOCK, BC.CANDS_PER_GPU
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak: 256 CU x 128 flop/clk x 2.4 GHz
@@ -57,9 +58,9 @@ class InProcess(object):
   """ one process, N devices: parallel.MultiEngine (dfh_mgpu_*) """
   mode = 'one process, in-library fan-out (dfh_mgpu_*: host thread + context per device, ncclCommInitAll)'
 
-  def __init__(self, n_gpus, prob, spec):
+  def __init__(self, n_gpus, prob, spec, cpg):
     from dragonfly_amd import parallel
-    self.world, self.rank = n_gpus, 0
+    self.world, self.rank, self.cpg = n_gpus, 0, cpg
     self.mg = parallel.MultiEngine(n_gpus)        # raises if fewer GPUs are visible
     self.eng0 = self.mg.engines[0]
     self.spec, self.prob = spec, prob
@@ -67,7 +68,7 @@ class InProcess(object):
     self.yd = [e.to_device(prob['Y'] - prob['mean_c']) for e in self.mg.engines]
     self.cd, self.ud = [], []
     for r, e in enumerate(self.mg.engines):
-      cands, U = BC.config4_shard(r)
+      cands, U = BC.config4_rows(r * cpg, (r + 1) * cpg)
       if r == 0:
         self.cands0, self.U0 = cands, U
       self.cd.append(e.to_device(cands))
@@ -94,10 +95,10 @@ class PerProcess(object):
   """ one process per GPU (launcher): Engine + parallel.RcclComm (dfh_comm_*) """
   mode = 'one process per GPU (launcher env), dfh_comm_*: ncclGetUniqueId by file rendezvous, ncclCommInitRank'
 
-  def __init__(self, n_gpus, prob, spec):
+  def __init__(self, n_gpus, prob, spec, cpg):
     from dragonfly_amd import parallel
     from dragonfly_amd.engine import Engine
-    self.world = n_gpus
+    self.world, self.cpg = n_gpus, cpg
     self.rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
     self.eng0 = Engine(local_rank)
@@ -105,14 +106,14 @@ class PerProcess(object):
     self.spec, self.prob = spec, prob
     self.Xd = self.eng0.to_device(prob['X'])
     self.yd = self.eng0.to_device(prob['Y'] - prob['mean_c'])
-    self.cands0, self.U0 = BC.config4_shard(self.rank)
+    self.cands0, self.U0 = BC.config4_rows(self.rank * cpg, (self.rank + 1) * cpg)
     self.cd, self.ud = self.eng0.to_device(self.cands0), self.eng0.to_device(self.U0)
     self.result = {}
 
   def step(self):
     gp = self.eng0.gp_fit(self.spec, self.Xd, self.yd, self.prob['noise'])
     v, i = gp.thompson(self.cd, self.ud, block=TS_BLOCK, mean_const=self.prob['mean_c'])
-    v, i = self.comm.allgather_argmax(v, i + self.rank * CANDS_PER_GPU)
+    v, i = self.comm.allgather_argmax(v, i + self.rank * self.cpg)
     self.result.update(lml=gp.lml, best=v, idx=i)
     gp.free()
 
@@ -181,7 +182,7 @@ def oracle_stages(O, kern, X, Y, mean_c, noise, cand_blocks, U_blocks):
   return t, out
 
 
-def cpu_baseline_and_parity(prob, cands0, U0, eng, spec):
+def cpu_baseline_and_parity(prob, cands0, U0, eng, spec, cpg=CANDS_PER_GPU):
   """ cpu_baseline: the oracle on this host's cores -- the FULL n = 16384 fit once and three full
       Thompson blocks of 4096 candidates (median block time x 64 blocks; the blocks are
       independent and identical in work).  parity_vs_oracle: the device on the same inputs. """
@@ -197,7 +198,7 @@ def cpu_baseline_and_parity(prob, cands0, U0, eng, spec):
   measured_s = time.perf_counter() - t_all0
   fit_s = t['kernel'] + t['chol'] + t['solve']
   block_s = sorted(sum(tb.values()) for tb in t['blocks'])
-  n_blocks = CANDS_PER_GPU // TS_BLOCK
+  n_blocks = cpg // TS_BLOCK
   full_ms = (fit_s + n_blocks * block_s[len(block_s) // 2]) * 1e3
   # one BLAS thread: a smaller sample (the full step would take ~an hour), scaled by algorithmic work
   single = None
@@ -349,6 +350,9 @@ def main():
   ap.add_argument('--warmup', type=int, default=1)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
+  ap.add_argument('--no-c4-full', action='store_true', help='skip the untimed 2 097 152-candidate single-GPU extra (~35 s)')
+  ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                  help='weak: 262144 candidates per GPU (default); strong: the 2 097 152 candidates of config 4 split over the GPUs')
   args = ap.parse_args()
 
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes)
@@ -362,7 +366,10 @@ def main():
   # DFH_BENCH_PER_PROCESS=1: take the process-per-GPU route even with one process (exercises
   # ncclGetUniqueId / file rendezvous / ncclCommInitRank on a one-GPU box)
   per_process = world_env > 1 or os.environ.get('DFH_BENCH_PER_PROCESS', '0') == '1'
-  runner = (PerProcess if per_process else InProcess)(args.gpus, prob, spec)
+  if args.scaling == 'strong' and (BC.CANDS_TOTAL_8 % (args.gpus * TS_BLOCK)) != 0:
+    raise SystemExit('bench.py: --scaling strong needs --gpus to divide %d' % (BC.CANDS_TOTAL_8 // TS_BLOCK))
+  cpg = CANDS_PER_GPU if args.scaling == 'weak' else BC.CANDS_TOTAL_8 // args.gpus
+  runner = (PerProcess if per_process else InProcess)(args.gpus, prob, spec, cpg)
   rank, world, eng = runner.rank, runner.world, runner.eng0
 
   for _ in range(args.warmup):
@@ -398,17 +405,17 @@ def main():
       'metric': 'GP-fit+acq-batch ms at n=16384,d=32',
       'value': round(ms_per_step, 3), 'unit': 'ms', 'n_gpus': world, 'steps': args.steps,
       'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': False,
-      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+      'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
       'config': {'workload': ('C3 fit (n=16384, d=32, SE-ARD: kernel matrix + Cholesky + alpha + lml) '
-                              '+ C4 shard: blocked-joint Thompson sampling, block 4096, over 262144 '
-                              'candidates per GPU with arg-max'),
-                 'n': N_TRAIN, 'd': DIM, 'candidates_per_gpu': CANDS_PER_GPU,
-                 'candidates_total': CANDS_PER_GPU * world, 'ts_block': TS_BLOCK,
-                 'candidate_rows': 'rank r: rows [r*262144, (r+1)*262144) of RandomState(204).random_sample((2097152, 32)), '
-                                   'normals RandomState(304).standard_normal(2097152)',
+                              '+ C4 %s: blocked-joint Thompson sampling, block 4096, over %d '
+                              'candidates per GPU with arg-max' % ('shard' if args.scaling == 'weak' else 'whole, split over the GPUs', cpg)),
+                 'n': N_TRAIN, 'd': DIM, 'candidates_per_gpu': cpg,
+                 'candidates_total': cpg * world, 'ts_block': TS_BLOCK,
+                 'candidate_rows': 'rank r: rows [r*%d, (r+1)*%d) of RandomState(204).random_sample((2097152, 32)), '
+                                   'normals RandomState(304).standard_normal(2097152)' % (cpg, cpg),
                  'parallelism': 'candidate shards x%d, replicated fit, RCCL all-gather of (val,idx)' % world,
                  'launch': runner.mode},
-      'candidates_per_s': round(CANDS_PER_GPU * world / (ms_per_step * 1e-3), 1),
+      'candidates_per_s': round(cpg * world / (ms_per_step * 1e-3), 1),
       'sections_ms_extra_untimed_step_rank0': {k: round(v, 3) for k, v in sections.items() if v > 0},
       'result': {'lml': result['lml'], 'ts_best': result['best'], 'ts_argmax': int(result['idx'])},
       'roofline': {
@@ -486,8 +493,11 @@ def main():
       nb.free()
       out['candidate_generation_untimed_rank0'] = gen
       out['configs'] = other_configs(eng)
+      # round 3: config 1 through the mirrors, the tuning / append / tree-search workloads and the whole of
+      # config 4 on one GPU -- each with the oracle beside it and an equality / parity flag (bench_extras.py)
+      out['configs'].update(BX.run_all(eng, prob, spec, include_c4_full=not args.no_c4_full))
     if not args.no_cpu_baseline and world == 1:
-      out['cpu_baseline'], out['parity_vs_oracle'] = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec)
+      out['cpu_baseline'], out['parity_vs_oracle'] = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec, cpg)
     elif not args.no_cpu_baseline:
       out['cpu_baseline'] = None
   runner.close()

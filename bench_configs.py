@@ -51,6 +51,14 @@ def config3_candidates(m=65536):
   return np.random.RandomState(203).random_sample((m, DIM))
 
 
+def config4_rows(lo, hi):
+  """ Rows [lo, hi) of the ONE seed-204 candidate set (2 097 152 x 32) and of the seed-304 standard
+      normals -- what a single process drawing the whole set would hold in those rows. """
+  cands = np.random.RandomState(204).random_sample((hi, DIM))[lo:]
+  U = np.random.RandomState(304).standard_normal(hi)[lo:]
+  return np.ascontiguousarray(cands), np.ascontiguousarray(U)
+
+
 def config4_shard(rank, world=None):
   """ Rank's rows [rank*262144, (rank+1)*262144) of the ONE seed-204 candidate set
       (2 097 152 x 32) and of the seed-304 standard normals: the N-GPU run evaluates the first

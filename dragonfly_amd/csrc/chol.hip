@@ -1403,6 +1403,8 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
           ctx->gemm_cond = nullptr;
           DFH_TRY(rc_r);
         }
+        static const bool lr_inplace = env_int("DFH_CHOL_LR_INPLACE", 0) != 0;     // ablation: operands of the update in place
+        if (lr_inplace) DFH_TRY(copy_matrix(ctx, Xk, NB, A21, lda, rem, NB));
         DFH_HIP(hipEventRecord(e_panel, Pc));
       }
       {
@@ -1421,7 +1423,10 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
       {
         double* C = A + (k0 + NB) * lda + (k0 + NB);
         ctx->gemm_la_cnt = next_resident ? sy + 1 : nullptr;
-        const int rc_u = gemm_f64(ctx, GEMM_LOWER, rem, rem, NB, -1.0, Xk, NB, Xk, NB, 1.0, C, lda, C, lda);
+        static const bool lr_inplace_u = env_int("DFH_CHOL_LR_INPLACE", 0) != 0;
+        const double* Uop = lr_inplace_u ? A21 : Xk;
+        const int64_t ldu = lr_inplace_u ? lda : NB;
+        const int rc_u = gemm_f64(ctx, GEMM_LOWER, rem, rem, NB, -1.0, Uop, ldu, Uop, ldu, 1.0, C, lda, C, lda);
         ctx->gemm_la_cnt = nullptr;
         DFH_TRY(rc_u);
       }

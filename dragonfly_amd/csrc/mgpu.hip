@@ -295,6 +295,7 @@ extern "C" int dfh_comm_barrier(dfh_comm* c) {
 // ---------------------------------------------------------------------------------------------
 struct dfh_mgpu {
   int n = 0;
+  bool host_exchange = false;   // test mode (DFH_MGPU_ALLOW_DUPLICATE_DEVICES): no communicator, pairs reduced on the host
   std::vector<int> devices;
   std::vector<dfh_ctx*> ctxs;
   std::vector<dfh_comm*> comms;
@@ -314,12 +315,21 @@ extern "C" int dfh_mgpu_create(int n_devices, const int* device_ids, dfh_mgpu** 
   *out = nullptr;
   int visible = 0;
   DFH_HIP(hipGetDeviceCount(&visible));
-  if (n_devices > visible) {
+  // Test switch (tests/test_gpu_mgpu.py): with DFH_MGPU_ALLOW_DUPLICATE_DEVICES=1 a device id may be
+  // given several times -- N contexts and N host threads on ONE device, driven concurrently through
+  // the same fan-out as N devices.  RCCL refuses duplicate devices in a communicator, so the 16-byte
+  // pairs are then reduced on the host (the same reduce every rank applies to the gathered pairs).
+  const char* dup_env = getenv("DFH_MGPU_ALLOW_DUPLICATE_DEVICES");
+  bool duplicates = false;
+  if (dup_env && atoi(dup_env) != 0 && device_ids)
+    for (int r = 0; r < n_devices; ++r)
+      for (int q = 0; q < r; ++q) duplicates = duplicates || device_ids[q] == device_ids[r];
+  if (!duplicates && n_devices > visible) {
     dfh_set_error("dfh_mgpu_create: %d devices requested, %d visible", n_devices, visible);
     return DFH_ERR_BAD_ARG;
   }
   const RcclApi* api = nullptr;
-  {
+  if (!duplicates) {
     // one device has nobody to exchange with: RCCL is used when it is there (the same code path as
     // N devices), but its absence is not an error
     const int rc = rccl_load(&api);
@@ -328,10 +338,12 @@ extern "C" int dfh_mgpu_create(int n_devices, const int* device_ids, dfh_mgpu** 
   }
   dfh_mgpu* mg = new dfh_mgpu();
   mg->n = n_devices;
+  mg->host_exchange = duplicates;
   auto body = [&]() -> int {
     for (int r = 0; r < n_devices; ++r) {
       const int dev = device_ids ? device_ids[r] : r;
-      for (int q = 0; q < r; ++q) DFH_ARG(mg->devices[q] != dev);     // one rank per device
+      DFH_ARG(dev >= 0 && dev < visible);
+      if (!duplicates) for (int q = 0; q < r; ++q) DFH_ARG(mg->devices[q] != dev);     // one rank per device
       mg->devices.push_back(dev);
       dfh_ctx* ctx = nullptr;
       DFH_TRY(dfh_ctx_create(dev, &ctx));
@@ -402,9 +414,9 @@ int fan_out(dfh_mgpu* mg, Fn fn) {
 // checking that the others hold the same
 int exchange(dfh_mgpu* mg, const std::vector<double>& vals, const std::vector<int64_t>& idxs, double* best_val,
              int64_t* best_idx) {
-  if (mg->comms.empty()) {                    // single device, RCCL not installed: the reduce alone
-    DFH_ARG(mg->n == 1);
-    return dfh_reduce_argmax(vals.data(), idxs.data(), 1, best_val, best_idx);
+  if (mg->comms.empty()) {                    // single device without RCCL, or the duplicate-device test mode: the reduce alone
+    DFH_ARG(mg->n == 1 || mg->host_exchange);
+    return dfh_reduce_argmax(vals.data(), idxs.data(), mg->n, best_val, best_idx);
   }
   const RcclApi* api = mg->comms[0]->api;
   DFH_NCCL(api, api->GroupStart());

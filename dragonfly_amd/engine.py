@@ -69,7 +69,23 @@ class DeviceArray(object):
     """ A raw pointer n_elems doubles into the buffer (no ownership). """
     return C.c_void_p(self.ptr.value + 8 * int(n_elems))
 
+  def view(self, start, shape):
+    """ A DeviceArray over the elements [start, start + prod(shape)) of this buffer: no copy, no
+        ownership (it keeps this buffer alive; free() on the view does nothing). """
+    v = DeviceArray.__new__(DeviceArray)
+    v.engine = self.engine
+    v.shape = tuple(int(x) for x in np.atleast_1d(shape))
+    v.size = int(np.prod(v.shape))
+    assert 0 <= int(start) and int(start) + v.size <= self.size
+    v.ptr = self.offset(start)
+    v._owner = self
+    return v
+
   def free(self):
+    if getattr(self, '_owner', None) is not None:      # a view
+      self.ptr = None
+      self._owner = None
+      return
     if self.ptr is not None and self.engine.ctx is not None:
       self.engine.lib.dfh_free(self.engine.ctx, self.ptr)
     self.ptr = None

@@ -110,3 +110,51 @@ def test_process_per_gpu_communicator_single_rank(engine, monkeypatch, tmp_path)
   finally:
     comm.close()
   assert not list(tmp_path.iterdir())       # rank 0 removed the rendezvous file
+
+
+@pytest.mark.parametrize('nranks', [2, 4, 8])
+def test_mgpu_concurrent_contexts_on_one_device(engine, nranks, monkeypatch):
+  """ N contexts and N host threads driven CONCURRENTLY through dfh_mgpu_fit / _ts / _acq_argmax on the
+      one device of the box (library test switch; the 16-byte pairs are reduced on the host because
+      RCCL refuses duplicate devices): what would first show up on an 8-GPU node -- races in the
+      per-context pools, per-device function attributes, thread-local error state, the one-launch
+      panels' flag hand-offs with several launches in flight -- has to show up here.  Results are
+      those of the unsharded single-context calls, bit for bit, every time. """
+  monkeypatch.setenv('DFH_MGPU_ALLOW_DUPLICATE_DEVICES', '1')
+  n, d, B = 2500, 6, 256
+  m = nranks * 1536 - 5 * B + 77                          # ragged: the last shard is short
+  X, yc, mean_c, noise, spec, cands, U = _problem(n=n, d=d, m=m, seed=40 + nranks)
+  gp = engine.gp_fit(spec, X, yc, noise)
+  want_ts = gp.thompson(cands, U, block=B, mean_const=mean_c)
+  best = float(yc.max() + mean_c)
+  want_ei = gp.acq_argmax('ei', cands, params=(best, 0.0), mean_const=mean_c)
+  want_ucb = gp.acq_argmax('ucb', cands, params=(2.0, 0.0), mean_const=mean_c)
+  bounds = [parallel.shard_bounds(m, r, nranks, align=B) for r in range(nranks)]
+  mg = parallel.MultiEngine(nranks, device_ids=[0] * nranks)
+  try:
+    cs = [cands[lo:hi] for lo, hi in bounds]
+    us = [U[lo:hi] for lo, hi in bounds]
+    for rep in range(3):
+      lml = mg.fit(spec, X, yc, noise)
+      assert lml == [gp.lml] * nranks, rep
+      got = mg.thompson(cs, us, block=B, mean_const=mean_c, return_local=True)
+      assert got[:2] == want_ts, rep
+      # every rank's local winner is what a single context finds on that shard
+      if rep == 0:
+        for r, (lo, hi) in enumerate(bounds):
+          if hi > lo:
+            v, i = gp.thompson(cands[lo:hi], U[lo:hi], block=B, mean_const=mean_c)
+            assert got[2][r] == (v, i + lo), r
+      assert mg.acq_argmax('ei', cs, params=(best, 0.0), mean_const=mean_c) == want_ei, rep
+      assert mg.acq_argmax('ucb', cs, params=(2.0, 0.0), mean_const=mean_c) == want_ucb, rep
+    # shards resident in each context's memory, a smaller second fit replacing the first
+    cd = [e.to_device(c) for e, c in zip(mg.engines, cs)]
+    ud = [e.to_device(u) for e, u in zip(mg.engines, us)]
+    assert mg.thompson(cd, ud, block=B, mean_const=mean_c) == want_ts
+    mg.fit(spec, X[:900], yc[:900], noise)
+    g2 = engine.gp_fit(spec, X[:900], yc[:900], noise)
+    assert mg.thompson(cd, ud, block=B, mean_const=mean_c) == g2.thompson(cands, U, block=B, mean_const=mean_c)
+    for a in cd + ud:
+      a.free()
+  finally:
+    mg.close()
