@@ -373,14 +373,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_la_kernel(GemmArgs p, GemmExt
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int tm, tn;
   bool is_la = false;
-  if (x.vgrid == -1) {                 // diagnostics: plain order inside this kernel
-    if (blockIdx.x >= gridDim.x - (unsigned)x.la_pad + 0u * 0) { }
-    map_tile(p, blockIdx.x, gridDim.x, tm, tn);
-    if (tm >= p.tiles_m || tn > tm) return;
-  } else {
-    if (!map_tile_lookahead(p, x.la_pad, blockIdx.x, gridDim.x, tm, tn, is_la)) return;
-    if (x.vgrid == -2) is_la = false;  // diagnostics: look-ahead order without the hand-off
-  }
+  if (!map_tile_lookahead(p, x.la_pad, blockIdx.x, gridDim.x, tm, tn, is_la)) return;
   // two copies of the tile body: the (few) look-ahead tiles take the one with the hand-off epilogue,
   // all others exactly the plain kernel's (with the hand-off merely compiled in, every tile was 4 % slower)
   if (is_la) gemm_tile<false, EDGE, 4, true>(p, tm, tn, true, x.la_cnt, smem);
@@ -473,9 +466,6 @@ int dispatch(dfh_ctx* ctx, GemmArgs& p, int count, bool edge, const GemmExt* ext
         grid.x = (unsigned)(x.la_pad + rest);
       }
       x.vgrid = (int)grid.x;
-      static const int la_debug = getenv("DFH_LA_DEBUG") ? atoi(getenv("DFH_LA_DEBUG")) : 0;
-      if (x.la_cnt && la_debug == 1) { grid.x = (unsigned)ntiles; x.vgrid = -1; }
-      if (x.la_cnt && la_debug == 2) x.vgrid = -2;
       if (x.cond && x.la_cnt) { dfh_set_error("extended GEMM launch: condition and look-ahead order exclude each other"); return DFH_ERR_BAD_ARG; }
       if (x.cond && grid.x > COND_GRID) grid.x = COND_GRID;
       return edge ? launch<false, true, 4, true>(ctx, p, grid, &x) : launch<false, false, 4, true>(ctx, p, grid, &x);

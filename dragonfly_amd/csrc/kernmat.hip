@@ -684,6 +684,47 @@ __global__ void k_pack_norms(const double* __restrict__ Xp, long n, int P, int n
   Np[row * n_parts_total + part] = np_sumsq(Xp + row * P + pd.poff, nreal);
 }
 
+// Both passes in one launch (round 3: the Gram-matrix section of a fit is packing + norms + the Gram
+// kernel, and at n = 16384 the two packing launches with the gaps around them were 3 - 4 % of it): a
+// workgroup scales R rows, coalesced as k_pack_cols does, keeps the packed values in LDS and takes the
+// norms from there -- the same operations in the same order, so Xp / Np are bit for bit what the two
+// kernels above produce.
+__global__ __launch_bounds__(256) void k_pack_fused(const double* __restrict__ X, long n, long ldx, int P, int c_lo, int c_hi,
+                                                    const int* __restrict__ cols, const int* __restrict__ cols_all,
+                                                    const double* __restrict__ bw, const PartDev* __restrict__ parts,
+                                                    int part_lo, int part_hi, int n_parts_total, int R,
+                                                    double* __restrict__ Xp, double* __restrict__ Np, long sBlob,
+                                                    long sXp, long sNp) {
+  extern __shared__ double pk[];               // [R][w]
+  cols = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cols) + (long)blockIdx.y * sBlob);
+  cols_all = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cols_all) + (long)blockIdx.y * sBlob);
+  bw = reinterpret_cast<const double*>(reinterpret_cast<const char*>(bw) + (long)blockIdx.y * sBlob);
+  parts = reinterpret_cast<const PartDev*>(reinterpret_cast<const char*>(parts) + (long)blockIdx.y * sBlob);
+  Xp += (long)blockIdx.y * sXp;
+  Np += (long)blockIdx.y * sNp;
+  const int w = c_hi - c_lo;
+  const long r0 = (long)blockIdx.x * R;
+  const int rows = (int)((n - r0 < R) ? n - r0 : R);
+  for (int idx = threadIdx.x; idx < rows * w; idx += blockDim.x) {
+    const int lr = idx / w, pc = c_lo + (idx - lr * w);
+    const long row = r0 + lr;
+    const int c = cols[pc];
+    const double b = bw[pc];
+    const double v = c >= 0 ? (b < 0.0 ? X[row * ldx + c] * -b : X[row * ldx + c] / b) : 0.0;    // as k_pack_cols
+    Xp[row * P + pc] = v;
+    pk[idx] = v;
+  }
+  __syncthreads();
+  const int np = part_hi - part_lo;
+  for (int idx = threadIdx.x; idx < rows * np; idx += blockDim.x) {
+    const int lr = idx / np, part = part_lo + (idx - lr * np);
+    const PartDev pd = parts[part];
+    int nreal = 0;
+    for (int c = 0; c < pd.kc; ++c) nreal += cols_all[pd.poff + c] >= 0;   // padding is trailing
+    Np[(r0 + lr) * n_parts_total + part] = np_sumsq(pk + lr * w + (pd.poff - c_lo), nreal);          // as k_pack_norms
+  }
+}
+
 double factorial_d(int n) {
   double r = 1.0;
   for (int i = 2; i <= n; ++i) r *= (double)i;
@@ -1282,6 +1323,18 @@ int pack_scaled(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool 
   DFH_ARG(!pre_gathered || part_hi == part_lo + 1);
   const int c_lo = kd.parts[part_lo].poff;
   const int c_hi = kd.parts[part_hi - 1].poff + kd.parts[part_hi - 1].kc;
+  static const bool fused_pack = getenv("DFH_PACK_FUSED") ? atoi(getenv("DFH_PACK_FUSED")) != 0 : true;
+  if (fused_pack && c_hi - c_lo <= 2048) {
+    const int w = c_hi - c_lo;
+    int R = 4096 / w;                          // <= 32 KB of LDS
+    R = R < 1 ? 1 : (R > 64 ? 64 : R);
+    hipLaunchKernelGGL(k_pack_fused, dim3((unsigned)((n + R - 1) / R), (unsigned)count), dim3(256), (size_t)R * w * 8,
+                       ctx->stream, X, (long)n, (long)ldx, kd.P, c_lo, c_hi, pre_gathered ? kd.d_lcols : kd.d_cols,
+                       kd.d_cols, kd.d_bw, kd.d_parts, part_lo, part_hi, kd.n_parts, R, Xp, Np, (long)sBlob, (long)sXp,
+                       (long)sNp);
+    DFH_LAUNCH_CHECK();
+    return DFH_OK;
+  }
   const int64_t total = n * (c_hi - c_lo);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -4,11 +4,12 @@
 
 Every GP the fitter builds, and every log-marginal-likelihood it evaluates while tuning
 hyper-parameters, is one dfh_gp_fit call on the MI355X (the training inputs are uploaded once per
-fitter and stay in HBM: SURVEY.md section 8f item 1).  Hyper-parameter *search* strategies that
-are serial host-side tree searches / MCMC in the reference (DIRECT, PDOO, slice / NUTS posterior
-sampling: out of scope) are available only when this package
-is installed under a real Dragonfly (dragonfly_amd.install); stand-alone the fitter offers the
-two data-parallel strategies of the reference, 'rand' and 'rand_exp_sampling'.
+fitter and stay in HBM: SURVEY.md section 8f item 1).  Stand-alone the fitter offers the
+reference's maximum-likelihood strategies ('rand', 'rand_exp_sampling', the tree searches) and its
+posterior sampling of the hyper-parameters ('post_sampling' with the slice sampler,
+dragonfly_amd/hp_sampling.py) -- the bandit's default criterion is 'ml-post_sampling'
+(opt/gp_bandit.py:51); only NUTS, which needs the gradient of the marginal likelihood, is left to
+dragonfly_amd.install under a real Dragonfly.
 """
 from argparse import Namespace
 from itertools import product as itertools_product
@@ -22,6 +23,7 @@ from .gp_core import GP, ConstantMean
 from .kernel import _as_2d_array
 from .doo import pdoo_maximise_batched
 from .oper_utils import random_maximise, random_sample_cts_dscr
+from .hp_sampling import PosteriorHPSampler
 from .option_handler import get_option_specs, load_options
 
 _DFLT_KERNEL_TYPE = 'matern'
@@ -254,16 +256,18 @@ class EuclideanGPFitter(object):
     for method in self.methods_to_use:
       if method not in ['ml', 'post_sampling', 'post_mean']:
         raise ValueError('hp_tune_criterion should be ml or post_sampling.')
-      if method != 'ml':
-        raise NotImplementedError(
-            'hp_tune_criterion=%s is a serial host-side MCMC in the reference and is not part of '
-            'the device engine; use dragonfly_amd.install under Dragonfly for it.' % (method))
-    # probabilities of the tuning methods (gp_core.py:365-378); stand-alone only 'ml' exists, so the
-    # 'adaptive' weights never move -- but the draw in get_next_gp still consumes one uniform
+      if method == 'post_mean':
+        raise NotImplementedError('Not implemented post_mean yet.')        # gp_core.py:497-499: neither has the reference
+    # probabilities of the tuning methods (gp_core.py:358-378, 380-392)
+    self.methods_to_use_counter = {key: 0 for key in self.methods_to_use}
     probs = self.options.hp_tune_probs
     n_methods = len(self.methods_to_use)
-    if probs in ('uniform', 'adaptive'):
+    if probs == 'uniform':
       self.hp_tune_probs = np.ones(n_methods) / float(n_methods)
+    elif probs == 'adaptive':
+      self.hp_tune_uniform_sampling_prob = 0.05
+      self.hp_tune_sampling_weights = {key: 1.0 for key in self.methods_to_use}
+      self.hp_tune_probs = self._get_adaptive_hp_tune_probs()
     else:
       self.hp_tune_probs = np.array([float(x) for x in probs.split('-')])
       if len(self.hp_tune_probs) != n_methods:
@@ -272,6 +276,23 @@ class EuclideanGPFitter(object):
     self.cts_hp_bounds = np.array(self.cts_hp_bounds)
     self.num_hps = len(self.cts_hp_bounds) + len(self.dscr_hp_vals)
     self._set_up_ml_hp_tune()
+    if 'post_sampling' in self.methods_to_use and self.options.post_hp_tune_method not in ('slice', 'nuts'):
+      raise ValueError('Unknown post_hp_tune_method %s.' % (self.options.post_hp_tune_method))
+
+  def _get_adaptive_hp_tune_probs(self):
+    """ gp_core.py:380-392: a uniform floor plus weights ~ successes / sqrt(1 + uses) """
+    n_methods = len(self.methods_to_use)
+    floor = self.hp_tune_uniform_sampling_prob * np.ones((n_methods,)) / n_methods
+    successes = np.array([self.hp_tune_sampling_weights[key] for key in self.methods_to_use])
+    uses = np.array([self.methods_to_use_counter[key] for key in self.methods_to_use])
+    weights = successes / np.sqrt(1 + uses)
+    ret = floor + (1 - self.hp_tune_uniform_sampling_prob) * weights / weights.sum()
+    return ret / ret.sum()
+
+  def update_hp_tune_method_weight(self, method, weight_to_add=1):
+    """ gp_core.py:743-746 """
+    if self.options.hp_tune_probs == 'adaptive':
+      self.hp_tune_sampling_weights[method] += weight_to_add
 
   def _set_up_mean_and_noise_variance_bounds(self):
     """ gp_core.py:393-416 """
@@ -494,14 +515,55 @@ class EuclideanGPFitter(object):
     opt_cts_val, opt_cts_hps, _ = self.cts_hp_optimise(cts_tuning_obj, self.hp_tune_max_evals)
     return opt_cts_val, opt_cts_hps, None
 
+  def lml_batch(self, cts_hps_list, dscr_hps_list, other_gp_params=None):
+    """ what dragonfly_amd.hp_sampling asks of a fitter: the log marginal likelihoods of a list of
+        (continuous, discrete) hyper-parameter candidates, one device call """
+    return self._tuning_objective_batch(cts_hps_list, dscr_hps_list, other_gp_params)
+
+  def _sample_cts_dscr_hps_for_post_sampling(self, num_samples):
+    """ gp_core.py:592-726 """
+    additive = self.options.use_additive_gp
+    sampler = PosteriorHPSampler(self, add_dim=self.dim if additive else None,
+                                 add_max_group_size=self.add_max_group_size if additive else None)
+    return sampler.sample(num_samples)
+
+  def _sample_hps_for_rand_exp_sampling_in_add_model(self):
+    """ euclidean_gp.py:748-775: per sample a group size, a random partition of the coordinates, the
+        other discrete hyper-parameters and a uniform point of the continuous box -- drawn in that
+        order from the global np.random state --; weights exp(lml) WITHOUT the shift by the maximum
+        that the non-additive sampler applies (the reference's arithmetic).  One device call per
+        sample: every sample has its own grouping. """
+    gidx = self.add_group_size_idx_in_dscr_hp_vals
+    cts_all, dscr_all, other_all, vals = [], [], [], []
+    for _ in range(int(self.hp_tune_max_evals)):
+      group_size = np.random.choice(self.dscr_hp_vals[gidx])
+      order = list(np.random.permutation(self.dim))
+      other = Namespace(add_gp_groupings=[order[i:i + group_size] for i in range(0, self.dim, group_size)])
+      dscr = [np.random.choice(categ) for categ in self.dscr_hp_vals]
+      dscr[gidx] = group_size
+      cts = map_to_bounds(np.random.random((len(self.cts_hp_bounds),)), self.cts_hp_bounds)
+      vals.append(self._tuning_objective_batch([cts], [dscr], other)[0])
+      cts_all.append(cts); dscr_all.append(dscr); other_all.append(other)
+    probs = np.exp(vals)
+    return cts_all, dscr_all, other_all, probs / probs.sum()
+
   def fit_gp(self, num_samples=1, hp_tune_criterion=None):
-    """ gp_core.py:783-821 ('ml' branch). Returns ('fitted_gp', gp, (cts_hps, dscr_hps)) or, for
-        rand_exp_sampling, ('sample_hps_with_probs', cts, dscr, other_params, probs). """
-    # pylint: disable=unused-argument
+    """ gp_core.py:783-821. Returns ('fitted_gp', gp, (cts_hps, dscr_hps)); for rand_exp_sampling
+        ('sample_hps_with_probs', cts, dscr, other_params, probs); for post_sampling
+        ('post_fitted_gp', gp, hps) with one sample, else ('post_sample_hps_with_probs', cts, dscr,
+        other_params). """
     if hp_tune_criterion is None:
       hp_tune_criterion = self.options.hp_tune_criterion
+    if hp_tune_criterion == 'post_sampling':
+      sample_cts_hps, sample_dscr_hps, sample_other_gp_params = \
+        self._sample_cts_dscr_hps_for_post_sampling(num_samples)
+      if num_samples == 1:
+        opt_gp = self.build_gp(sample_cts_hps[0], sample_dscr_hps[0],
+                               other_gp_params=sample_other_gp_params[0])
+        return 'post_fitted_gp', opt_gp, (sample_cts_hps, sample_dscr_hps)
+      return ('post_sample_hps_with_probs', sample_cts_hps, sample_dscr_hps, sample_other_gp_params)
     if hp_tune_criterion != 'ml':
-      raise NotImplementedError('Only hp_tune_criterion="ml" runs on the device engine.')
+      raise ValueError('hp_tune_criterion should be ml or post_sampling.')
     if self.ml_hp_tune_opt_method in ['direct', 'rand', 'pdoo']:
       best_cts_hps = None
       best_dscr_hps = None
@@ -519,7 +581,10 @@ class EuclideanGPFitter(object):
       opt_hps = (best_cts_hps, best_dscr_hps)
       return 'fitted_gp', opt_gp, opt_hps
     if self._uses_additive_model():
-      raise NotImplementedError('rand_exp_sampling with additive GPs: use ml_hp_tune_opt="rand".')
+      sample_cts_hps, sample_dscr_hps, sample_other_gp_params, sample_probs = \
+        self._sample_hps_for_rand_exp_sampling_in_add_model()
+      return ('sample_hps_with_probs', sample_cts_hps, sample_dscr_hps,
+              sample_other_gp_params, sample_probs)
     sample_cts_hps, sample_dscr_hps, sample_probs = \
       self.hp_sampler(self._tuning_objective_batch, self.hp_tune_max_evals)
     sample_other_gp_params = [None] * len(sample_cts_hps)
@@ -531,9 +596,9 @@ class EuclideanGPFitter(object):
     self.hp_tune_results = {}
     for method in self.methods_to_use:
       ret = self.fit_gp(num_samples, method)
-      if ret[0] == 'fitted_gp':
+      if ret[0] in ('fitted_gp', 'post_fitted_gp'):
         self.hp_tune_results[method] = (ret[0], ret[1])
-      else:
+      elif ret[0] == 'sample_hps_with_probs':
         sample_hps = list(zip(ret[1], ret[2], ret[3]))
         sample_probs = ret[-1]
         if sum(sample_probs > 0) >= num_samples:
@@ -543,13 +608,19 @@ class EuclideanGPFitter(object):
         use_hps_idxs = np.random.choice(len(sample_hps), size=(num_samples,),
                                         replace=to_replace, p=sample_probs)
         self.hp_tune_results[method] = (ret[0], [sample_hps[idx] for idx in use_hps_idxs])
+      elif ret[0] == 'post_sample_hps_with_probs':
+        self.hp_tune_results[method] = (ret[0], list(zip(ret[1], ret[2], ret[3])))
+      else:
+        raise ValueError('Unknown option %s for results of fit_gp.' % (ret[0]))
 
   def get_next_gp(self):
     """ gp_core.py:728-741 """
+    if self.options.hp_tune_probs == 'adaptive':
+      self.hp_tune_probs = self._get_adaptive_hp_tune_probs()
     # p= as in the reference: it draws one uniform even for a single method (the no-p form does not)
     method = np.random.choice(self.methods_to_use, p=self.hp_tune_probs)
     fit_type = self.hp_tune_results[method][0]
-    if fit_type == 'fitted_gp':
+    if fit_type in ('fitted_gp', 'post_fitted_gp'):
       gp = self.hp_tune_results[method][1]
     else:
       next_gp_hps = self.hp_tune_results[method][1].pop(0)

@@ -174,6 +174,61 @@ def gen_fitter_case():
   print('wrote fitter_d3_n45')
 
 
+POST_SAMPLING_CASES = {
+  # name: (fitter options, num_samples)
+  'se_one': (dict(kernel_type='se', hp_tune_criterion='post_sampling', post_hp_tune_burn=6), 1),
+  'matern_nu_three': (dict(kernel_type='matern', matern_nu=-1.0, hp_tune_criterion='post_sampling',
+                           post_hp_tune_burn=4, post_hp_tune_offset=3), 3),
+  'additive_two': (dict(kernel_type='se', use_additive_gp=True, add_max_group_size=3, hp_tune_criterion='post_sampling',
+                        post_hp_tune_burn=3, post_hp_tune_offset=2, mean_func_type='median'), 2),
+}
+ADD_REXP_OPTS = dict(kernel_type='se', use_additive_gp=True, add_max_group_size=3, ml_hp_tune_opt='rand_exp_sampling',
+                     hp_tune_max_evals=25, hp_tune_criterion='ml')
+
+
+def gen_post_sampling_cases():
+  """ The reference's EuclideanGPFitter with hp_tune_criterion='post_sampling' (gp_core.py:592-726: slice
+      sampling of the continuous hyper-parameters, Metropolis on the discrete ones and on the additive
+      grouping's seed) and its additive rand_exp_sampling (euclidean_gp.py:748-775), seeded: the sampled
+      hyper-parameters, groupings and the state of the random stream afterwards. """
+  from dragonfly.gp.euclidean_gp import EuclideanGPFitter
+  rs = np.random.RandomState(91)
+  n, d = 30, 4
+  X = rs.random_sample((n, d))
+  Y = np.sin(3 * X[:, 0] + X[:, 1]) + np.cos(2 * X[:, 2]) + 0.05 * rs.randn(n)
+  res = {}
+  for name, (opts, num) in sorted(POST_SAMPLING_CASES.items()):
+    np.random.seed(2718)
+    fitter = EuclideanGPFitter(list(X), list(Y), options=Namespace(**opts))
+    ret = fitter.fit_gp(num, 'post_sampling')
+    if num == 1:
+      kind, gp, hps = ret
+      cts, dscr = hps
+      res[name + '_lml'] = gp.compute_log_marginal_likelihood()
+      others = [None]
+    else:
+      kind, cts, dscr, others = ret
+    res[name + '_kind'] = np.array(kind)
+    res[name + '_cts'] = np.array(cts, dtype=float)
+    res[name + '_dscr'] = np.array(dscr, dtype=float)
+    for t, o in enumerate(others):
+      if o is not None and o.add_gp_groupings is not None:
+        res[name + '_grouping_%d' % t] = np.array(sum([list(g) + [-1] for g in o.add_gp_groupings], []), dtype=float)
+    res[name + '_rand_after'] = np.random.random()
+    print('post_sampling %s: %s cts %s dscr %s' % (name, kind, np.round(res[name + '_cts'], 3).tolist(), res[name + '_dscr'].tolist()))
+  np.random.seed(31415)
+  fitter = EuclideanGPFitter(list(X), list(Y), options=Namespace(**ADD_REXP_OPTS))
+  kind, cts, dscr, others, probs = fitter.fit_gp()
+  res['add_rexp_kind'] = np.array(kind)
+  res['add_rexp_cts'] = np.array(cts, dtype=float)
+  res['add_rexp_dscr'] = np.array(dscr, dtype=float)
+  res['add_rexp_probs'] = np.array(probs, dtype=float)
+  res['add_rexp_first_grouping'] = np.array(sum([list(g) + [-1] for g in others[0].add_gp_groupings], []), dtype=float)
+  res['add_rexp_rand_after'] = np.random.random()
+  np.savez_compressed(os.path.join(OUT, 'post_sampling_d4_n30.npz'), X=X, Y=Y, **res)
+  print('wrote post_sampling_d4_n30')
+
+
 def gen_c1_case():
   """ BASELINE config 1: Branin 2-D, n = 200, SE kernel, UCB over 1000 random candidates, driven
       through the reference's own optimiser objects in ask/tell mode. """
@@ -653,6 +708,9 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'mffitter':
     gen_mf_fitter_case()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'post_sampling':
+    gen_post_sampling_cases()
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'slice':
     gen_slice_cases()
     sys.exit(0)
@@ -673,5 +731,6 @@ if __name__ == '__main__':
   gen_mf_fitter_case()
   gen_pdoo_cases()
   gen_slice_cases()
+  gen_post_sampling_cases()
   gen_trajectory_case()
   gen_nonpsd_cases()
