@@ -24,6 +24,7 @@ from .kernel import _as_2d_array
 from .doo import pdoo_maximise_batched
 from .oper_utils import random_maximise, random_sample_cts_dscr
 from .hp_sampling import PosteriorHPSampler
+from .hp_layout import consume_kernel_hps, describe_kernel_hps, group_kernel_args
 from .option_handler import get_option_specs, load_options
 
 _DFLT_KERNEL_TYPE = 'matern'
@@ -137,61 +138,23 @@ def get_euclidean_integral_gp_kernel_with_scale(kernel_type, scale, kernel_hyper
                                                 gp_cts_hps, gp_dscr_hps,
                                                 use_same_bandwidth, add_gp_groupings=None,
                                                 esp_kernel_type=None):
-  """ euclidean_gp.py:808-900 for the se / matern / poly / expdecay (and additive) kernels; the
-      reference's 'esp' kernels are not part of the device path. """
+  """ The kernel a hyper-parameter vector describes (interface of euclidean_gp.py:808-900 for the
+      se / matern / poly / expdecay kernels, plain or additive; the reference's 'esp' kernels are not
+      part of the device path).  Which values of the two vectors feed which argument of which kernel
+      class is the table of dragonfly_amd/hp_layout.py.  An additive kernel carries the scale itself
+      and its groups' kernels scale 1 (kernel.py:484-494).  Returns (kernel, left-over continuous,
+      left-over discrete hyper-parameters). """
   # pylint: disable=unused-argument
   dim = kernel_hyperparams['dim']
-  is_additive = False
-  if add_gp_groupings is None:
-    add_gp_groupings = [list(range(dim))]
-    grp_scale = scale
-  else:
-    is_additive = True
-    grp_scale = 1.0
-  if kernel_type not in ['se', 'matern', 'poly', 'expdecay']:
-    raise Exception('Unknown kernel type %s!'%(kernel_type))
-  if kernel_type in ['se', 'matern', 'poly']:
-    if use_same_bandwidth:
-      ke_dim_bandwidths = [np.exp(gp_cts_hps[0])] * dim
-      gp_cts_hps = gp_cts_hps[1:]
-    else:
-      ke_dim_bandwidths = np.exp(gp_cts_hps[0:dim])
-      gp_cts_hps = gp_cts_hps[dim:]
-  if kernel_type == 'poly':                 # euclidean_gp.py:870-879
-    if 'order' not in kernel_hyperparams or kernel_hyperparams['order'] < 0:
-      poly_order = gp_dscr_hps[0]
-      gp_dscr_hps = gp_dscr_hps[1:]
-    else:
-      poly_order = kernel_hyperparams['order']
-    grp_kernels = [gp_kernel.PolyKernel(dim=len(grp), order=poly_order, scale=grp_scale, \
-                     dim_scalings=get_sublist_from_indices(ke_dim_bandwidths, grp))
-                   for grp in add_gp_groupings]
-  elif kernel_type == 'expdecay':           # euclidean_gp.py:880-887
-    exp_decay_offset = np.exp(gp_cts_hps[0])
-    exp_decay_powers = np.exp(gp_cts_hps[1:dim+1])
-    gp_cts_hps = gp_cts_hps[dim+1:]
-    grp_kernels = [gp_kernel.ExpDecayKernel(dim=len(grp), scale=grp_scale, \
-                    offset=exp_decay_offset, powers=exp_decay_powers)
-                   for grp in add_gp_groupings]
-  elif kernel_type == 'se':
-    grp_kernels = [gp_kernel.SEKernel(dim=len(grp), scale=grp_scale, \
-                     dim_bandwidths=get_sublist_from_indices(ke_dim_bandwidths, grp))
-                   for grp in add_gp_groupings]
-  else:
-    if 'nu' not in kernel_hyperparams or kernel_hyperparams['nu'] < 0:
-      matern_nu = gp_dscr_hps[0]
-      gp_dscr_hps = gp_dscr_hps[1:]
-    else:
-      matern_nu = kernel_hyperparams['nu']
-    grp_kernels = [gp_kernel.MaternKernel(dim=len(grp), nu=matern_nu, scale=grp_scale, \
-                     dim_bandwidths=get_sublist_from_indices(ke_dim_bandwidths, grp))
-                   for grp in add_gp_groupings]
-  if is_additive:
-    euc_kernel = gp_kernel.AdditiveKernel(scale=scale, kernel_list=grp_kernels,
-                                          groupings=add_gp_groupings)
-  else:
-    euc_kernel = grp_kernels[0]
-  return euc_kernel, gp_cts_hps, gp_dscr_hps
+  values, cls_name, gp_cts_hps, gp_dscr_hps = consume_kernel_hps(kernel_type, dim, kernel_hyperparams,
+                                                                 gp_cts_hps, gp_dscr_hps, use_same_bandwidth)
+  additive = add_gp_groupings is not None
+  groups = add_gp_groupings if additive else [list(range(dim))]
+  make = getattr(gp_kernel, cls_name)
+  parts = [make(dim=len(grp), scale=1.0 if additive else scale, **group_kernel_args(kernel_type, values, grp))
+           for grp in groups]
+  kernel = gp_kernel.AdditiveKernel(scale=scale, kernel_list=parts, groupings=groups) if additive else parts[0]
+  return kernel, gp_cts_hps, gp_dscr_hps
 
 
 # Additive-model helpers (euclidean_gp.py:718-774) -------------------------------------------------
@@ -324,22 +287,26 @@ class EuclideanGPFitter(object):
       raise ValueError('Unknown mean_func_type. Should be mean/median/const/zero/tune.')
     self.kernel_type = _DFLT_KERNEL_TYPE if self.options.kernel_type == 'default' else \
                        self.options.kernel_type
-    # scale and bandwidths (euclidean_gp.py:254-268)
+    # the scale, then the kernel's own hyper-parameters in the order of hp_layout.KERNEL_HP_LAYOUT
+    # (boxes as in euclidean_gp.py:254-268: scale within [0.1, 10] Var(Y), bandwidths within
+    # [0.01, 10] x the Frobenius norm of the inputs, nu over {0.5, 1.5, 2.5})
     self.scale_log_bounds = [np.log(0.1 * self.Y_var), np.log(10 * self.Y_var)]
     self.param_order.append(["scale", "cts"])
     X_std_norm = np.linalg.norm(_as_2d_array(self.X), 'fro') + 1e-4
     single_bandwidth_log_bounds = [np.log(0.01 * X_std_norm), np.log(10 * X_std_norm)]
-    if self.options.use_same_bandwidth:
-      self.bandwidth_log_bounds = [single_bandwidth_log_bounds]
-      self.param_order.append(["same_dim_bandwidths", "cts"])
-    else:
-      self.bandwidth_log_bounds = [single_bandwidth_log_bounds] * self.dim
-      for _ in range(self.dim):
-        self.param_order.append(["dim_bandwidths", "cts"])
+    boxes = {'dim_bandwidths': single_bandwidth_log_bounds, 'same_dim_bandwidths': single_bandwidth_log_bounds}
+    value_lists = {'nu': [0.5, 1.5, 2.5]}
+    kernel_hyperparams = prep_euclidean_integral_kernel_hyperparams(self.kernel_type, self.options, self.dim)
+    self.bandwidth_log_bounds = []
+    for name, source, count in describe_kernel_hps(self.kernel_type, self.dim, kernel_hyperparams,
+                                                   self.options.use_same_bandwidth):
+      if source == 'cts':
+        self.bandwidth_log_bounds += [boxes[name]] * count
+        self.param_order += [[name, "cts"] for _ in range(count)]
+      else:
+        self.dscr_hp_vals.append(value_lists[name])
+        self.param_order.append([name, "dscr"])
     self.cts_hp_bounds += [self.scale_log_bounds] + self.bandwidth_log_bounds
-    if self.kernel_type == 'matern' and self.options.matern_nu < 0:
-      self.dscr_hp_vals.append([0.5, 1.5, 2.5])
-      self.param_order.append(["nu", "dscr"])
     if self.options.use_additive_gp:
       self.add_group_size_idx_in_dscr_hp_vals = len(self.dscr_hp_vals)
       self.add_max_group_size = min(self.options.add_max_group_size, self.dim)
