@@ -255,3 +255,72 @@ int64_t ld_gaussian_draw(const double* C, int64_t b, double jitter, const double
   free(A);
   return 0;
 }
+
+/* The same posterior for ANY kernel, given its Gram matrices in double (additive / polynomial /
+ * product kernels, host-evaluated kernels: everything ld_gp_truth has no formula for): the LINEAR
+ * ALGEBRA of gp_core.py:155-190, 222-227 in extended precision on the inputs the other two
+ * implementations' linear algebra receives.  K [n x n] without noise, Kx [m x n] = K(X*, X),
+ * kxx [m] = k(x*, x*), Kss [m x m] = K(X*, X*) (for cov_out; may be NULL).  Returns 0, the 1-based
+ * failing pivot, or -1 (allocation). */
+int64_t ld_gram_truth(const double* K, int64_t n, double diag_add, const double* yc, const double* Kx,
+                      const double* kxx, const double* Kss, int64_t m, double mean_const, double* alpha_out,
+                      double* lml_out, double* mu_out, double* sd_out, double* cov_out) {
+  ld* A = (ld*)malloc(sizeof(ld) * (size_t)n * (size_t)n);
+  ld* z = (ld*)malloc(sizeof(ld) * (size_t)n);
+  ld* al = (ld*)malloc(sizeof(ld) * (size_t)n);
+  if (!A || !z || !al) { free(A); free(z); free(al); return -1; }
+  for (int64_t i = 0; i < n * n; ++i) A[i] = (ld)K[i];
+  for (int64_t i = 0; i < n; ++i) A[i * n + i] += (ld)diag_add;
+  const int64_t piv = chol_ld(A, n);
+  if (piv != 0) { free(A); free(z); free(al); return piv; }
+  for (int64_t i = 0; i < n; ++i) {
+    ld s = (ld)yc[i];
+    for (int64_t p = 0; p < i; ++p) s -= A[i * n + p] * z[p];
+    z[i] = s / A[i * n + i];
+  }
+  for (int64_t i = n - 1; i >= 0; --i) {
+    ld s = z[i];
+    for (int64_t p = i + 1; p < n; ++p) s -= A[p * n + i] * al[p];
+    al[i] = s / A[i * n + i];
+  }
+  if (alpha_out)
+    for (int64_t i = 0; i < n; ++i) alpha_out[i] = (double)al[i];
+  if (lml_out) {
+    ld dot = 0, logdet = 0;
+    for (int64_t i = 0; i < n; ++i) { dot += (ld)yc[i] * al[i]; logdet += logl(A[i * n + i]); }
+    *lml_out = (double)(-dot / 2 - logdet - (ld)n / 2 * logl(2 * acosl((ld)-1)));
+  }
+  if (m > 0 && Kx) {
+    ld* V = (ld*)malloc(sizeof(ld) * (size_t)m * (size_t)n);
+    if (!V) { free(A); free(z); free(al); return -1; }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t c = 0; c < m; ++c) {
+      ld* v = V + c * n;
+      ld mu = (ld)mean_const, ss = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        const ld k = (ld)Kx[c * n + i];
+        mu += k * al[i];
+        ld s = k;
+        for (int64_t p = 0; p < i; ++p) s -= A[i * n + p] * v[p];
+        v[i] = s / A[i * n + i];
+        ss += v[i] * v[i];
+      }
+      if (mu_out) mu_out[c] = (double)mu;
+      if (sd_out && kxx) sd_out[c] = (double)sqrtl((ld)kxx[c] - ss);
+    }
+    if (cov_out && Kss) {
+#pragma omp parallel for schedule(dynamic, 4)
+      for (int64_t a = 0; a < m; ++a)
+        for (int64_t b = 0; b <= a; ++b) {
+          ld s = (ld)Kss[a * m + b];
+          const ld *va = V + a * n, *vb = V + b * n;
+          for (int64_t p = 0; p < n; ++p) s -= va[p] * vb[p];
+          cov_out[a * m + b] = (double)s;
+          cov_out[b * m + a] = (double)s;
+        }
+    }
+    free(V);
+  }
+  free(A); free(z); free(al);
+  return 0;
+}

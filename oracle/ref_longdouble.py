@@ -106,3 +106,36 @@ def gaussian_draw(mu, C_mat, u, jitter=0.0):
   if rc > 0:
     raise np.linalg.LinAlgError('truth: covariance not positive definite at pivot %d' % rc)
   return s
+
+
+def gram_truth(K, diag_add, y_centred, K_cross=None, k_ss=None, K_tete=None, mean_const=0.0):
+  """ The posterior's linear algebra in extended precision for ANY kernel, given its Gram matrices in
+      double: K [n x n] (no noise), K_cross [m x n], k_ss [m] = k(x*, x*), K_tete [m x m] (for 'cov').
+      Returns a dict: alpha, lml, and with K_cross mu (+ sd with k_ss, cov with K_tete). """
+  lib = _load()
+  if not hasattr(lib, '_gram_ready'):
+    lib.ld_gram_truth.restype = C.c_int64
+    lib.ld_gram_truth.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_double] + [C.c_void_p] * 5
+    lib._gram_ready = True
+  K, yc = _f64(K), _f64(y_centred).reshape(-1)
+  n = K.shape[0]
+  Kx = None if K_cross is None else _f64(K_cross)
+  m = 0 if Kx is None else Kx.shape[0]
+  kss = None if k_ss is None else _f64(k_ss).reshape(-1)
+  Kss = None if K_tete is None else _f64(K_tete)
+  out = dict(alpha=np.empty(n), lml=np.empty(1))
+  if m:
+    out['mu'] = np.empty(m)
+    if kss is not None:
+      out['sd'] = np.empty(m)
+    if Kss is not None:
+      out['cov'] = np.empty((m, m))
+  rc = lib.ld_gram_truth(_p(K), n, float(diag_add), _p(yc), _p(Kx), _p(kss), _p(Kss), m, float(mean_const),
+                         _p(out['alpha']), _p(out['lml']), _p(out.get('mu')), _p(out.get('sd')), _p(out.get('cov')))
+  if rc > 0:
+    raise np.linalg.LinAlgError('truth: matrix not positive definite at pivot %d' % rc)
+  if rc < 0:
+    raise MemoryError('truth: allocation failed')
+  out['lml'] = float(out['lml'][0])
+  return out

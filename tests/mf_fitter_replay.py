@@ -18,7 +18,7 @@ CASES = {
 }
 
 
-def check(name, tol=1e-9):
+def check(name, tol=1e-10):
   from dragonfly_amd.mf_gp import EuclideanMFGPFitter, EuclideanMFGP
   g = load_golden('mf_fitter_f2_d3_n48')
   opts = Namespace(ml_hp_tune_opt='rand', hp_tune_max_evals=60, hp_tune_criterion='ml', **CASES[name])

@@ -47,7 +47,7 @@ class ProductOverParts(object):
     return 'DomProd'
 
 
-def check(tol=1e-9):
+def check(tol=1e-10):
   from dragonfly_amd.gp_core import GP
   from dragonfly_amd.cartesian_product_gp import CPGP
   from dragonfly_amd import kernel as K

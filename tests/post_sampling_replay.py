@@ -16,7 +16,7 @@ def _flat(groupings):
   return np.array(sum([list(g) + [-1] for g in groupings], []), dtype=float)
 
 
-def check_post_sampling(name, tol=1e-9):
+def check_post_sampling(name, tol=1e-10):
   from dragonfly_amd.euclidean_gp import EuclideanGPFitter
   g = load_golden('post_sampling_d4_n30')
   opts, num = POST_SAMPLING_CASES[name]

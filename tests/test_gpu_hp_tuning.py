@@ -70,14 +70,20 @@ def test_lml_batch_jitter_ladder_per_candidate(engine):
     og = O.GPOracle(X, Y, ospecs[c], 0.0, noises[c])
     assert og.jitter_power == powers[c]
     ref = og.lml()
-    # after the ladder K + 1e-11 max(diag) I still has cond ~1e11-1e13: y^T alpha amplifies the
-    # 1e-16 differences between two correct factorisations to ~1e-5 relative
-    tol = TOL if powers[c] is None else 1e-4
-    assert abs(lml[c] - ref) <= tol * abs(ref), (c, lml[c], ref)
+    # after the ladder K + 1e-11 max(diag) I still has cond ~1e11-1e13: y^T alpha amplifies the 1e-16
+    # differences between two correct factorisations.  Bound: twice the oracle's own distance from the
+    # same solve in extended precision on the same (jittered) Gram matrix
+    tol = TOL
+    if powers[c] is not None:
+      from truth_bounds import gram_bounds
+      Kc = ospecs[c](X, X)
+      jit = (10.0 ** powers[c]) * float(np.diag(Kc + noises[c] * np.eye(n)).max())
+      tol = gram_bounds(Kc, noises[c] + jit, Y, dict(alpha=og.alpha, lml=ref))['lml']
+    assert abs(lml[c] - ref) <= tol * abs(ref), (c, lml[c], ref, tol)
     one = engine.gp_fit(specs[c], X, Y, noises[c])
     # the batch evaluates y^T alpha as ||L^-1 y||^2 (forward solve only), the single fit through both
     # solves: identical to 1e-12 for well-conditioned candidates, to the conditioning's share of it after the ladder
-    assert one.jitter_power == powers[c] and abs(one.lml - lml[c]) <= (1e-12 if powers[c] is None else 1e-9) * abs(one.lml)
+    assert one.jitter_power == powers[c] and abs(one.lml - lml[c]) <= (1e-12 if powers[c] is None else tol) * abs(one.lml)
   with pytest.raises(np.linalg.LinAlgError):
     engine.gp_lml_batch(specs, X, Y, None, noises, allow_jitter=False)
 
@@ -113,7 +119,7 @@ def test_fitter_rand_exp_sampling_probabilities(engine):
     assert ret[0] == 'sample_hps_with_probs'
     res.append(ret)
   assert np.array_equal(np.asarray(res[0][1]), np.asarray(res[1][1])) and res[0][2] == res[1][2]
-  assert np.allclose(res[0][4], res[1][4], rtol=1e-9, atol=1e-300)
+  assert np.allclose(res[0][4], res[1][4], rtol=1e-10, atol=1e-300)
   assert abs(res[0][4].sum() - 1.0) < 1e-12
 
 
@@ -176,8 +182,15 @@ def test_small_problems_take_the_one_launch_path_and_match(engine, n, d):
   lml, powers = engine.gp_lml_batch([p[0] for p in pairs], X, Y, means, noises, return_powers=True)
   for c, (spec, ospec) in enumerate(pairs):
     ref = O.GPOracle(X, Y, ospec, means[c], noises[c]).lml()
-    tol = 1e-6 if (ospec.kind == 'matern' and ospec.nu == 0.5) else TOL
-    assert abs(lml[c] - ref) <= tol * max(abs(ref), 1.0), (c, ospec.kind, lml[c], ref)
+    tol = TOL
+    if ospec.kind == 'matern' and ospec.nu == 0.5 and n > 1:
+      # sqrt of a squared distance that is rounding noise on the diagonal: twice the
+      # oracle's own distance from the extended-precision value
+      from oracle import ref_longdouble as T
+      from truth_bounds import bound
+      tr = T.gp_truth('matern', ospec.bandwidths, ospec.scale, X, Y - means[c], noises[c], nu=0.5)
+      tol = max(bound([ref], [tr['lml']]), TOL)
+    assert abs(lml[c] - ref) <= tol * max(abs(ref), 1.0), (c, ospec.kind, lml[c], ref, tol)
     one = engine.gp_fit(spec, X, Y - means[c], noises[c])
     assert abs(lml[c] - one.lml) <= 1e-11 * max(abs(one.lml), 1.0) and powers[c] == one.jitter_power
     one.free()

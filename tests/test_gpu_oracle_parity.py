@@ -7,6 +7,8 @@ import pytest
 from conftest import relerr
 from oracle import ref_numpy as O
 
+from truth_bounds import draw_bound    # noqa: E402
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
@@ -29,8 +31,14 @@ def test_kernel_matrix(engine, kind, nu, shape):
   assert relerr(engine.kernel_matrix(spec, X1, X2), ospec(X1, X2)) < 1e-12
   Ks = engine.kernel_matrix(spec, X1, None, diag_add=0.3)
   assert np.array_equal(Ks, Ks.T)                                       # bitwise symmetric
-  tol = 1e-6 if nu == 0.5 else 1e-12     # reference diagonal carries sqrt(rounding of dist_sq)
-  assert relerr(Ks, ospec(X1, X1) + 0.3 * np.eye(n1)) < tol
+  tol = 1e-12
+  if nu == 0.5:
+    # the reference's diagonal carries sqrt(rounding of dist_sq) (kernel.py:296 on general_utils.py:66-68):
+    # bound = twice the oracle's own distance from the extended-precision kernel matrix
+    from oracle import ref_longdouble as T
+    from truth_bounds import bound
+    tol = bound(ospec(X1, X1), T.kernel_matrix('matern', ospec.bandwidths, ospec.scale, X1, X1, nu=0.5))
+  assert relerr(Ks, ospec(X1, X1) + 0.3 * np.eye(n1)) <= tol
 
 
 def test_reference_known_answers_on_device(engine):
@@ -125,7 +133,7 @@ def test_fit_and_posterior_against_oracle(engine, kind, d, n, m):
   for acq, params in (('ucb', (2.5, 0.0)), ('ei', (best, 0.0)), ('pi', (best, 0.0)), ('ttei', (best, 0.2))):
     bv, bi, vals = gp.acq_argmax(acq, Xs, params=params, mean_const=mean_c, return_vals=True)
     vr = O.acq_values(acq, mur, sdr, *params)
-    assert relerr(vals, vr) < 1e-9
+    assert relerr(vals, vr) < TOL
     assert bi == O.argmax_first(vr)[1]
   # blocked Thompson sampling, several blocks per call
   U = rs.randn(m)
@@ -217,7 +225,7 @@ def test_additive_gp_and_add_ucb_groups(engine):
     beta = O.add_ucb_beta_th(len(grp), n)
     bv, bi, vals = gp.add_ucb_group(j, beta, Xj, return_vals=True)
     vr = O.add_ucb_group_values(og, j, Xj, n)
-    assert relerr(vals, vr) < 1e-9 and bi == int(np.argmax(vr))
+    assert relerr(vals, vr) < TOL and bi == int(np.argmax(vr))
 
 
 @pytest.mark.parametrize('noise_frac', [1e-13, 1e-9])
@@ -269,7 +277,9 @@ def test_thompson_blocks_in_the_panel_strip_regime(engine):
   for b in (0, 1, 31, 63):                       # a few blocks against the oracle (one 1100 x 1100 Cholesky each)
     sl = slice(b * blk, (b + 1) * blk)
     want = og.draw_samples_blocked(Xs[sl], U[sl], blk)
-    assert relerr(samp[sl], want) < 1e-4
+    mu_b, cov_b = og.eval(Xs[sl], 'covar')
+    tol_b = draw_bound(mu_b, cov_b, U[sl], want)        # 1100 x 1100 covariance behind a 300-point fit: rank-deficient, jittered
+    assert relerr(samp[sl], want) <= tol_b, (b, relerr(samp[sl], want), tol_b)
     assert int(np.argmax(samp[sl])) == int(np.argmax(want))
   assert bi == int(np.argmax(samp)) and bv == samp[bi]
   # the same call with the strips switched off is checked in tools (DFH_CHOL_STRIPS=0): here, blocks
@@ -277,4 +287,5 @@ def test_thompson_blocks_in_the_panel_strip_regime(engine):
   for b in (5, 40):
     sl = slice(b * blk, (b + 1) * blk)
     _, _, one, _ = gp.thompson(Xs[sl], U[sl], block=blk, mean_const=mean_c, return_samples=True)
-    assert relerr(one, samp[sl]) < 1e-6
+    mu_b, cov_b = og.eval(Xs[sl], 'covar')
+    assert relerr(one, samp[sl]) <= draw_bound(mu_b, cov_b, U[sl], og.draw_samples_blocked(Xs[sl], U[sl], blk))
