@@ -27,21 +27,30 @@ struct dfh_gp {
 
 namespace {
 
-int64_t pick_chunk(int64_t n, int64_t m) {
+int64_t pick_chunk(dfh_ctx* ctx, int64_t n, int64_t m) {
   // candidate rows per posterior chunk: the m_c x n cross matrix (solved in place into V^T) is sized
   // for a 288 GB part -- DFH_CHUNK_GIB (32) GiB, two of them alive in the pipelined Thompson
-  // sampling, never more than an eighth of the device's memory each.  Measured on the bench step
-  // (n = 16384, 262144 candidates, TS blocks factored in lock-step batches of DFH_TS_BATCH):
-  // 4 GiB / 8 blocks 1434 ms, 8 GiB / 16 1403-1412, 16 GiB / 32 1397, 32 GiB / 64 1389 -- bigger
-  // chunks mean taller TRSM products (1048 -> 1021 ms) and more Thompson blocks per latency-bound
-  // factorisation chain (332 -> 310 ms).
+  // sampling.  Measured on the bench step (n = 16384, 262144 candidates, TS blocks factored in
+  // lock-step batches of DFH_TS_BATCH): 4 GiB / 8 blocks 1434 ms, 8 GiB / 16 1403-1412, 16 GiB / 32
+  // 1397, 32 GiB / 64 1389 -- bigger chunks mean taller TRSM products (1048 -> 1021 ms) and more
+  // Thompson blocks per latency-bound factorisation chain (332 -> 310 ms).
+  // The cap is per CONTEXT (its device, and whoever else is on it): an eighth of what was free on the
+  // context's device when the context first asked, plus what the context's own scratch pool already
+  // held then -- not an eighth of the first device's total memory for the whole process.
   static const double chunk_gib = []() { const char* e = getenv("DFH_CHUNK_GIB"); double v = e ? atof(e) : 32.0; return v > 0.0 ? v : 32.0; }();
-  static const double mem_cap = []() {
+  if (ctx->chunk_cap_gib <= 0.0) {
     size_t f = 0, t = 0;
-    if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return 36.0; }
-    return (double)t / 8.0 / 1073741824.0;
-  }();
-  const double gib = chunk_gib < mem_cap ? chunk_gib : mem_cap;
+    double cap = 36.0;
+    if (hipMemGetInfo(&f, &t) == hipSuccess) {
+      size_t own = 0;
+      for (const DevBuf& b : ctx->scratch) own += b.bytes;
+      cap = (double)(f + own) / 8.0 / 1073741824.0;
+    } else {
+      (void)hipGetLastError();
+    }
+    ctx->chunk_cap_gib = cap > 0.25 ? cap : 0.25;
+  }
+  const double gib = chunk_gib < ctx->chunk_cap_gib ? chunk_gib : ctx->chunk_cap_gib;
   int64_t mc = (int64_t)(gib * (double)(1LL << 27)) / (n > 0 ? n : 1);
   mc = std::max<int64_t>(512, std::min<int64_t>(mc, 262144));
   mc = (mc / 512) * 512;
@@ -724,7 +733,7 @@ extern "C" int dfh_gp_predict_gram(dfh_gp* gp, const double* Kcross, int64_t m, 
   dfh_ctx* ctx = gp->ctx;
   DFH_HIP(hipSetDevice(ctx->device));
   const int64_t n = gp->n;
-  const int64_t mc_max = pick_chunk(n, m);
+  const int64_t mc_max = pick_chunk(ctx, n, m);
   const bool k_dev = is_device_ptr(Kcross), s_dev = kss ? is_device_ptr(kss) : true;
   const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
   double *vec = nullptr, *Kct = nullptr;
@@ -1308,7 +1317,7 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
   }
   struct AugGuard { dfh_gp* g; ~AugGuard() { if (g) dfh_gp_free(g); } } aug_guard{nullptr};
   aug_guard.g = aug;
-  const int64_t mc_max = pick_chunk(gp->n + (aug ? q : 0), m);
+  const int64_t mc_max = pick_chunk(gp->ctx, gp->n + (aug ? q : 0), m);
   const bool xs_dev = is_device_ptr(Xs);
   const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
   double* vec = nullptr;
@@ -1420,7 +1429,7 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
     xoff[g + 1] = xoff[g] + m_per_group[g] * gdim[g];
   }
   const int64_t M = off[G];
-  if (M > pick_chunk(n, M)) {
+  if (M > pick_chunk(ctx, n, M)) {
     for (int g = 0; g < G; ++g)
       DFH_TRY(dfh_gp_add_ucb_group(gp, g, betas[g], Xg_all + xoff[g], m_per_group[g],
                                    vals_out ? vals_out + off[g] : nullptr, &best_vals[g], &best_idx[g]));
@@ -1539,7 +1548,7 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   if (block > m) block = m;
   DFH_ARG((double)block * (double)block * 8.0 < 32e9);
   // several TS blocks share one posterior chunk so the TRSM runs on big GEMMs
-  int64_t bpc = std::max<int64_t>(1, pick_chunk(n, m) / block);
+  int64_t bpc = std::max<int64_t>(1, pick_chunk(ctx, n, m) / block);
   const int64_t mc_max = std::min(m, bpc * block);
   const int64_t nchunks = (m + mc_max - 1) / mc_max;
   const bool xs_dev = is_device_ptr(Xs), u_dev = is_device_ptr(U);

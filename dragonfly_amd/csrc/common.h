@@ -71,6 +71,7 @@ struct dfh_ctx {
   hipEvent_t tev0[DFH_T_COUNT] = {nullptr}, tev1[DFH_T_COUNT] = {nullptr};   // one pair per section (nestable)
   char name[256] = {0};
   int n_cu = 256;
+  double chunk_cap_gib = 0.0;        // posterior chunk cap of this context (api.hip: pick_chunk), set on first use
   // per-launch HIP-event profile of the GEMM kernel (bench.py roofline numbers)
   // When set, 128x128 GEMM launches request > 80 KB of LDS so that only ONE workgroup fits per
   // CU: the other half of every CU stays available to latency-critical kernels of another stream.

@@ -81,3 +81,16 @@ def draw_bound(mu, cov, U, ref_draw):
   _, pw = O.stable_cholesky(cov, return_power=True)
   jit = 0.0 if pw is None else (10.0 ** pw) * float(np.diag(cov).max())
   return bound(ref_draw, T.gaussian_draw(mu, cov, U, jit))
+
+
+def kernel_draw_bound(kind, nu, bw, scale, X, y_centred, noise, Xs, mean_const, U, ref_draw, ref_cov):
+  """ Bound for a joint Thompson draw when the posterior covariance is numerically singular (more
+      candidates than training points): there the draw is sensitive to the rounding of the covariance
+      ITSELF, so the truth starts from the kernel (oracle/ld_truth.c: covariance and draw in extended
+      precision, with the jitter the reference's ladder settles on for ref_cov). """
+  from oracle import ref_longdouble as T
+  from oracle import ref_numpy as O
+  _, pw = O.stable_cholesky(np.asarray(ref_cov, dtype=float), return_power=True)
+  jit = 0.0 if pw is None else (10.0 ** pw) * float(np.diag(ref_cov).max())
+  tr = T.gp_truth(kind, bw, scale, X, y_centred, noise, Xs, mean_const, 0.0, nu=nu or 0.0, ts_normals=U, ts_jitter=jit)
+  return bound(ref_draw, tr['draw'])
