@@ -55,31 +55,58 @@ def reduce_argmax(vals, idxs):
 
 
 # ---- passing the RCCL unique id between the processes of one node ---------------------------
+def _rendezvous_dir():
+  """ A directory only this user can write: DFH_RDZV_DIR if given, else $XDG_RUNTIME_DIR, else
+      /tmp/dfhip-<uid> (created 0700).  A directory that belongs to somebody else or is writable by
+      others is refused: the id file is what every rank of the job trusts. """
+  base = os.environ.get('DFH_RDZV_DIR') or os.environ.get('XDG_RUNTIME_DIR')
+  if not base:
+    base = os.path.join('/tmp', 'dfhip-%d' % os.getuid())
+  os.makedirs(base, mode=0o700, exist_ok=True)
+  st = os.stat(base)
+  if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+    raise RuntimeError('Rendezvous directory %s is not private to this user (owner %d, mode %o); set DFH_RDZV_DIR.'
+                       % (base, st.st_uid, st.st_mode & 0o777))
+  return base
+
+
 def _rendezvous_path(key=None):
   if key is None:
-    key = '%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
-                        os.getppid())
-  base = os.environ.get('DFH_RDZV_DIR', '/tmp')
-  return os.path.join(base, 'dfhip_rccl_id_%s.bin' % ''.join(ch if ch.isalnum() or ch in '-_' else '_' for ch in str(key)))
+    # the launcher's rendezvous, its restart generation (a restarted worker group must not pick up
+    # the id of the group that crashed) and the launcher's pid
+    key = '%s_%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+                           os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), os.getppid())
+  name = 'dfhip_rccl_id_%s.bin' % ''.join(ch if ch.isalnum() or ch in '-_' else '_' for ch in str(key))
+  return os.path.join(_rendezvous_dir(), name)
 
 
 def exchange_unique_id(rank, make_id, key=None, timeout=600.0, nbytes=_lib.UNIQUE_ID_BYTES):
   """ Rank 0 creates the id (make_id() -> bytes) and publishes it atomically in a file every rank
-      of this node can see; the others wait for the file.  Returns (id bytes, path). """
+      of this node can see; the others wait for the file.  Returns (id bytes, path).
+      Rank 0 removes whatever a crashed run left under the name, writes a fresh 0600 file created with
+      O_EXCL and renames it into place; the readers refuse links and files they do not own. """
   path = _rendezvous_path(key)
   if rank == 0:
     blob = bytes(make_id())
     assert len(blob) == nbytes
     tmp = '%s.%d.tmp' % (path, os.getpid())
-    with open(tmp, 'wb') as f:
+    for stale in (path, tmp):
+      try:
+        os.remove(stale)
+      except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+    with os.fdopen(fd, 'wb') as f:
       f.write(blob)
     os.replace(tmp, path)
     return blob, path
   deadline = time.time() + timeout
   while True:
     try:
-      with open(path, 'rb') as f:
-        blob = f.read()
+      fd = os.open(path, os.O_RDONLY | getattr(os, 'O_NOFOLLOW', 0))
+      with os.fdopen(fd, 'rb') as f:
+        st = os.fstat(f.fileno())
+        blob = f.read() if (st.st_uid == os.getuid() and not (st.st_mode & 0o077)) else b''
       if len(blob) == nbytes:
         return blob, path
     except OSError:

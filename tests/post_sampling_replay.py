@@ -51,7 +51,7 @@ def check_additive_rand_exp_sampling():
   assert kind == str(g['add_rexp_kind'])
   assert np.array_equal(np.array(cts, dtype=float), g['add_rexp_cts'])
   assert np.array_equal(np.array(dscr, dtype=float), g['add_rexp_dscr'])
-  assert np.allclose(probs, g['add_rexp_probs'], rtol=1e-8, atol=1e-300)
+  assert np.allclose(probs, g['add_rexp_probs'], rtol=1e-10, atol=1e-300)
   assert np.array_equal(_flat(others[0].add_gp_groupings), g['add_rexp_first_grouping'])
   assert np.random.random() == float(g['add_rexp_rand_after'])
   # the bandit's use of the sample (gp_core.py:748-781) and of the adaptive method weights

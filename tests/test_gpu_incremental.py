@@ -85,7 +85,13 @@ def test_append_falls_back_to_the_ladder_like_a_rebuild(engine):
   assert og.jitter_power is not None and ext.jitter_power == og.jitter_power
   full = engine.gp_fit(spec, Xd, Yd, 0.0)
   assert full.jitter_power == ext.jitter_power and abs(full.lml - ext.lml) <= 1e-12 * abs(full.lml)
-  assert abs(ext.lml - og.lml()) <= 1e-4 * abs(og.lml())       # cond ~1e11 after the ladder
+  # cond ~1e11 after the ladder: bound = twice the oracle's own distance from the same solve in extended
+  # precision on the same jittered Gram matrix
+  from truth_bounds import gram_bounds
+  Kd = ospec(Xd, Xd)
+  jit = (10.0 ** og.jitter_power) * float(np.diag(Kd).max())
+  tol_l = gram_bounds(Kd, jit, Yd, dict(alpha=og.alpha, lml=og.lml()))['lml']
+  assert abs(ext.lml - og.lml()) <= tol_l * abs(og.lml()), (abs(ext.lml - og.lml()) / abs(og.lml()), tol_l)
   with pytest.raises(np.linalg.LinAlgError):
     base.append(X[dup], Yd, allow_jitter=False)
   # an existing fit that needed the ladder is rebuilt as well (plain attempt first, then ladder)
@@ -94,7 +100,10 @@ def test_append_falls_back_to_the_ladder_like_a_rebuild(engine):
   ext2 = ext.append(xn, yn)
   og2 = O.GPOracle(np.vstack([Xd, xn]), yn, ospec, 0.0, 0.0)
   assert og2.jitter_power is not None and ext2.jitter_power == og2.jitter_power
-  assert ext2.n == n0 + q + 3 and abs(ext2.lml - og2.lml()) <= 1e-4 * abs(og2.lml())
+  Kd2 = ospec(np.vstack([Xd, xn]), np.vstack([Xd, xn]))
+  jit2 = (10.0 ** og2.jitter_power) * float(np.diag(Kd2).max())
+  tol_l2 = gram_bounds(Kd2, jit2, yn, dict(alpha=og2.alpha, lml=og2.lml()))['lml']
+  assert ext2.n == n0 + q + 3 and abs(ext2.lml - og2.lml()) <= tol_l2 * abs(og2.lml())
 
 
 def test_additive_kernel_append(engine):

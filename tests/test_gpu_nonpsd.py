@@ -57,3 +57,25 @@ def test_fit_gram_branches_against_the_oracle(engine):
 
 def test_nonpsd_gp_and_cpgp_against_reference_outputs(engine):
   check(tol=1e-10)
+
+
+def test_projection_stops_early_and_rejects_non_finite_input(engine):
+  """ round 3 (advisor): a spectrum bounded away from zero converges in ~25 Newton-Schulz steps -- the
+      iteration notices -- with the result of the eigen-decomposition route all the same; NaN / Inf
+      entries are an error (np.linalg.eigh raises LinAlgError in the reference's route) """
+  rs = np.random.RandomState(4)
+  n = 400
+  Q, _ = np.linalg.qr(rs.randn(n, n))
+  lam = np.concatenate([rs.uniform(0.5, 2.0, n // 2), -rs.uniform(0.5, 2.0, n - n // 2)])
+  M = (Q * lam).dot(Q.T)
+  M = (M + M.T) / 2
+  want = O.project_symmetric_to_psd_cone(M, 0.05)
+  got = engine.project_psd(M, 0.05)
+  assert relerr(got, want) < 1e-12 and np.array_equal(got, got.T)
+  bad = M.copy()
+  bad[3, 7] = bad[7, 3] = np.nan
+  with pytest.raises(np.linalg.LinAlgError):
+    engine.project_psd(bad, 0.0)
+  bad[3, 7] = bad[7, 3] = np.inf
+  with pytest.raises(np.linalg.LinAlgError):
+    engine.project_psd(bad, 0.0)

@@ -102,7 +102,7 @@ def test_cholesky_failure_modes(engine):
   M = A.dot(A.T)
   L, p = engine.stable_cholesky(M, return_power=True)
   _, pr = O.stable_cholesky(M, return_power=True)
-  assert p == pr and relerr(L.dot(L.T), M) < 1e-8
+  assert p == pr and relerr(L.dot(L.T), M) < 1e-8      # (reconstruction of a rank-40 matrix + jitter 1e-11 max diag: not a parity assert)
   # hopeless: ValueError after p = 4 (general_utils.py:199-203)
   with pytest.raises(ValueError):
     G.stable_cholesky(-np.eye(70))
@@ -141,8 +141,15 @@ def test_fit_and_posterior_against_oracle(engine, kind, d, n, m):
   bv, bi, samp, jps = gp.thompson(Xs[:2048], U[:2048], block=blk, mean_const=mean_c, return_samples=True)
   sr = og.draw_samples_blocked(Xs[:2048], U[:2048], blk)
   # the block covariance needs the jitter ladder (cond ~1e11 after it): rounding differences of
-  # 1e-16 in Sigma are amplified by its Cholesky factor, hence the looser tolerance on the draw
-  assert relerr(samp, sr) < 1e-4 and bi == int(np.argmax(sr))
+  # 1e-16 in Sigma are amplified by its Cholesky factor.  Per block: twice the oracle draw's own distance
+  # from the truth built from the kernel in extended precision
+  for b in range(2048 // blk):
+    sl = slice(b * blk, (b + 1) * blk)
+    _, cov_b = og.eval(Xs[sl], 'covar')
+    tol_b = kernel_draw_bound(kind, ospec.nu, ospec.bandwidths, ospec.scale, X, Y - mean_c, noise, Xs[sl], mean_c, U[sl],
+                              sr[sl], cov_b)
+    assert relerr(samp[sl], sr[sl]) <= tol_b, (b, relerr(samp[sl], sr[sl]), tol_b)
+  assert bi == int(np.argmax(sr))
 
 
 def test_ragged_and_single_point_inputs(engine):
@@ -249,6 +256,9 @@ def test_hallucination_when_the_augmented_matrix_needs_the_ladder(engine, noise_
   Xs = rs.rand(m, d)
   mu_o, sd_o = og.eval_with_hallucinated_observations(Xs, Xh)
   mu_d, sd_d = gp.predict(Xs, X_halluc=Xh)
+  # (robustness asserts, not parity asserts: the augmented matrix is numerically singular, the two sides'
+  #  solves differ by cond x eps; what is checked is that the device does what the reference does -- goes on
+  #  with the ladder -- and lands where the reference lands to the accuracy such a matrix allows)
   assert relerr(mu_d, mu_o) < 1e-6
   assert np.all(np.isfinite(sd_d) == np.isfinite(sd_o))
   ok = np.isfinite(sd_o)

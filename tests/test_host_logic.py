@@ -229,3 +229,31 @@ def test_reference_se_kernel_helper_known_answers(monkeypatch):
   kern = K.SEKernel(2, 1.0, [0.5, 2.0])
   kern.change_smoothness(2.0)
   assert np.array_equal(kern.hyperparams['dim_bandwidths'], [1.0, 4.0])
+
+
+def test_rccl_id_rendezvous_file_is_private_and_fresh(tmp_path, monkeypatch):
+  """ dragonfly_amd/parallel.py: the unique id travels through a 0600 file in a directory only this user
+      can write; rank 0 replaces whatever a crashed run left; readers ignore files with foreign modes """
+  import os
+  import stat
+  import threading
+  from dragonfly_amd import parallel
+  d = tmp_path / 'rdzv'
+  d.mkdir(mode=0o700)
+  monkeypatch.setenv('DFH_RDZV_DIR', str(d))
+  monkeypatch.setenv('TORCHELASTIC_RESTART_COUNT', '3')
+  path = parallel._rendezvous_path()                      # pylint: disable=protected-access
+  assert os.path.dirname(path) == str(d) and '_3_' in os.path.basename(path)
+  with open(path, 'wb') as f:                             # a stale, world-readable leftover of the right size
+    f.write(b'x' * 128)
+  os.chmod(path, 0o644)
+  got = {}
+  t = threading.Thread(target=lambda: got.update(r=parallel.exchange_unique_id(1, None, timeout=20.0, nbytes=128)))
+  t.start()
+  blob, p0 = parallel.exchange_unique_id(0, lambda: bytes(range(128)), nbytes=128)
+  t.join()
+  assert p0 == path and got['r'][0] == blob == bytes(range(128))          # the reader waited for the fresh, private file
+  assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
+  os.chmod(str(d), 0o777)
+  with pytest.raises(RuntimeError):
+    parallel._rendezvous_path()                           # pylint: disable=protected-access
