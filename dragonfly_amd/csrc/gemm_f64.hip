@@ -431,10 +431,10 @@ int launch(dfh_ctx* ctx, const GemmArgs& p, dim3 grid, const GemmExt* x = nullpt
     const double b_elems = (p.flags & GEMM_KTRI_B) ? 0.5 * (double)p.N * ((double)p.N + 1.0) : (double)p.N * (double)p.K;
     rec->bytes = 8.0 * (double)grid.z * ((double)p.M * (double)p.K + (p.B == p.A ? 0.0 : b_elems) +
                                          c_elems * ((p.Cin != nullptr && p.beta != 0.0) ? 2.0 : 1.0));
-    rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);   // (extended launches count with their plain twin)
-    // diagnostics: DFH_GEMM_PROF_SPLIT_LA=1 books the look-ahead trailing updates under variant 7 (tools/chol_gemm_prof.py)
-    static const bool split_la = getenv("DFH_GEMM_PROF_SPLIT_LA") && atoi(getenv("DFH_GEMM_PROF_SPLIT_LA")) != 0;
-    if (split_la && la) rec->variant = 7;
+    rec->variant = (TRANSB ? 4 : 0) | (EDGE ? 2 : 0) | (WT == 2 ? 1 : 0);
+    // the factorisation's extended launches are kernels of their own (gemm_f64_la_kernel / _cond_kernel in a
+    // rocprof trace) and are booked apart: slots 7 / 6, which no NN edge launch of the library's paths uses
+    if (EXT) rec->variant = la ? 7 : 6;
     DFH_HIP(hipEventRecord(rec->e0, ctx->stream));
   }
   if constexpr (EXT) {
@@ -716,7 +716,8 @@ int gemm_f64(dfh_ctx* ctx, int flags, int64_t M, int64_t N, int64_t K, double al
 
 // Enable / disable per-launch event timing of the GEMM kernel and fetch the totals.
 // stats_out[8][5]: per kernel variant (bit2 = NN, bit1 = edge path, bit0 = 64x64 tiles; variant 0
-// is the 128x128 NT throughput configuration) {launches, sum of launch durations in ms,
+// is the 128x128 NT throughput configuration; 7 / 6 = the factorisation's look-ahead-order /
+// conditional launches, kernels of their own) {launches, sum of launch durations in ms,
 // algorithmic flop, busy ms, algorithmic bytes}.  `busy` is the length of the union of the variant's launch
 // intervals: launches on different streams overlap (look-ahead Cholesky, TS pipeline) and then
 // share the CUs, so the plain sum counts that wall-clock more than once.

@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --no-cpu-baseline"
+B="python $REPO/bench.py --no-cpu-baseline --no-c4-full"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B --steps 2 --warmup 1 > $OUT/trace.log 2>&1
 grep -h "^{\"metric" $OUT/trace.log | cut -c1-4000 > $OUT/bench_under_trace.json
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS"; do
