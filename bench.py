@@ -44,7 +44,7 @@ import bench_extras as BX       # noqa: E402  pylint: disable=wrong-import-posit
 N_TRAIN, DIM, TS_BLOCK, CANDS_PER_GPU = BC.N_TRAIN, BC.DIM, BC.TS_BLOCK, BC.CANDS_PER_GPU
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak: 256 CU x 128 flop/clk x 2.4 GHz
 HBM_PEAK_TBS = 8.0
-PMC_TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+PMC_TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def rel(a, b):
@@ -337,7 +337,10 @@ def pmc_traffic():
     path = os.path.join(ROOT, 'profiles', name)
     try:
       with open(path) as f:
-        return json.load(f)['hbm_bytes_per_launch'], 'profiles/' + name
+        rec = json.load(f)
+        note = (' (%d launches per step in the counter passes: %s)' % (rec['launches'], rec['schedule_note'])) \
+               if 'schedule_note' in rec else ''
+        return rec['hbm_bytes_per_launch'], 'profiles/' + name + note
     except (OSError, KeyError, ValueError):
       continue
   return None, None

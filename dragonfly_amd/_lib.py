@@ -79,6 +79,7 @@ SIGNATURES = {
                                    C.c_void_p]),
   'dfh_rand_mt19937_uniform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, C.c_void_p, C.c_void_p]),
+  'dfh_mt19937_advance': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
   'dfh_rand_mt19937_normal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
   'dfh_rand_philox_uniform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

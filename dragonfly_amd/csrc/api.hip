@@ -1322,8 +1322,15 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
   const bool mv_dev = mean_vals ? is_device_ptr(mean_vals) : true;
   double* vec = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)mc_max * 8 * 8, (void**)&vec));
-  // a kernel with a polynomial / exponential-decay factor: k(x, x) per candidate (never on the add-UCB group path)
-  double* kss = (want_var && !gp->kd.stationary && !pre_gathered) ? vec + 7 * mc_max : nullptr;
+  // a kernel with a polynomial / exponential-decay factor: k(x, x) per candidate; on the add-UCB group path
+  // (pre_gathered: one group of an additive kernel) the group's own prior variance, if it is such a group
+  bool range_stationary = gp->kd.stationary;
+  if (pre_gathered) {
+    range_stationary = true;
+    for (int g = part_lo; g < part_hi; ++g)
+      range_stationary = range_stationary && (gp->kd.parts[g].kind == DFH_KERNEL_SE || gp->kd.parts[g].kind == DFH_KERNEL_MATERN);
+  }
+  double* kss = (want_var && !range_stationary) ? vec + 7 * mc_max : nullptr;
   double* mu_raw = vec; double* ss = vec + mc_max; double* ss2 = vec + 2 * mc_max;
   double* mu_c = vec + 3 * mc_max; double* sd_c = vec + 4 * mc_max; double* val_c = vec + 5 * mc_max;
   bool have = false; double bv = 0.0; int64_t bi = -1;
@@ -1348,7 +1355,7 @@ static int gp_eval_driver(dfh_gp* gp, int acq, const double* params, const doubl
       DFH_TRY(posterior_chunk(gp, xs_c, mc, ldxs, part_lo, part_hi, pre_gathered, want_var, &h, nullptr, mu_raw, ss, ss2,
                               0, &xsp, &nsp));
     }
-    if (kss) DFH_TRY(prior_diag(ctx, gp->kd, xsp, nsp, mc, kss));
+    if (kss) DFH_TRY(pre_gathered ? prior_diag(ctx, gp->kd, xsp, nsp, mc, kss, part_lo, part_hi) : prior_diag(ctx, gp->kd, xsp, nsp, mc, kss));
     {
       SectionTimer t(ctx, DFH_T_ACQ);
       const bool need_val = vals_out || best_val || best_idx;
@@ -1444,8 +1451,8 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
   double* Nsp = reinterpret_cast<double*>(xs + b_xsp);
   double *Kct = nullptr, *vec = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)M * n * 8, (void**)&Kct));
-  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)M * 8 * 3, (void**)&vec));
-  double* mu_raw = vec; double* ss = vec + M; double* val = vec + 2 * M;
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)M * 8 * 4, (void**)&vec));
+  double* mu_raw = vec; double* ss = vec + M; double* val = vec + 2 * M; double* kss_w = vec + 3 * M;
   {
     SectionTimer t(ctx, DFH_T_CROSS);
     for (int g = 0; g < G; ++g) {
@@ -1466,8 +1473,14 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
   for (int g = 0; g < G; ++g) {
     const double kxx = kd.outer_scale * kerndev_part_kxx(kd, g);        // kern_scale * kernel_j(x, x)
     const int64_t mg = m_per_group[g];
+    const double* kss_g = nullptr;
+    if (kd.parts[g].kind != DFH_KERNEL_SE && kd.parts[g].kind != DFH_KERNEL_MATERN) {
+      // a polynomial group: its prior variance depends on the point
+      DFH_TRY(prior_diag(ctx, kd, Xsp + off[g] * kd.P, Nsp + off[g] * kd.n_parts, mg, kss_w + off[g], g, g + 1));
+      kss_g = kss_w + off[g];
+    }
     hipLaunchKernelGGL(k_posterior_acq, dim3((unsigned)((mg + 255) / 256)), dim3(256), 0, ctx->stream, (int)DFH_ACQ_UCB,
-                       betas[g], 0.0, kxx, (const double*)nullptr, 0.0, (const double*)nullptr, mu_raw + off[g], ss + off[g],
+                       betas[g], 0.0, kxx, kss_g, 0.0, (const double*)nullptr, mu_raw + off[g], ss + off[g],
                        (const double*)nullptr, (long)mg, (double*)nullptr, (double*)nullptr, val + off[g]);
     DFH_LAUNCH_CHECK();
   }

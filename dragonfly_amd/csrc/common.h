@@ -148,6 +148,8 @@ bool ctx_is_live(const dfh_ctx* ctx);    // false once dfh_ctx_destroy ran (or f
 // return the device copy; if it is a device pointer return it unchanged.
 int to_device(dfh_ctx* ctx, const void* p, size_t bytes, int slot, const double** out);
 bool is_device_ptr(const void* p);
+// MT19937 state n_words further down the stream, by jump-ahead on the host (mtjump.hip)
+int mt19937_advance_host(uint32_t* key, int32_t* pos, int64_t n_words);
 // Copy a device result to a user pointer that may be host or device.
 int from_device(dfh_ctx* ctx, void* user_dst, const void* dev_src, size_t bytes);
 
@@ -248,7 +250,9 @@ int kerndev_clone(dfh_ctx* ctx, const KernDev& src, KernDev* out);   // deep cop
 void kerndev_free(KernDev* kd);
 double kerndev_part_kxx(const KernDev& kd, int part);
 // out[i] = k(x_i, x_i) from the packed inputs of m points (any kernel; needed when !kd.stationary)
-int prior_diag(dfh_ctx* ctx, const KernDev& kd, const double* Xp, const double* Np, int64_t m, double* out);
+// part_lo / part_hi (default: all parts): the prior variance of those groups of an additive kernel only
+int prior_diag(dfh_ctx* ctx, const KernDev& kd, const double* Xp, const double* Np, int64_t m, double* out, int part_lo = 0,
+               int part_hi = -1);
 
 // Xp[n][P] / Np[n][n_parts] for parts [part_lo, part_hi) (other parts' columns untouched).
 // pre_gathered: X holds only the columns of part_lo (ldx >= |cols|), as in add-UCB group

@@ -1209,7 +1209,8 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
       DFH_ARG(hi > lo);
       for (int c = lo; c < hi; ++c) DFH_ARG(k->group_dims[c] >= 0 && k->group_dims[c] < k->dim);
       const int sk = k->sub_kind[g];
-      DFH_ARG(kind_is_stationary(sk) || (product && (sk == DFH_KERNEL_POLY || sk == DFH_KERNEL_EXPDECAY)));
+      // polynomial groups also in an additive kernel (the reference's factory builds them: euclidean_gp.py:870-879)
+      DFH_ARG(kind_is_stationary(sk) || sk == DFH_KERNEL_POLY || (product && sk == DFH_KERNEL_EXPDECAY));
       DFH_TRY(make_part(kd, sk, k->sub_scale[g], k->sub_nu ? k->sub_nu[g] : 0.0, k->group_dims + lo,
                         k->sub_bw + lo, hi - lo));
       if (!kind_is_stationary(sk)) kd->stationary = false;
@@ -1231,11 +1232,11 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
 // (gp_core.py:181 takes it from the full test Gram matrix).
 __global__ void k_prior_diag(const PartDev* __restrict__ parts, int n_parts, int multi, int product, double outer,
                              const double* __restrict__ Xp, const double* __restrict__ Np, long m, int P,
-                             double* __restrict__ out) {
+                             double* __restrict__ out, int g_lo, int g_hi) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   double res = (multi && product) ? outer : 0.0;
-  for (int g = 0; g < n_parts; ++g) {
+  for (int g = g_lo; g < g_hi; ++g) {
     const PartDev& pd = parts[g];
     double kv;
     if (pd.kind == DFH_KERNEL_POLY) kv = poly_eval(pd, Np[i * n_parts + g]);
@@ -1248,10 +1249,13 @@ __global__ void k_prior_diag(const PartDev* __restrict__ parts, int n_parts, int
   out[i] = res;
 }
 
-int prior_diag(dfh_ctx* ctx, const KernDev& kd, const double* Xp, const double* Np, int64_t m, double* out) {
+int prior_diag(dfh_ctx* ctx, const KernDev& kd, const double* Xp, const double* Np, int64_t m, double* out, int part_lo,
+               int part_hi) {
   if (m <= 0) return DFH_OK;
+  if (part_hi < 0) { part_lo = 0; part_hi = kd.n_parts; }
   hipLaunchKernelGGL(k_prior_diag, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, kd.d_parts,
-                     kd.n_parts, kd.multi ? 1 : 0, kd.product ? 1 : 0, kd.outer_scale, Xp, Np, (long)m, kd.P, out);
+                     kd.n_parts, kd.multi ? 1 : 0, kd.product ? 1 : 0, kd.outer_scale, Xp, Np, (long)m, kd.P, out, part_lo,
+                     part_hi);
   DFH_LAUNCH_CHECK();
   return DFH_OK;
 }

@@ -16,6 +16,8 @@
 //    of four words, no sequential part at all.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -415,18 +417,37 @@ extern "C" int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* po
     DFH_TRY(scratch_get(ctx, SCR_OUT, size_t(count) * sizeof(double), &p));
     d_out = static_cast<double*>(p);
   }
-  DFH_TRY(scratch_get(ctx, SCR_VEC2, MT_N * sizeof(uint32_t), &p));
-  uint32_t* d_state = static_cast<uint32_t*>(p);
-  DFH_HIP(hipMemcpyAsync(d_state, key, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   const int64_t total_words = 2 * m * d;
   const int64_t keep_lo = 2 * row_begin * d, keep_hi = keep_lo + 2 * count;
-  const int64_t chunk_words = total_words < MT_CHUNK_WORDS ? total_words : MT_CHUNK_WORDS;   // even
+  // The words before and after the shard are not walked when there are many of them: the state
+  // jumps over them on the host (mtjump.hip; a few ms whatever the distance, the walk is 0.36 us per
+  // 624 words).  DFH_MT_JUMP_MIN_WORDS moves the threshold (0: never jump).
+  static const int64_t jump_min = getenv("DFH_MT_JUMP_MIN_WORDS") ? atoll(getenv("DFH_MT_JUMP_MIN_WORDS")) : (int64_t(1) << 23);
+  const bool jump_front = jump_min > 0 && keep_lo >= jump_min;
+  const bool jump_back = jump_min > 0 && total_words - keep_hi >= jump_min;
+  const int64_t walk_lo = jump_front ? keep_lo : 0, walk_hi = jump_back ? keep_hi : total_words;
+  uint32_t start_key[MT_N];
+  memcpy(start_key, key, sizeof(start_key));
+  int32_t start_pos = *pos;
+  if (jump_front) DFH_TRY(mt19937_advance_host(start_key, &start_pos, keep_lo));
+  if (walk_hi == walk_lo) {                       // nothing to generate here: the state only
+    if (jump_back) DFH_TRY(mt19937_advance_host(start_key, &start_pos, total_words - keep_hi));
+    memcpy(key, start_key, sizeof(start_key));
+    *pos = start_pos;
+    return DFH_OK;
+  }
+  DFH_TRY(scratch_get(ctx, SCR_VEC2, MT_N * sizeof(uint32_t), &p));
+  uint32_t* d_state = static_cast<uint32_t*>(p);
+  DFH_HIP(hipMemcpyAsync(d_state, start_key, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));     // start_key lives on this frame
+  const int64_t span_words = walk_hi - walk_lo;
+  const int64_t chunk_words = span_words < MT_CHUNK_WORDS ? span_words : MT_CHUNK_WORDS;   // even
   const int64_t raw_words = 2 * count < chunk_words ? 2 * count : chunk_words;
   DFH_TRY(scratch_get(ctx, SCR_TMP, size_t(raw_words > 0 ? raw_words : 2) * sizeof(uint32_t), &p));
   uint32_t* d_raw = static_cast<uint32_t*>(p);
-  int cur = *pos;
-  for (int64_t w0 = 0; w0 < total_words; w0 += chunk_words) {
-    const int64_t nw = total_words - w0 < chunk_words ? total_words - w0 : chunk_words;
+  int cur = start_pos;
+  for (int64_t w0 = walk_lo; w0 < walk_hi; w0 += chunk_words) {
+    const int64_t nw = walk_hi - w0 < chunk_words ? walk_hi - w0 : chunk_words;
     // the part of this chunk that belongs to the kept rows, chunk-local word indices
     const int64_t lo = (keep_lo > w0 ? keep_lo : w0) - w0;
     const int64_t hi = (keep_hi < w0 + nw ? keep_hi : w0 + nw) - w0;
@@ -449,6 +470,7 @@ extern "C" int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* po
   DFH_HIP(hipMemcpyAsync(key, d_state, MT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   DFH_HIP(hipStreamSynchronize(ctx->stream));
   *pos = cur;
+  if (jump_back) DFH_TRY(mt19937_advance_host(key, pos, total_words - keep_hi));
   if (!out_on_device) DFH_TRY(from_device(ctx, out, d_out, size_t(count) * sizeof(double)));
   return DFH_OK;
 }

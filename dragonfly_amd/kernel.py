@@ -331,7 +331,7 @@ class _GroupedKernel(_EuclideanDeviceKernel):
   def get_scaled_repr(self, X):
     raise NotImplementedError('Not defined for grouped kernels.')
 
-  _factor_kinds = ('se', 'matern')          # what the device evaluates inside this grouped kernel
+  _factor_kinds = ('se', 'matern', 'poly')  # what the device evaluates inside this grouped kernel (poly: euclidean_gp.py:870-879)
 
   def has_device_spec(self):
     return all(_factor_kind(kern) in self._factor_kinds for kern in self.kernel_list)

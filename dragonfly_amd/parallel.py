@@ -348,6 +348,21 @@ def sharded_thompson(fitted_gp, cands, U, block, mean_const=0.0, comm=None):
   return comm.allgather_argmax(v, i)
 
 
+def advance_mt19937(rng, n_doubles):
+  """ Move a legacy NumPy generator (None / np.random: the global state; or a RandomState) past
+      n_doubles draws of random_sample without making them: polynomial jump-ahead on the host
+      (dfh_mt19937_advance), a few ms whatever the distance.  The state afterwards is the state the
+      draws would have left. """
+  legacy = np.random if (rng is None or rng is np.random) else rng
+  state = legacy.get_state()
+  if state[0] != 'MT19937':
+    raise ValueError('The legacy NumPy state is not MT19937.')
+  key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+  pos = C.c_int32(int(state[2]))
+  check(_lib.load().dfh_mt19937_advance(key.ctypes.data_as(C.c_void_p), C.byref(pos), 2 * int(n_doubles)))
+  legacy.set_state((state[0], key, int(pos.value)) + tuple(state[3:]))
+
+
 def sharded_random_candidates(engine, m, bounds, rank=0, world_size=1, align=1, rng=None):
   """ This rank's shard of the m random candidates of a 'rand' acquisition, generated in HBM
       (Engine.random_candidates, rows=...).  Every rank must call this with the generator in the

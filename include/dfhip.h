@@ -297,10 +297,15 @@ int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double* Xg_all, co
  * Only rows [row_begin, row_begin + row_count) of the m x d block are written (`out` is
  * [row_count x d]) while the state advances over the whole block: every rank of a multi-GPU run
  * starts from the same state, keeps its own shard of the candidates, and ends in the same state
- * (one process draws them all in the reference).  MT19937 has to walk the stream up to the end
- * whatever the shard; Philox computes the shard's blocks only.                                   */
+ * (one process draws them all in the reference).  Philox computes the shard's blocks only; for
+ * MT19937 the words before and after the shard are jumped over (polynomial jump-ahead on the host,
+ * a few ms whatever the distance) once there are more than 2^23 of them, walked otherwise.
+ *
+ * dfh_mt19937_advance (host only, no device needed): key / pos after n_words further 32-bit words
+ * of the stream, i.e. what np.random.get_state() shows after random_sample(n_words / 2).         */
 int dfh_rand_mt19937_uniform(dfh_ctx* ctx, uint32_t* key, int32_t* pos, int64_t m, int64_t d,
                              int64_t row_begin, int64_t row_count, const double* bounds, double* out);
+int dfh_mt19937_advance(uint32_t* key, int32_t* pos, int64_t n_words);
 /* np.random.normal(size=m) from the same legacy state -- the standard normals draw_gaussian_samples
  * takes (dragonfly/utils/general_utils.py:230; Thompson sampling, gp_core.py:250-254) -- produced in
  * HBM bit for bit: NumPy's legacy_gauss (polar method with rejection on the MT19937 double stream).

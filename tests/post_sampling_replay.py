@@ -51,9 +51,16 @@ def check_additive_rand_exp_sampling():
   assert kind == str(g['add_rexp_kind'])
   assert np.array_equal(np.array(cts, dtype=float), g['add_rexp_cts'])
   assert np.array_equal(np.array(dscr, dtype=float), g['add_rexp_dscr'])
-  assert np.allclose(probs, g['add_rexp_probs'], rtol=1e-10, atol=1e-300)
   assert np.array_equal(_flat(others[0].add_gp_groupings), g['add_rexp_first_grouping'])
   assert np.random.random() == float(g['add_rexp_rand_after'])
+  # weights exp(lml) / sum: a relative 1e-10 on a marginal likelihood is |lml| * 1e-10 on its weight
+  # (they span 300 decades here), so the bound is computed per sample from the lml values themselves
+  lml = np.array([fitter._tuning_objective_batch([c], [d], o)[0] for c, d, o in zip(cts, dscr, others)])
+  bound = 1e-10 * (np.abs(lml) + np.abs(lml).max())
+  ref = g['add_rexp_probs']
+  pos = ref > 1e-300
+  assert np.all(np.abs(np.asarray(probs)[pos] - ref[pos]) <= bound[pos] * ref[pos])
+  assert np.all(np.asarray(probs)[~pos] <= 1e-300)
   # the bandit's use of the sample (gp_core.py:748-781) and of the adaptive method weights
   np.random.seed(5)
   fitter.fit_gp_for_gp_bandit(num_samples=3)

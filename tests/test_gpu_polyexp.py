@@ -89,6 +89,42 @@ def test_bad_descriptions_are_rejected(engine):
     K.ExpDecayKernel(9, 1.0, 0.1, np.ones(9))(X)           # more than 8 dimensions
   with pytest.raises(ValueError):
     K.PolyKernel(9, 2.5, 1.0, np.ones(9))(X)               # the order has to be an integer
-  add = K.AdditiveKernel(1.0, [K.PolyKernel(4, 2, 1.0, np.ones(4)), K.SEKernel(5, 1.0, np.ones(5))],
+  add = K.AdditiveKernel(1.0, [K.ExpDecayKernel(4, 1.0, 0.1, np.ones(4)), K.SEKernel(5, 1.0, np.ones(5))],
                          [[0, 1, 2, 3], [4, 5, 6, 7, 8]])
-  assert not add.has_device_spec()                         # additive groups stay SE / Matern on the device
+  assert not add.has_device_spec()                         # an exponential-decay factor only inside a product
+
+
+def test_polynomial_groups_in_an_additive_kernel(engine):
+  """ the reference's factory builds additive kernels of polynomial groups (euclidean_gp.py:870-879,
+      kernel.py:461-501): Gram / cross matrices, the posterior with its per-candidate prior variance and
+      the add-UCB group acquisitions (gpb_acquisitions.py:161-176), one group at a time and stacked """
+  from dragonfly_amd import kernel as K
+  from dragonfly_amd.gp_core import GP
+  rs = np.random.RandomState(11)
+  n, d, m = 450, 9, 1300
+  groups = [[0, 4, 7], [1, 2], [3, 5, 6, 8]]
+  sc = [rs.random_sample(len(g)) + 0.4 for g in groups]
+  bw = rs.random_sample(2) + 0.4
+  subs_dev = [K.PolyKernel(3, 3, 0.7, sc[0]), K.SEKernel(2, 1.3, bw), K.PolyKernel(4, 2, 1.1, sc[2])]
+  subs_ora = [O.KernelSpec('poly', 3, 0.7, sc[0], nu=3), O.KernelSpec('se', 2, 1.3, bw), O.KernelSpec('poly', 4, 1.1, sc[2], nu=2)]
+  kern = K.AdditiveKernel(1.6, subs_dev, groups)
+  spec = O.KernelSpec('additive', d, 1.6, groups=groups, subs=subs_ora)
+  assert kern.has_device_spec()
+  X, Xs = rs.random_sample((n, d)), rs.random_sample((m, d))
+  assert relerr(kern(X), spec(X)) < 1e-13 and relerr(kern(Xs, X), spec(Xs, X)) < 1e-13
+  Y = (X[:, groups[0]].sum(axis=1)) ** 2 + np.sin(4 * X[:, 1]) + 0.05 * rs.randn(n)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 15)
+  gp = GP(list(X), list(Y), kern, lambda x: np.array([mean_c] * len(x)), noise)
+  og = O.GPOracle(X, Y, spec, mean_c, noise)
+  mu, sd = gp.eval(Xs, 'std')
+  mur, sdr = og.eval(Xs, 'std')
+  assert relerr(gp.alpha, og.alpha) < 1e-10 and relerr(mu, mur) < 1e-10 and relerr(sd, sdr) < 1e-10
+  t = 37
+  cands = [rs.random_sample((700 + 50 * j, len(g))) for j, g in enumerate(groups)]
+  want = [O.add_ucb_group_values(og, j, cands[j], t) for j in range(len(groups))]
+  betas = [O.add_ucb_beta_th(len(g), t) for g in groups]
+  bvs, bis, vals_all = gp.device_gp.add_ucb_all(betas, cands, return_vals=True)
+  for j in range(len(groups)):
+    bv, bi, vals = gp.device_gp.add_ucb_group(j, betas[j], cands[j], return_vals=True)
+    assert relerr(vals, want[j]) < 1e-10 and relerr(vals_all[j], want[j]) < 1e-10
+    assert bi == int(np.argmax(want[j])) == bis[j] and bv == vals[bi] and bvs[j] == vals_all[j][bi]

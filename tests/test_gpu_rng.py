@@ -147,6 +147,31 @@ def test_row_shards_tile_the_full_draw_and_leave_the_same_state(engine, kind):
     engine.random_candidates(10, 2, rows=(5, 6))
 
 
+def test_large_mt19937_shards_jump_over_the_rest_of_the_stream(engine):
+  """ Shards with more than 2^23 words before or after them do not walk those words: the state jumps
+      (csrc/mtjump.hip).  Rows and the state handed back must still be the full draw's
+      (np.random.random((m, d)), oper_utils.py:62); a rank with no rows only moves the state. """
+  from dragonfly_amd.parallel import shard_bounds
+  m, d = 1 << 19, 32                       # 2^25 words; a quarter is 2^23
+  ref = np.random.RandomState(77)
+  ref.random_sample(13)
+  want = ref.random_sample((m, d))
+  want_state = ref.get_state()
+  for world, ranks in ((2, (0, 1)), (4, (0, 2, 3))):
+    for rank in ranks:
+      lo, hi = shard_bounds(m, rank, world, align=64)
+      g = np.random.RandomState(77)
+      g.random_sample(13)
+      part = engine.random_candidates(m, d, rng=g, rows=(lo, hi - lo)).download()
+      assert np.array_equal(part, want[lo:hi])
+      st = g.get_state()
+      assert np.array_equal(st[1], want_state[1]) and st[2] == want_state[2]
+  g = np.random.RandomState(77)
+  g.random_sample(13)
+  engine.random_candidates(m, d, rng=g, rows=(m // 2, 0))
+  assert np.array_equal(g.get_state()[1], want_state[1]) and g.get_state()[2] == want_state[2]
+
+
 def test_c_abi_argument_checks(engine):
   """ bad generator positions / row windows / dimensions are DFH_ERR_BAD_ARG (-> ValueError), not
       memory errors """

@@ -107,6 +107,27 @@ def test_reduce_argmax_numpy_semantics():
     assert (v != v) if np.isnan(vals[i]) else v == vals[i]
 
 
+def test_mt19937_jump_ahead_lands_in_numpys_state():
+  """ dfh_mt19937_advance (host code, polynomial jump-ahead) against NumPy walking the stream:
+      same key, same position, same draws afterwards -- inside a block, across one block edge,
+      across many, and 2^26 words away """
+  from dragonfly_amd.parallel import advance_mt19937
+  for seed, before, n in ((1, 0, 1), (2, 5, 311), (3, 0, 312), (4, 7, 313), (5, 100, 1872), (6, 3, 100001),
+                          (7, 11, (1 << 23) + 5), (8, 0, 1 << 25)):
+    walked, jumped = np.random.RandomState(seed), np.random.RandomState(seed)
+    walked.random_sample(before)
+    jumped.random_sample(before)
+    left = n
+    while left > 0:
+      walked.random_sample(min(left, 1 << 22))
+      left -= min(left, 1 << 22)
+    advance_mt19937(jumped, n)
+    a, b = walked.get_state(), jumped.get_state()
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2], (seed, n)
+    assert np.array_equal(walked.random_sample(7), jumped.random_sample(7))
+    assert walked.standard_normal() == jumped.standard_normal()
+
+
 def test_gp_kernel_modes_and_bad_lengths():
   from dragonfly_amd.gp_core import GP
   class Foreign(object):                     # a kernel the host evaluates (no device description)

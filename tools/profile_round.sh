@@ -14,8 +14,11 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $set -d $OUT/wl_$tag -o wl -- python $REPO/tools/pmc_workload.py > $OUT/wl_$tag.log 2>&1
 done
+# (the resident look-ahead schedule hands tiles over between CONCURRENT kernels; --pmc serialises
+#  kernels, every hand-off would time out and fall back, so the counter passes run the schedule
+#  without it -- the dominant kernel's launches are the same products either way)
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/bench_$set -o bench -- $B --steps 1 --warmup 0 > $OUT/bench_$set.log 2>&1
+  DFH_CHOL_LR=0 rocprofv3 --kernel-trace --pmc $set -d $OUT/bench_$set -o bench -- $B --steps 1 --warmup 0 > $OUT/bench_$set.log 2>&1
 done
 find $OUT -name '*.db' -size +40M -delete
 ls -la $OUT $OUT/*/ 2>/dev/null | head -60
