@@ -115,6 +115,32 @@ __global__ void k_argmax_stage2(const double* pv, const long* pi, int nparts, do
   if (threadIdx.x == 0) { out_v[0] = sv[0]; out_i[0] = si[0]; }
 }
 
+// One workgroup per segment [off[g], off[g+1]) of v: its arg-max (np.argmax rule, index local to the segment)
+__global__ void k_argmax_segments(const double* __restrict__ v, const long* __restrict__ off,
+                                  double* __restrict__ out_v, long* __restrict__ out_i) {
+  __shared__ double sv[256];
+  __shared__ long si[256];
+  const long lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+  double bv = -INFINITY;
+  long bi = LONG_MAX;
+  for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const double x = v[i];
+    if (bi == LONG_MAX || better(x, i - lo, bv, bi)) { bv = x; bi = i - lo; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = sv[threadIdx.x + s]; const long oi = si[threadIdx.x + s];
+      if (oi != LONG_MAX && (si[threadIdx.x] == LONG_MAX || better(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
+        sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out_v[blockIdx.x] = sv[0]; out_i[blockIdx.x] = si[0]; }
+}
+
 bool host_better(double va, int64_t ia, double vb, int64_t ib) {
   const bool na = va != va, nb = vb != vb;
   if (na || nb) { if (na && nb) return ia < ib; return na; }
@@ -296,8 +322,10 @@ int posterior_chunk(dfh_gp* gp, const double* Xs_dev, int64_t mc, int64_t ldxs, 
   {
     SectionTimer t(ctx, DFH_T_CROSS);
     DFH_TRY(pack_scaled(ctx, kd, part_lo, part_hi, pre_gathered, Xs_dev, mc, ldxs, Xsp, Nsp));
-    DFH_TRY(kernmat_packed(ctx, kd, part_lo, part_hi, true, Xsp, Nsp, mc, gp->Xp, gp->Np, gp->n, false, 0.0, Kct, gp->n));
-    DFH_TRY(gemv_rows(ctx, Kct, mc, gp->n, gp->n, gp->alpha, 1.0, nullptr, 0.0, mu_raw));   // gp_core.py:174
+    bool mu_done = false;      // gp_core.py:174, from the same pass where the kernel can
+    DFH_TRY(kernmat_packed(ctx, kd, part_lo, part_hi, true, Xsp, Nsp, mc, gp->Xp, gp->Np, gp->n, false, 0.0, Kct, gp->n,
+                           gp->alpha, mu_raw, &mu_done));
+    if (!mu_done) DFH_TRY(gemv_rows(ctx, Kct, mc, gp->n, gp->n, gp->alpha, 1.0, nullptr, 0.0, mu_raw));
   }
   if (want_var) {
     {
@@ -1444,6 +1472,9 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
   }
   const double* dXg = nullptr;
   DFH_TRY(to_device(ctx, Xg_all, (size_t)xoff[G] * 8, SCR_STAGE_A, &dXg));
+  static_assert(sizeof(long) == sizeof(int64_t), "offsets travel as int64");
+  const double* d_off = nullptr;                     // segment offsets for the per-group arg-max
+  DFH_TRY(to_device(ctx, reinterpret_cast<const double*>(off.data()), (size_t)(G + 1) * 8, SCR_STAGE_B, &d_off));
   char* xs = nullptr;
   const size_t b_xsp = ((size_t)M * kd.P * 8 + 255) / 256 * 256;
   DFH_TRY(scratch_get(ctx, SCR_XS, b_xsp + (size_t)M * kd.n_parts * 8, (void**)&xs));
@@ -1455,14 +1486,17 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
   double* mu_raw = vec; double* ss = vec + M; double* val = vec + 2 * M; double* kss_w = vec + 3 * M;
   {
     SectionTimer t(ctx, DFH_T_CROSS);
+    bool mu_all = true;          // posterior means from the cross-matrix pass itself where the kernel can
     for (int g = 0; g < G; ++g) {
       double* Xsp_g = Xsp + off[g] * kd.P; double* Nsp_g = Nsp + off[g] * kd.n_parts;
       DFH_TRY(pack_scaled(ctx, kd, g, g + 1, true, dXg + xoff[g], m_per_group[g], gdim[g], Xsp_g, Nsp_g));
       // K_j(X*_j, X[:, group j]) with the outer scale        (gpb_acquisitions.py:166-168)
+      bool mu_done = false;
       DFH_TRY(kernmat_packed(ctx, kd, g, g + 1, true, Xsp_g, Nsp_g, m_per_group[g], gp->Xp, gp->Np, n, false,
-                             0.0, Kct + off[g] * n, n));
+                             0.0, Kct + off[g] * n, n, gp->alpha, mu_raw + off[g], &mu_done));
+      mu_all = mu_all && mu_done;
     }
-    DFH_TRY(gemv_rows(ctx, Kct, M, n, n, gp->alpha, 1.0, nullptr, 0.0, mu_raw));
+    if (!mu_all) DFH_TRY(gemv_rows(ctx, Kct, M, n, n, gp->alpha, 1.0, nullptr, 0.0, mu_raw));
   }
   {
     SectionTimer t(ctx, DFH_T_TRSM);
@@ -1484,10 +1518,16 @@ extern "C" int dfh_gp_add_ucb_all(dfh_gp* gp, const double* betas, const double*
                        (const double*)nullptr, (long)mg, (double*)nullptr, (double*)nullptr, val + off[g]);
     DFH_LAUNCH_CHECK();
   }
-  for (int g = 0; g < G; ++g) {
-    bool have = false; double bv = 0.0; int64_t bi = -1;
-    DFH_TRY(argmax_update(ctx, val + off[g], m_per_group[g], 0, &have, &bv, &bi));
-    best_vals[g] = bv; best_idx[g] = bi;
+  {   // the G arg-maxes in one launch and one copy back (each used to cost a stream synchronisation)
+    char* red = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_RED, (size_t)G * 16, (void**)&red));
+    double* d_bv = reinterpret_cast<double*>(red);
+    long* d_bi = reinterpret_cast<long*>(red + (size_t)G * 8);
+    hipLaunchKernelGGL(k_argmax_segments, dim3((unsigned)G), dim3(256), 0, ctx->stream, val,
+                       reinterpret_cast<const long*>(d_off), d_bv, d_bi);
+    DFH_LAUNCH_CHECK();
+    DFH_HIP(hipMemcpyAsync(best_vals, d_bv, (size_t)G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipMemcpyAsync(best_idx, d_bi, (size_t)G * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   if (vals_out) DFH_TRY(from_device(ctx, vals_out, val, (size_t)M * 8));
   DFH_HIP(hipStreamSynchronize(ctx->stream));

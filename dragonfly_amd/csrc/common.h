@@ -128,6 +128,7 @@ enum ScratchSlot {
   SCR_CHOLR,        // ... and residual
   SCR_REFINE,       // residual of the refined row solves (trsm_rows*)
   SCR_CHOLKEEP,     // ... block inverses when the caller keeps none
+  SCR_MUPART,       // cross matrix with the posterior mean fused in: per-block partial sums
   SCR_COUNT
 };
 
@@ -271,7 +272,9 @@ int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob,
 int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool apply_outer,
                    const double* Xp1, const double* Np1, int64_t n1, const double* Xp2,
                    const double* Np2, int64_t n2, bool symmetric, double diag_add, double* K,
-                   int64_t ldk);
+                   int64_t ldk, const double* mu_alpha = nullptr, double* mu_out = nullptr, bool* mu_done = nullptr);
+// (mu_alpha, mu_out, mu_done: ask for mu_out[n1] = K mu_alpha from the same pass; *mu_done tells whether
+//  the kernel that ran could do it -- the caller multiplies itself otherwise)
 
 // Blocked Cholesky, in place on the lower triangle of the row-major matrix A (upper part of the
 // off-diagonal blocks is left untouched; the upper part of the 64x64 diagonal blocks is zeroed).

@@ -57,7 +57,14 @@ struct KmArgs {
   // term per batch element (NULL: diag_add)
   long sXp, sNp, sK, sBlob;
   const double* diag_adds;
+  // strip kernel with the posterior mean fused in: mu_part[row][blk] = sum over the columns of block
+  // blk (KM_MU_BLOCK columns) of K[row][col] * mu_alpha[col]
+  const double* mu_alpha;
+  double* mu_part;
+  double* mu_out;
+  int mu_nblk;
 };
+constexpr int KM_MU_BLOCK = 512;
 
 __device__ __forceinline__ double ipow(double m, int k) {
   double r = 1.0;                      // 0**0 == 1 as in numpy (kernel.py:266)
@@ -443,6 +450,171 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
   }
 }
 
+// Symmetric Gram matrix of a multi-part kernel with stationary parts (additive: scale * sum_g k_g,
+// kernel.py:484-494; coordinate product of SE / Matern factors: kernel.py:578-589): the lower
+// triangle of 64 x 64 tiles only, each tile stored twice through the LDS staging buffer as in
+// kernmat_sym_kernel.  The parts' packed columns are adjacent, so one LDS fill takes as many whole
+// parts as fit into KC columns (the groups of an additive model are a few columns wide: two barriers
+// per KC columns instead of two per part), then each part runs its own MFMA dot product, its
+// epilogue, and is combined into the running result in the reference's order.
+// Half the tiles of the generic kernel, a quarter of its LDS, 20 KB per workgroup.
+template <int KC, int SR, int OCC>
+__global__ __launch_bounds__(256, OCC) void kernmat_symmulti_kernel(KmArgs p) {
+  constexpr int TS = 64, WT = 2, WS = 32;
+  constexpr int SP = TS + 2;
+  constexpr int NH = TS / SR;
+  constexpr int KP = KC + 2;
+  constexpr int OPER = 2 * TS * KP;
+  constexpr int STAGE = SR * SP;
+  constexpr int BODY = (OPER > STAGE) ? OPER : STAGE;
+  constexpr int MAXP = KC / 4;           // parts per fill (a part is at least 4 packed columns)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                     // [TS][KP]
+  double* Bs = As + TS * KP;             // [TS][KP]
+  double* na = smem + BODY;              // [MAXP][TS]
+  double* nb = na + MAXP * TS;           // [MAXP][TS]
+  double* St = smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const unsigned lin = blockIdx.x;
+  unsigned ti = (unsigned)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+  while ((unsigned long long)ti * (ti + 1) / 2 > lin) --ti;
+  while ((unsigned long long)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+  const unsigned tj = lin - (unsigned)((unsigned long long)ti * (ti + 1) / 2);
+  const long m0 = (long)ti * TS, n0 = (long)tj * TS;
+  const ExpConsts& ec = p.ec;
+
+  double4_t res[WT][WT];
+  {
+    const double r0 = p.product ? p.outer : 0.0;
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j) res[i][j] = (double4_t){r0, r0, r0, r0};
+  }
+
+  int part = p.part_lo;
+  while (part < p.part_hi) {
+    int pe = part, cols = 0;
+    while (pe < p.part_hi && cols + p.parts[pe].kc <= KC) { cols += p.parts[pe].kc; ++pe; }
+    const int c0 = p.parts[part].poff;
+    const int ch = cols >> 1;
+    __syncthreads();
+    for (int idx = tid; idx < TS * ch; idx += 256) {
+      const int r = idx / ch, c2 = (idx - r * ch) * 2;
+      const long rowa = m0 + r, rowb = n0 + r;
+      double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
+      if (rowa < p.n1) va = *reinterpret_cast<const double2_t*>(p.Xp1 + rowa * p.P + c0 + c2);
+      if (rowb < p.n1) vb = *reinterpret_cast<const double2_t*>(p.Xp1 + rowb * p.P + c0 + c2);
+      *reinterpret_cast<double2_t*>(As + r * KP + c2) = va;
+      *reinterpret_cast<double2_t*>(Bs + r * KP + c2) = vb;
+    }
+    for (int idx = tid; idx < (pe - part) * TS; idx += 256) {
+      const int q = idx / TS, r = idx - q * TS;
+      const long rowa = m0 + r, rowb = n0 + r;
+      na[idx] = rowa < p.n1 ? p.Np1[rowa * p.n_parts_total + part + q] : 0.0;
+      nb[idx] = rowb < p.n1 ? p.Np1[rowb * p.n_parts_total + part + q] : 0.0;
+    }
+    __syncthreads();
+    for (int q = part; q < pe; ++q) {
+      const PartDev& pd = p.parts[q];
+      const int off = pd.poff - c0;
+      double4_t acc[WT][WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      const double* as = As + (wm * WS + l15) * KP + off + l4;
+      const double* bs = Bs + (wn * WS + l15) * KP + off + l4;
+      for (int kk = 0; kk < pd.kc; kk += 4) {
+        double a[WT], b[WT];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) a[t] = as[t * 16 * KP + kk];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) b[t] = bs[t * 16 * KP + kk];
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      const bool se = (pd.kind == DFH_KERNEL_SE);
+      const double* naq = na + (q - part) * TS;
+      const double* nbq = nb + (q - part) * TS;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double nai = naq[wm * WS + i * 16 + l4 + 4 * r];
+#pragma unroll
+          for (int j = 0; j < WT; ++j) {
+            const double nbj = nbq[wn * WS + j * 16 + l15];
+            double kv;
+            if (se) {                    // -dsq/2 = acc - (na/2 + nb/2), see kernmat_sym_kernel
+              double t = acc[i][j][r] - (0.5 * nbj + 0.5 * nai);
+              t = t > 0.0 ? 0.0 : t;
+              kv = pd.scale_c * exp_fast(t, ec);
+            } else {
+              double dsq = (nbj + nai) - 2.0 * acc[i][j][r];
+              dsq = dsq < 0.0 ? 0.0 : dsq;
+              kv = kern_eval(pd, dsq, ec);
+            }
+            res[i][j][r] = p.product ? res[i][j][r] * kv : res[i][j][r] + kv;   // kernel.py:588 / :493
+          }
+        }
+      }
+    }
+    part = pe;
+  }
+
+  const bool diag_tile = (ti == tj);
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        double v = res[i][j][r];
+        if (p.apply_outer && !p.product) v = p.outer * v;                       // kernel.py:494
+        if (diag_tile && (wm * WS + i * 16 + l4 + 4 * r) == (wn * WS + j * 16 + l15)) v += p.diag_add;
+        res[i][j][r] = v;
+      }
+
+  const int npass = diag_tile ? NH : 2 * NH;
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool mirror = pass >= NH;
+    const int h = mirror ? pass - NH : pass;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const int irow = mirror ? (wn * WS + j * 16 + l15) : (wm * WS + i * 16 + l4 + 4 * r);
+          const int icol = mirror ? (wm * WS + i * 16 + l4 + 4 * r) : (wn * WS + j * 16 + l15);
+          if (irow / SR == h) St[(irow - h * SR) * SP + icol] = res[i][j][r];
+        }
+    __syncthreads();
+    const long row_base = (mirror ? n0 : m0) + h * SR;
+    const long col_base = mirror ? m0 : n0;
+    constexpr int RP = TS / 2;
+#pragma unroll
+    for (int q = 0; q < (SR * RP) / 256; ++q) {
+      const int idx = tid + 256 * q;
+      const int r = idx / RP, c2 = (idx % RP) * 2;
+      const long row = row_base + r, col = col_base + c2;
+      if (row < p.n1 && col + 1 < p.n1) {
+        *reinterpret_cast<double2_t*>(p.K + row * p.ldk + col) = *reinterpret_cast<const double2_t*>(St + r * SP + c2);
+      } else if (row < p.n1 && col < p.n1) {
+        p.K[row * p.ldk + col] = St[r * SP + c2];
+      }
+    }
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Cross matrix K(X1, X2), single-part SE / Matern kernels, packed width 8..32: "strip" kernel.
@@ -463,7 +635,15 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
 // The 64 x 64-tile LDS kernel (kernmat_sym_kernel<..., false>) took 1.45 ms on this shape and
 // 0.84 ms (Matern-2.5) for 65536 x 4096 at d = 6, this one 1.1-1.2 ms and 0.5 ms.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int C, int MP>
+// MU: the product of the strip with a vector (the posterior mean K(X*, X) alpha, gp_core.py:174) rides
+// along: every lane accumulates K[row][col] * alpha[col] over the columns it owns, tile after tile;
+// at the end of every block of KM_MU_BLOCK columns the 16 lanes that share a row add up (fixed
+// butterfly) and the row's partial sum of that block is written out.  A second, tiny kernel adds
+// the blocks in order.  Blocks are cut by column index alone and segments consist of whole blocks,
+// so a row's mean does not depend on how many rows the call has or where they start (chunks,
+// shards, Thompson blocks all give the same bits) -- and the 8 n m bytes of the cross matrix are
+// not read again for it.
+template <int KIND, int C, int MP, bool MU = false>
 __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int tiles_per_seg) {
   // 32 rows x 64 (wide packed inputs: 32) columns per wave and tile, at least 2 waves per SIMD (measured
   // 1.40 -> 1.12 ms against 64 x 32 at one wave per SIMD: a lone wave has nothing to cover its own stalls)
@@ -507,6 +687,14 @@ __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int til
   const double s8 = pd.s8, s2 = pd.s2, gsc = pd.scale_c * pd.gfac;
   const double c0 = pd.coeff[0], c1 = pd.coeff[1], c2 = pd.coeff[2], c3 = pd.coeff[3];
   double b[WJ][C], nbh[WJ];
+  double alh[WJ], mu_acc[WI][4];
+  constexpr int TPB = KM_MU_BLOCK / (16 * WJ);        // tiles per mean block
+  if (MU) {
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mu_acc[i][r] = 0.0;
+  }
   auto load_b = [&](long t, double (&bb)[WJ][C], double (&nn)[WJ]) {
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -533,6 +721,13 @@ __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int til
   for (long t = t0; t < t1; ++t) {
     double bn[WJ][C], nbn[WJ];
     load_b(t + 1 < t1 ? t + 1 : t, bn, nbn);
+    if (MU) {               // this tile's alpha (L2-resident): issued here, used after the MFMAs
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) {
+        const long col = t * (16 * WJ) + WJ * l15 + j;
+        alh[j] = col < p.n2 ? p.mu_alpha[col] : 0.0;
+      }
+    }
     double4_t acc[WI][WJ];
 #pragma unroll
     for (int i = 0; i < WI; ++i)
@@ -576,6 +771,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int til
               kv = u * (gsc * exp_fast_neg(-s2 * dist, ec));             // kernel.py:268-269, 298
             }
             kvs[j] = kv;
+            if (MU) mu_acc[i][r] = fma(kv, alh[j], mu_acc[i][r]);
           }
           double* __restrict__ rowp = Kt + (long)(i * 16 + 4 * r) * p.ldk;      // wave-uniform
           if (FULL) {
@@ -593,6 +789,19 @@ __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int til
     };
     if (rows_full && n0 + 16 * WJ <= p.n2) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    if (MU && ((t + 1) % TPB == 0 || t + 1 == t1)) {          // a mean block is complete
+      const long blk = t / TPB;
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = mu_acc[i][r];
+          v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+          const long row = m0 + i * 16 + l4 + 4 * r;
+          if (l15 == 0 && row < p.n1) p.mu_part[row * p.mu_nblk + blk] = v;
+          mu_acc[i][r] = 0.0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       nbh[j] = nbn[j];
@@ -600,6 +809,15 @@ __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int til
       for (int c = 0; c < C; ++c) b[j][c] = bn[j][c];
     }
   }
+}
+
+// mu[row] = the mean blocks of the row added in order
+__global__ void k_mu_finish(const double* __restrict__ part, long n, int nblk, double* __restrict__ mu) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += part[row * nblk + b];
+  mu[row] = s;
 }
 
 template <int KIND, int MP>
@@ -612,9 +830,26 @@ int launch_strip(dfh_ctx* ctx, KmArgs a, int C) {
   long segs = (want_waves + strips - 1) / strips;
   if (segs > ntile) segs = ntile;
   if (segs < 1) segs = 1;
-  const int tps = (int)((ntile + segs - 1) / segs);
+  int tps = (int)((ntile + segs - 1) / segs);
+  if (a.mu_part) {                                   // segments of whole mean blocks
+    const int tpb = KM_MU_BLOCK / tile_cols;
+    tps = (tps + tpb - 1) / tpb * tpb;
+  }
   segs = (ntile + tps - 1) / tps;
   dim3 grid((unsigned)segs, (unsigned)((strips + 3) / 4));
+  if (a.mu_part) {
+    switch (C) {
+      case 2: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 2, MP, true>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+      case 4: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 4, MP, true>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+      case 6: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 6, MP, true>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+      default: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 8, MP, true>), grid, dim3(256), 0, ctx->stream, a, tps); break;
+    }
+    DFH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mu_finish, dim3((unsigned)((a.n1 + 255) / 256)), dim3(256), 0, ctx->stream, a.mu_part, (long)a.n1,
+                       a.mu_nblk, a.mu_out);
+    DFH_LAUNCH_CHECK();
+    return DFH_OK;
+  }
   switch (C) {
     case 2: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 2, MP>), grid, dim3(256), 0, ctx->stream, a, tps); break;
     case 4: hipLaunchKernelGGL((kernmat_strip_kernel<KIND, 4, MP>), grid, dim3(256), 0, ctx->stream, a, tps); break;
@@ -1383,10 +1618,12 @@ int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob,
 int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bool apply_outer,
                    const double* Xp1, const double* Np1, int64_t n1, const double* Xp2,
                    const double* Np2, int64_t n2, bool symmetric, double diag_add, double* K,
-                   int64_t ldk) {
+                   int64_t ldk, const double* mu_alpha, double* mu_out, bool* mu_done) {
+  if (mu_done) *mu_done = false;
   if (n1 <= 0 || n2 <= 0) return DFH_OK;
   DFH_ARG(n1 < (1LL << 31) && n2 < (1LL << 31));
   KmArgs a;
+  a.mu_alpha = nullptr; a.mu_part = nullptr; a.mu_out = nullptr; a.mu_nblk = 0;
   a.ec = kExpConsts;
   a.sXp = a.sNp = a.sK = a.sBlob = 0; a.diag_adds = nullptr;
   a.Xp1 = Xp1; a.Np1 = Np1; a.Xp2 = Xp2; a.Np2 = Np2;
@@ -1440,6 +1677,13 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
                             hp.kc >= 8 && hp.kc <= 32 && hp.kc % 8 == 0 && kd.P % 2 == 0 && hp.poff % 2 == 0 &&
                             32 * ldk + 64 < (1LL << 31) && (n1 + 127) / 128 <= 65535 &&
                             (reinterpret_cast<uintptr_t>(Xp1) & 15) == 0 && (reinterpret_cast<uintptr_t>(Xp2) & 15) == 0;
+      static const bool mu_fused = []() { const char* e = getenv("DFH_KM_FUSED_MEAN"); return e ? atoi(e) != 0 : true; }();
+      if (strip_ok && mu_fused && mu_alpha && mu_out && mu_done) {
+        a.mu_nblk = (int)((n2 + KM_MU_BLOCK - 1) / KM_MU_BLOCK);
+        DFH_TRY(scratch_get(ctx, SCR_MUPART, (size_t)n1 * a.mu_nblk * 8, (void**)&a.mu_part));
+        a.mu_alpha = mu_alpha; a.mu_out = mu_out;
+        *mu_done = true;
+      }
       if (strip_ok) {
         if (hp.kind == DFH_KERNEL_SE) {
           for (int i = 0; i < 12; ++i) a.ec.c[i] *= hp.scale_c;      // scale folded into the exp polynomial
@@ -1454,6 +1698,26 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
     }
     DFH_LAUNCH_CHECK();
     return DFH_OK;
+  }
+  if (multi && symmetric && kd.stationary && (ldk & 1) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 &&
+      (n1 + 63) / 64 <= 65535 && kd.P % 2 == 0 && (reinterpret_cast<uintptr_t>(Xp1) & 15) == 0) {
+    // symmetric Gram of an additive / product kernel: lower-triangle tiles, parts adjacent and <= 16 columns wide
+    static const bool symmulti_on = []() { const char* e = getenv("DFH_KM_SYMMULTI"); return e ? atoi(e) != 0 : true; }();
+    bool ok = symmulti_on;
+    for (int g = part_lo; g < part_hi && ok; ++g) {
+      ok = kd.parts[g].kc <= 16 && kd.parts[g].poff % 2 == 0 &&
+           (g == part_lo || kd.parts[g].poff == kd.parts[g - 1].poff + kd.parts[g - 1].kc);
+    }
+    if (ok) {
+      constexpr int KCM = 16, SRM = 32;
+      constexpr int oper = 2 * 64 * (KCM + 2), stage = SRM * 66;
+      constexpr int smem = ((oper > stage ? oper : stage) + 2 * (KCM / 4) * 64) * 8;
+      const int64_t T = (n1 + 63) / 64;
+      hipLaunchKernelGGL((kernmat_symmulti_kernel<KCM, SRM, 5>), dim3((unsigned)(T * (T + 1) / 2)), dim3(256), smem,
+                         ctx->stream, a);
+      DFH_LAUNCH_CHECK();
+      return DFH_OK;
+    }
   }
   const int64_t rows_per_launch = 65535LL * KM_BM;
   for (int64_t r0 = 0; r0 < n1; r0 += rows_per_launch) {
