@@ -32,7 +32,7 @@ constexpr int PBP = 65;      // LDS row stride
 constexpr unsigned SYNC_ST_RING = 1;      // an LDS column ring flag never came up (factor64_waves)
 constexpr unsigned SYNC_ST_FUSED = 2;     // a strip of the one-launch panel waited too long for another strip
 constexpr unsigned SYNC_ST_GATE = 4;      // a gate kernel / resident diagonal kernel waited too long for another launch
-constexpr int SPIN_LIMIT_DEFAULT = 1 << 23;   // polls of ~1 us each: seconds, far beyond any legitimate wait
+constexpr int SPIN_LIMIT_DEFAULT = 1 << 21;   // polls of ~0.5 us each: a second, a few hundred times the longest legitimate wait
 
 // ---------------------------------------------------------------------------------------------
 // 64 x 64 pivot-block kernels.  The block is factored by the four waves of a workgroup without
@@ -717,6 +717,8 @@ __device__ __forceinline__ void fused_wait(const int* p, int target, const Fused
     int spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > a.spin_limit) { atomicOr(a.status, (unsigned long long)what); break; }
+      // somebody else has already given up: this factorisation is going to be repeated anyway
+      if ((spins & 63) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
       __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -918,6 +920,7 @@ __global__ __launch_bounds__(64) void k_gate(const int* __restrict__ p, int targ
     int spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > spin_limit) { atomicOr(status, (unsigned long long)SYNC_ST_GATE); break; }
+      if ((spins & 63) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
       __builtin_amdgcn_s_sleep(8);
     }
   }
