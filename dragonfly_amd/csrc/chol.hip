@@ -1587,47 +1587,6 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
 // resident look-ahead with its inverse-based panel solve; a hand-off timeout -- and repeats itself on
 // the conservative schedule (no inter-workgroup waits, substitution only) when one occurs.  Without
 // it such a failure is DFH_ERR_HIP.
-// rebuild (optional): re-creates the input matrix in A (a failed or abandoned factorisation destroys
-// it).  With it the call may use the schedules whose rare failure modes need a second attempt -- the
-// resident look-ahead with its inverse-based panel solve; a hand-off timeout -- and repeats itself on
-// the conservative schedule (no inter-workgroup waits, substitution only) when one occurs.  Without
-// it such a failure is DFH_ERR_HIP.
-// Two-way recursion for large single matrices:
-//     A = [[A11, .], [A21, A22]] :  L11 = chol(A11) ;  L21 = A21 L11^-T ;  A22 -= L21 L21^T ;  L22 = chol(A22)
-// with the panel solve as the posterior's GEMM-based row solve (trsm_rows: block inverses + refinement
-// where the measured quality asks for it) and the update as ONE lower-triangular product of depth
-// K = n/2.  Half of the flops of the factorisation move from K = 512 trailing updates (52 - 60 TF/s
-// inside the look-ahead schedules) to products of depth n/2 (66 - 68 TF/s), and the two halves
-// are factorised by whatever schedule suits their size.  n = 16384: 32.1 (resident look-ahead) /
-// 34.5 (round 2) -> see DESIGN.md section 7 for the measured numbers.
-static int chol_recursive(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* inv_base, int64_t kb0,
-                          int64_t nblk_total, int64_t* info_pivot, int* refine_all, bool allow_lr, bool safe,
-                          int64_t rec_min) {
-  const int64_t NB = CHOL_NB;
-  double* keep = inv_base + kb0 * NB * NB;
-  if (n <= rec_min) {
-    return cholesky_device_impl(ctx, A, n, lda, keep, info_pivot, 1, 0, 0, refine_all + kb0, false, allow_lr, safe,
-                                nblk_total);
-  }
-  const int64_t n1 = (((n + 1) / 2 + NB - 1) / NB) * NB, n2 = n - n1;
-  DFH_TRY(chol_recursive(ctx, A, n1, lda, inv_base, kb0, nblk_total, info_pivot, refine_all, allow_lr, safe, rec_min));
-  double* A21 = A + n1 * lda;
-  DFH_TRY(trsm_rows(ctx, A, n1, lda, keep, A21, n2, lda, refine_all + kb0, keep + nblk_total * NB * NB));
-  double* A22 = A + n1 * lda + n1;
-  DFH_TRY(gemm_f64(ctx, GEMM_LOWER, n2, n2, n1, -1.0, A21, lda, A21, lda, 1.0, A22, lda, A22, lda));
-  int64_t piv2 = 0;
-  const int rc = chol_recursive(ctx, A22, n2, lda, inv_base, kb0 + n1 / NB, nblk_total, &piv2, refine_all, allow_lr, safe,
-                                rec_min);
-  if (piv2 != 0 && info_pivot) *info_pivot = piv2 + n1;
-  if (rc == DFH_ERR_NOT_PD) dfh_set_error("Matrix is not positive definite (pivot %lld)", (long long)(piv2 + n1));
-  return rc;
-}
-
-// rebuild (optional): re-creates the input matrix in A (a failed or abandoned factorisation destroys
-// it).  With it the call may use the schedules whose rare failure modes need a second attempt -- the
-// resident look-ahead with its inverse-based panel solve; a hand-off timeout -- and repeats itself on
-// the conservative schedule (no inter-workgroup waits, substitution only) when one occurs.  Without
-// it such a failure is DFH_ERR_HIP.
 int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* keep_inv,
                     int64_t* info_pivot, int nbatch, int64_t strideA, int64_t strideKeep, int* refine_out,
                     bool inv64_only, const std::function<int()>* rebuild) {
