@@ -302,3 +302,60 @@ def test_thompson_blocks_in_the_panel_strip_regime(engine):
     mu_b, cov_b = og.eval(Xs[sl], 'covar')
     assert relerr(one, samp[sl]) <= kernel_draw_bound('se', 0.0, ospec.bandwidths, ospec.scale, X, Y - mean_c, noise, Xs[sl],
                                                       mean_c, U[sl], og.draw_samples_blocked(Xs[sl], U[sl], blk), cov_b)
+
+
+@pytest.mark.parametrize('comb', ['additive', 'product'])
+@pytest.mark.parametrize('n', [1, 63, 65, 300, 1100])
+def test_symmetric_gram_of_grouped_kernels(engine, comb, n):
+  """ kernel.py:484-494 / 578-589: the lower-triangle kernel for symmetric Gram matrices of grouped
+      kernels -- groups of 1 ... 16 coordinates (packed widths 4, 8, 12, 16: one to four parts per
+      LDS fill), SE and Matern groups mixed, ragged tile edges; and a group of 17 coordinates, which
+      sends the whole matrix through the generic kernel instead """
+  from dragonfly_amd.engine import KernelSpec
+  rs = np.random.RandomState(n)
+  for sizes in ([1, 3, 5, 7, 13, 2, 16, 4], [5] * 7, [3, 17, 2]):
+    d = sum(sizes)
+    perm = list(rs.permutation(d))
+    groups, at = [], 0
+    for s in sizes:
+      groups.append(perm[at:at + s]); at += s
+    kinds = ['se' if i % 3 else 'matern' for i in range(len(sizes))]
+    nus = [[1.5, 2.5][i % 2] for i in range(len(sizes))]       # (nu = 0.5 on a symmetric matrix: test_kernel_matrix)
+    scales = list(0.5 + rs.rand(len(sizes))) if comb == 'additive' else [1.0] * len(sizes)
+    bws = [0.6 + rs.rand(s) for s in sizes]
+    spec = KernelSpec(comb, d, 1.3, groups=groups, sub_kinds=kinds, sub_scales=scales, sub_nus=nus, sub_bandwidths=bws)
+    subs = [O.KernelSpec(k, len(g), sc, b, nu=nu) for k, g, sc, b, nu in zip(kinds, groups, scales, bws, nus)]
+    ospec = O.KernelSpec(comb, d, 1.3, groups=groups, subs=subs)
+    X = rs.rand(n, d)
+    K = engine.kernel_matrix(spec, X, None, diag_add=0.25)
+    want = ospec(X, X) + 0.25 * np.eye(n)
+    assert np.array_equal(K, K.T)
+    assert relerr(K, want) < 1e-12, (comb, n, sizes, relerr(K, want))
+    # the cross-matrix route (generic kernel) gives the same values off the diagonal
+    Kc = engine.kernel_matrix(spec, X, X.copy())
+    off = ~np.eye(n, dtype=bool)
+    if n > 1:
+      assert relerr(K[off], Kc[off]) < 1e-13
+
+
+@pytest.mark.parametrize('kind,d,n', [('se', 6, 700), ('matern', 20, 1333), ('se', 32, 513), ('matern', 9, 64)])
+def test_posterior_mean_from_the_cross_matrix_pass(engine, kind, d, n):
+  """ gp_core.py:174 accumulated inside the cross-matrix kernel (blocks of 512 columns): against the
+      oracle for ragged candidate counts, and bit for bit the same whatever rows the call holds """
+  rs = np.random.RandomState(d + n)
+  spec, ospec = _spec_pair(kind, d, rs, scale=1.2)
+  X = rs.rand(n, d)
+  Y = np.cos(2 * X.sum(axis=1)) + 0.1 * rs.randn(n)
+  noise = float(Y.var() / 10)
+  og = O.GPOracle(X, Y, ospec, 0.0, noise)
+  gp = engine.gp_fit(spec, X, Y, noise)
+  Xs = rs.rand(2311, d)
+  mu_all, sd_all = gp.predict(Xs)
+  mur, sdr = og.eval_chunked(Xs, chunk=1024)
+  assert relerr(mu_all, mur) < TOL and relerr(sd_all, sdr) < TOL
+  for lo, hi in ((0, 1), (5, 36), (31, 64), (100, 1133), (2000, 2311)):
+    mu, sd = gp.predict(Xs[lo:hi])
+    assert np.array_equal(mu, mu_all[lo:hi]), (lo, hi)
+    assert relerr(sd, sd_all[lo:hi]) < 1e-12          # (few-row solves take a different product kernel)
+  bv, bi, vals = gp.acq_argmax('ucb', Xs, params=(1.5, 0.0), return_vals=True)
+  assert relerr(vals, mur + 1.5 * sdr) < TOL and bi == int(np.argmax(mur + 1.5 * sdr))
