@@ -1601,6 +1601,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   };
   int rc = attempt(rebuild != nullptr, force_safe);
   if (rc != DFH_INTERNAL_RETRY) return rc;
+  static const bool verbose = env_int("DFH_CHOL_VERBOSE", 0) != 0;
+  if (verbose) fprintf(stderr, "dfhip: factorisation of n = %lld repeated on the safe schedule: %s\n", (long long)n, dfh_last_error());
   if (!rebuild || force_safe) return DFH_ERR_HIP;
   DFH_TRY((*rebuild)());
   rc = attempt(false, true);
