@@ -30,7 +30,8 @@ class KernelDesc(C.Structure):
   _fields_ = [('kind', C.c_int32), ('dim', C.c_int32), ('scale', C.c_double), ('nu', C.c_double),
               ('bw', c_double_p), ('n_groups', C.c_int32), ('group_off', c_int32_p),
               ('group_dims', c_int32_p), ('sub_kind', c_int32_p), ('sub_scale', c_double_p),
-              ('sub_nu', c_double_p), ('sub_bw', c_double_p)]
+              ('sub_nu', c_double_p), ('sub_bw', c_double_p), ('group_factor', c_int32_p),
+              ('factor_is_sum', c_int32_p), ('factor_scale', c_double_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/dfhip.h declares

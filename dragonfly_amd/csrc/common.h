@@ -213,12 +213,21 @@ struct PartDev {
   double gfac;     // Matern: Gamma(p+1)/Gamma(2p+1) ; ExpDecay: offset
   double coeff[8]; // Matern: (p+i)!/(i!(p-i)!) ; ExpDecay: powers
   double k0;       // SE / Matern: k_part(x, x) (distance 0); unused for the non-stationary kinds
+  // A part of an ADDITIVE FACTOR of a product kernel (an AdditiveKernel among the kernels of a
+  // CoordinateProductKernel: the multi-fidelity GP with an additive domain model, gp/euclidean_gp.py:696-707):
+  // the factor's parts are adjacent; they are summed (0 + k_1 + k_2 ..., kernel.py:490-493), the sum is
+  // scaled (kernel.py:494) and only then multiplied into the product (kernel.py:588).
+  int fmode;       // 0: a factor of its own ; FM_IN (| FM_BEGIN | FM_END): inside an additive factor
+  int fpad;
+  double fscale;   // FM_END: the additive factor's scale
 };
+constexpr int FM_IN = 4, FM_BEGIN = 1, FM_END = 2;
 constexpr int EXPDECAY_MAX_DIM = 8;
 struct KernDev {
   int kind = 0, dim = 0, n_parts = 0, P = 0;
   bool multi = false;          // additive: sum over parts then outer scale; product: scale * prod over parts
   bool product = false;        // (multi only) combine the parts by multiplication (kernel.py:584-588)
+  bool nested = false;         // (product only) some factor is a sum of parts (PartDev::fmode)
   double outer_scale = 1.0;
   std::vector<PartDev> parts;
   std::vector<int> cols;       // [P] source column per packed column (-1 = padding)

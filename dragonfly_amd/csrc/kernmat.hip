@@ -152,9 +152,19 @@ __device__ __forceinline__ double expdecay_eval(const PartDev& pd, const double*
   return r + pd.gfac;
 }
 
+// One part's value into the running result of a product kernel whose factors may be sums of parts
+// (PartDev::fmode): a plain factor multiplies; inside an additive factor the parts are added up from
+// zero (np.zeros + k_1 + k_2 ..., kernel.py:490-493) and the scaled sum multiplies at its last part.
+__device__ __forceinline__ void combine_nested(const PartDev& pd, double kv, double& res, double& fsum) {
+  if (pd.fmode == 0) { res = res * kv; return; }
+  fsum = (pd.fmode & FM_BEGIN) ? 0.0 + kv : fsum + kv;
+  if (pd.fmode & FM_END) res = res * (pd.fscale * fsum);
+}
+
 // NS: the parts may be polynomial / exponential-decay kernels (an instance of its own: their pow()
-// calls cost the stationary multi-part kernel its registers)
-template <int TJ, bool MULTI, bool NS = false>
+// calls cost the stationary multi-part kernel its registers).  NESTED (with NS): a product kernel
+// with additive factors.
+template <int TJ, bool MULTI, bool NS = false, bool NESTED = false>
 __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
   constexpr int BN = 2 * TJ * 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
   const long m0 = (long)blockIdx.y * KM_BM, n0 = (long)blockIdx.x * BN;
 
   double4_t res[4][TJ];
+  double4_t fsum[NESTED ? 4 : 1][NESTED ? TJ : 1];
   if (MULTI) {
     // additive: 0 + k_1 + k_2 ...; product: scale * k_1 * k_2 ... in the reference's order
     // (kernel.py:584-588: K = scale * ones; K *= kernel(...))
@@ -177,6 +188,12 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < TJ; ++j) res[i][j] = (double4_t){r0, r0, r0, r0};
+  }
+  if (NESTED) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fsum[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   }
 
   for (int part = p.part_lo; part < p.part_hi; ++part) {
@@ -253,8 +270,15 @@ __global__ __launch_bounds__(256, 2) void kernmat_kernel(KmArgs p) {
             dsq = dsq < 0.0 ? 0.0 : dsq;                           // np.clip(.,0,inf), NaN kept
             kv = kern_eval(pd, dsq, ec);
           }
-          if (MULTI) res[i][j][r] = p.product ? res[i][j][r] * kv : res[i][j][r] + kv;   // kernel.py:493 / :588
-          else acc[i][j][r] = kv;
+          if (NESTED) {
+            double rr = res[i][j][r], ff = fsum[i][j][r];
+            combine_nested(pd, kv, rr, ff);
+            res[i][j][r] = rr; fsum[i][j][r] = ff;
+          } else if (MULTI) {
+            res[i][j][r] = p.product ? res[i][j][r] * kv : res[i][j][r] + kv;   // kernel.py:493 / :588
+          } else {
+            acc[i][j][r] = kv;
+          }
         }
       }
     }
@@ -1157,6 +1181,7 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
     for (int i = ty; i < n; i += 16) {
       for (int j = tx; j <= i; j += 16) {
         double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
+        double fsum = 0.0;
         for (int part = 0; part < n_parts; ++part) {
           const PartDev& pd = parts[part];
           const double* xi = Xp + i * P + pd.poff;
@@ -1166,8 +1191,9 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
           double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
           dsq = dsq < 0.0 ? 0.0 : dsq;
           const double kv = kern_eval(pd, dsq, a.ec);
-          if (cand.multi) res = cand.product ? res * kv : res + kv;
-          else res = kv;
+          if (!cand.multi) res = kv;
+          else if (!cand.product) res = res + kv;
+          else combine_nested(pd, kv, res, fsum);          // (a plain factor: res * kv)
         }
         if (cand.multi && !cand.product) res = cand.outer * res;
         if (i == j) {
@@ -1390,6 +1416,7 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
 static int make_part(KernDev* kd, int kind, double scale, double nu, const int* cols, const double* par, int ncols) {
   PartDev pd;
   DFH_TRY(fill_part(pd, kind, scale, nu));
+  pd.fmode = 0; pd.fpad = 0; pd.fscale = 1.0;
   std::vector<double> bw((size_t)ncols);
   if (kind == DFH_KERNEL_POLY) {
     for (int c = 0; c < ncols; ++c) {
@@ -1424,7 +1451,7 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
     std::vector<int> ident(k->dim);
     for (int i = 0; i < k->dim; ++i) ident[i] = i;
     DFH_TRY(make_part(kd, k->kind, k->scale, k->nu, ident.data(), k->bw, k->dim));
-    kd->multi = false; kd->product = false; kd->outer_scale = 1.0;
+    kd->multi = false; kd->product = false; kd->outer_scale = 1.0; kd->nested = false;
     kd->kxx = kd->parts[0].k0;
   } else if (k->kind == DFH_KERNEL_POLY || k->kind == DFH_KERNEL_EXPDECAY) {
     // a product with one factor and outer scale 1 (1.0 * k is exact): the generic multi-part
@@ -1433,12 +1460,16 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
     std::vector<int> ident(k->dim);
     for (int i = 0; i < k->dim; ++i) ident[i] = i;
     DFH_TRY(make_part(kd, k->kind, k->scale, k->nu, ident.data(), k->bw, k->dim));
-    kd->multi = true; kd->product = true; kd->outer_scale = 1.0;
+    kd->multi = true; kd->product = true; kd->outer_scale = 1.0; kd->nested = false;
     kd->stationary = false;
   } else if (k->kind == DFH_KERNEL_ADDITIVE || k->kind == DFH_KERNEL_PRODUCT) {
     DFH_ARG(k->n_groups >= 1 && k->group_off && k->group_dims && k->sub_kind && k->sub_scale && k->sub_bw);
     const bool product = (k->kind == DFH_KERNEL_PRODUCT);
+    const bool nested = product && k->group_factor != nullptr;
+    if (k->group_factor || k->factor_is_sum || k->factor_scale)
+      DFH_ARG(product && k->group_factor && k->factor_is_sum && k->factor_scale);
     double acc = product ? k->scale : 0.0;
+    double facc = 0.0;                              // k(x, x) of the additive factor under way
     for (int g = 0; g < k->n_groups; ++g) {
       const int lo = k->group_off[g], hi = k->group_off[g + 1];
       DFH_ARG(hi > lo);
@@ -1450,10 +1481,30 @@ int kerndev_build_host(const dfh_kernel_desc* k, KernDev* kd) {
                         k->sub_bw + lo, hi - lo));
       if (!kind_is_stationary(sk)) kd->stationary = false;
       const double k0 = kd->parts.back().k0;
-      if (product) acc *= k0;                         // K *= kernel(...)        kernel.py:588
-      else acc += k0;                                 // result += kernel(...)   kernel.py:493
+      PartDev& pd = kd->parts.back();
+      pd.fmode = 0; pd.fpad = 0; pd.fscale = 1.0;
+      if (nested) {
+        const int f = k->group_factor[g];
+        DFH_ARG(f >= 0 && f <= g && (g == 0 ? f == 0 : (f == k->group_factor[g - 1] || f == k->group_factor[g - 1] + 1)));
+        const bool first = g == 0 || k->group_factor[g - 1] != f;
+        const bool last = g + 1 == k->n_groups || k->group_factor[g + 1] != f;
+        if (k->factor_is_sum[f]) {
+          DFH_ARG(sk != DFH_KERNEL_EXPDECAY);       // an additive kernel's groups: SE / Matern / polynomial
+          pd.fmode = FM_IN | (first ? FM_BEGIN : 0) | (last ? FM_END : 0);
+          pd.fscale = k->factor_scale[f];
+          facc = first ? 0.0 + k0 : facc + k0;
+          if (last) acc *= pd.fscale * facc;
+        } else {
+          DFH_ARG(first && last);                   // a plain factor is one group
+          acc *= k0;
+        }
+      } else if (product) {
+        acc *= k0;                                    // K *= kernel(...)        kernel.py:588
+      } else {
+        acc += k0;                                    // result += kernel(...)   kernel.py:493
+      }
     }
-    kd->multi = true; kd->product = product; kd->outer_scale = k->scale;
+    kd->multi = true; kd->product = product; kd->outer_scale = k->scale; kd->nested = nested;
     kd->kxx = !kd->stationary ? 0.0 : (product ? acc : k->scale * acc);        // kernel.py:494
   } else {
     dfh_set_error("unknown kernel kind %d", k->kind);
@@ -1471,6 +1522,7 @@ __global__ void k_prior_diag(const PartDev* __restrict__ parts, int n_parts, int
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   double res = (multi && product) ? outer : 0.0;
+  double fsum = 0.0;
   for (int g = g_lo; g < g_hi; ++g) {
     const PartDev& pd = parts[g];
     double kv;
@@ -1478,7 +1530,8 @@ __global__ void k_prior_diag(const PartDev* __restrict__ parts, int n_parts, int
     else if (pd.kind == DFH_KERNEL_EXPDECAY) kv = expdecay_eval(pd, Xp + i * P + pd.poff, Xp + i * P + pd.poff);
     else kv = pd.k0;
     if (!multi) res = kv;
-    else res = product ? res * kv : res + kv;
+    else if (!product) res = res + kv;
+    else combine_nested(pd, kv, res, fsum);
   }
   if (multi && !product) res = outer * res;
   out[i] = res;
@@ -1644,6 +1697,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<2, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernmat_kernel<2, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
     attr_set = true;
   }
   if (!multi && part_hi == part_lo + 1 && (ldk & 1) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 &&
@@ -1699,7 +1754,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
     DFH_LAUNCH_CHECK();
     return DFH_OK;
   }
-  if (multi && symmetric && kd.stationary && (ldk & 1) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 &&
+  if (multi && symmetric && kd.stationary && !kd.nested && (ldk & 1) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 &&
       (n1 + 63) / 64 <= 65535 && kd.P % 2 == 0 && (reinterpret_cast<uintptr_t>(Xp1) & 15) == 0) {
     // symmetric Gram of an additive / product kernel: lower-triangle tiles, parts adjacent and <= 16 columns wide
     static const bool symmulti_on = []() { const char* e = getenv("DFH_KM_SYMMULTI"); return e ? atoi(e) != 0 : true; }();
@@ -1727,7 +1782,8 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
     if (r0 != 0) b.symmetric = 0;    // only reachable for n1 > 8M rows; diagonal handled in slab 0
     if (multi) {
       dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((rr + KM_BM - 1) / KM_BM));
-      if (kd.stationary) hipLaunchKernelGGL((kernmat_kernel<2, true>), grid, dim3(256), SM2, ctx->stream, b);
+      if (kd.nested) hipLaunchKernelGGL((kernmat_kernel<2, true, true, true>), grid, dim3(256), SM2, ctx->stream, b);
+      else if (kd.stationary) hipLaunchKernelGGL((kernmat_kernel<2, true>), grid, dim3(256), SM2, ctx->stream, b);
       else hipLaunchKernelGGL((kernmat_kernel<2, true, true>), grid, dim3(256), SM2, ctx->stream, b);
     } else {
       dim3 grid((unsigned)((n2 + 127) / 128), (unsigned)((rr + KM_BM - 1) / KM_BM));

@@ -104,10 +104,14 @@ class KernelSpec(object):
   """ Host-side description of a Euclidean kernel, convertible to struct dfh_kernel_desc.
       kind: 'se' | 'matern' | 'poly' (nu = order, bandwidths = dim_scalings) | 'expdecay' (nu =
       offset, bandwidths = powers) | 'additive' | 'product' (coordinate-wise product, kernel.py:541;
-      its factors may be any of the four single kinds, an additive kernel's only se / matern). """
+      its factors may be any of the four single kinds, an additive kernel's se / matern / poly).
+      A product may hold ADDITIVE FACTORS (an AdditiveKernel among its kernels): list the factor's
+      groups like any others and give group_factors[g] = index of the factor group g belongs to
+      (non-decreasing), factor_sums[f] = True for an additive factor, factor_scales[f] = its scale. """
 
   def __init__(self, kind, dim, scale, bandwidths=None, nu=0.0, groups=None, sub_kinds=None,
-               sub_scales=None, sub_nus=None, sub_bandwidths=None):
+               sub_scales=None, sub_nus=None, sub_bandwidths=None, group_factors=None, factor_sums=None,
+               factor_scales=None):
     self.kind = kind
     self.dim = int(dim)
     self.scale = float(scale)
@@ -118,6 +122,7 @@ class KernelSpec(object):
     self.sub_scales = sub_scales
     self.sub_nus = sub_nus
     self.sub_bandwidths = sub_bandwidths
+    self.group_factors, self.factor_sums, self.factor_scales = group_factors, factor_sums, factor_scales
     self._keep = []
 
   def signature(self):
@@ -129,7 +134,8 @@ class KernelSpec(object):
     subs = None if self.sub_bandwidths is None else tuple(_t(b) for b in self.sub_bandwidths)
     kinds = None if self.sub_kinds is None else tuple(self.sub_kinds)
     return (self.kind, self.dim, self.scale, self.nu, _t(self.bandwidths), groups, kinds,
-            _t(self.sub_scales), _t(self.sub_nus), subs)
+            _t(self.sub_scales), _t(self.sub_nus), subs, _t(self.group_factors), _t(self.factor_sums),
+            _t(self.factor_scales))
 
   def to_desc(self):
     """ Builds the ctypes struct.  The arrays it points at are kept alive both on the struct
@@ -171,6 +177,18 @@ class KernelSpec(object):
       d.sub_scale = scales.ctypes.data_as(_lib.c_double_p)
       d.sub_nu = nus.ctypes.data_as(_lib.c_double_p)
       d.sub_bw = bws.ctypes.data_as(_lib.c_double_p)
+      if self.group_factors is not None:
+        if self.kind != 'product':
+          raise ValueError('Additive factors exist in product kernels only.')
+        gf = np.ascontiguousarray(self.group_factors, dtype=np.int32)
+        fs = np.ascontiguousarray([1 if s else 0 for s in self.factor_sums], dtype=np.int32)
+        fsc = _f64(self.factor_scales)
+        if gf.size != ng or fs.size != fsc.size or (ng and int(gf.max()) >= fs.size):
+          raise ValueError('group_factors / factor_sums / factor_scales do not fit the groups.')
+        self._keep += [gf, fs, fsc]
+        d.group_factor = gf.ctypes.data_as(_lib.c_int32_p)
+        d.factor_is_sum = fs.ctypes.data_as(_lib.c_int32_p)
+        d.factor_scale = fsc.ctypes.data_as(_lib.c_double_p)
     else:
       raise ValueError('Unidentified kernel type %s.' % (self.kind))
     d.backing = self._keep[first:]

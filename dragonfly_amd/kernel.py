@@ -411,8 +411,55 @@ class CoordinateProductKernel(_GroupedKernel):
   def set_kernel_hyperparams(self, kernel_idx, **kwargs):
     self.kernel_list[kernel_idx].set_hyperparams(**kwargs)
 
+  @staticmethod
+  def _additive_factor(kern):
+    """ An AdditiveKernel among the product's kernels (ours or, left in place by `install()`, the
+        reference's): the multi-fidelity GP with an additive domain model, euclidean_gp.py:696-707 """
+    return type(kern).__name__ == 'AdditiveKernel' and hasattr(kern, 'kernel_list') and hasattr(kern, 'groupings') \
+           and isinstance(getattr(kern, 'hyperparams', None), dict) and 'scale' in kern.hyperparams
+
+  def has_device_spec(self):
+    for kern in self.kernel_list:
+      if self._additive_factor(kern):
+        if not all(_factor_kind(k) in AdditiveKernel._factor_kinds for k in kern.kernel_list):
+          return False
+      elif _factor_kind(kern) not in self._factor_kinds:
+        return False
+    return True
+
   def to_spec(self, in_dim=None):
-    return super(CoordinateProductKernel, self).to_spec(self.dim if in_dim is None else in_dim)
+    in_dim = self.dim if in_dim is None else in_dim
+    if not any(self._additive_factor(kern) for kern in self.kernel_list):
+      return super(CoordinateProductKernel, self).to_spec(in_dim)
+    # additive factors: their groups are listed with the product's own, in absolute coordinates
+    if len(self.coordinate_list) != len(self.kernel_list):
+      raise ValueError("number of kernels do not correspond to number of groups.")
+    groups, kinds, scales, nus, bws, gfac, fsum, fscale = [], [], [], [], [], [], [], []
+    for f, (kern, coords) in enumerate(zip(self.kernel_list, self.coordinate_list)):
+      coords = [int(c) for c in coords]
+      if self._additive_factor(kern):
+        if len(kern.kernel_list) != len(kern.groupings):
+          raise ValueError("number of kernels do not correspond to number of groups.")
+        members = [(k, [coords[int(c)] for c in grp]) for k, grp in zip(kern.kernel_list, kern.groupings)]
+        allowed = AdditiveKernel._factor_kinds
+        fsum.append(True)
+        fscale.append(kern.hyperparams['scale'])
+      else:
+        members = [(kern, coords)]
+        allowed = self._factor_kinds
+        fsum.append(False)
+        fscale.append(1.0)
+      for k, cols in members:
+        kind = _factor_kind(k)
+        if kind not in allowed:
+          raise TypeError('%s on the device supports %s sub-kernels only, got %s.'
+                          % (type(self).__name__, '/'.join(allowed), type(k)))
+        scale, nu, per_col = _factor_fields(k, kind)
+        groups.append(cols); kinds.append(kind); scales.append(scale); nus.append(nu); bws.append(per_col)
+        gfac.append(f)
+    return KernelSpec('product', in_dim, self.hyperparams['scale'], groups=groups, sub_kinds=kinds,
+                      sub_scales=scales, sub_nus=nus, sub_bandwidths=bws, group_factors=gfac, factor_sums=fsum,
+                      factor_scales=fscale)
 
   def _host_compose(self, X1, X2):
     """ kernel.py:578-589 with each factor evaluated by its own class """

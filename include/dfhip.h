@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFH_ABI_VERSION 1
+#define DFH_ABI_VERSION 2   /* 2: dfh_kernel_desc grew the additive-factor fields at its end */
 
 /* ---- status codes --------------------------------------------------------------------- */
 #define DFH_OK            0
@@ -50,8 +50,8 @@ extern "C" {
                                * y_d)^-powers_d + offset; `nu` = offset, `bw` = powers, dim <= 8.
                                * POLY and EXPDECAY are not stationary: k(x,x) depends on x.  They
                                * are accepted alone and as factors of a PRODUCT (sub_kind, with
-                               * sub_nu = order / offset and sub_bw = scalings / powers), not as
-                               * groups of an ADDITIVE kernel.                                   */
+                               * sub_nu = order / offset and sub_bw = scalings / powers); POLY also
+                               * as a group of an ADDITIVE kernel (gp/euclidean_gp.py:870-879).    */
 
 /* One Euclidean kernel.  For SE / MATERN: `dim`, `scale`, `nu`, `bw[dim]` (dim_bandwidths); POLY /
  * EXPDECAY reuse `nu` and `bw` as described above.
@@ -72,6 +72,16 @@ typedef struct dfh_kernel_desc {
   const double*  sub_scale;   /* [n_groups]                                                  */
   const double*  sub_nu;      /* [n_groups]                                                  */
   const double*  sub_bw;      /* [group_off[n_groups]]                                       */
+  /* PRODUCT only, all three NULL when every group is a factor of its own.  Otherwise an
+   * AdditiveKernel may stand among the product's kernels (the multi-fidelity GP with an additive
+   * domain model, gp/euclidean_gp.py:696-707; kernel.py:461-501 inside kernel.py:578-589): its
+   * groups are listed like any others, group_factor[g] (non-decreasing, 0 .. n_factors-1) says
+   * which factor group g belongs to, and a factor f with factor_is_sum[f] != 0 is
+   * factor_scale[f] * (k_g + k_g' + ...) over its groups (sub_scale[g] = the group kernels' own
+   * scales); a factor with factor_is_sum[f] == 0 has exactly one group and is that kernel.        */
+  const int32_t* group_factor;   /* [n_groups]                                               */
+  const int32_t* factor_is_sum;  /* [n_factors]                                              */
+  const double*  factor_scale;   /* [n_factors]                                              */
 } dfh_kernel_desc;
 
 /* ---- acquisitions ---------------------------------------------------------------------- */

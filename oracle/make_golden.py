@@ -414,6 +414,48 @@ def gen_mf_fitter_case():
   print('wrote mf_fitter_f2_d3_n48')
 
 
+MF_ADDITIVE_OPTS = dict(ml_hp_tune_opt='rand', hp_tune_max_evals=40, hp_tune_criterion='ml', fidel_kernel_type='se',
+                        domain_kernel_type='se', domain_use_additive_gp=True, domain_add_max_group_size=3,
+                        domain_num_groups_per_group_size=2)
+
+
+def gen_mf_fitter_additive_case():
+  """ EuclideanMFGPFitter with an ADDITIVE domain model (euclidean_gp.py:480-486, 622-633, 696-707: the
+      joint kernel is a CoordinateProductKernel whose second kernel is an AdditiveKernel), ML by
+      random search over groupings and continuous hyper-parameters, seeded: the chosen
+      hyper-parameters and grouping, the joint Gram matrix, the fitted GP's predictions. """
+  from dragonfly.gp.euclidean_gp import EuclideanMFGPFitter
+  rs = np.random.RandomState(314)
+  n, fd, dd = 40, 1, 6
+  ZZ, XX = rs.random_sample((n, fd)), rs.random_sample((n, dd))
+  YY = (np.sin(3 * XX[:, :3].sum(axis=1)) + XX[:, 3:].sum(axis=1) ** 2) * (1.0 - 0.4 / (1.0 + 3 * ZZ.sum(axis=1))) \
+       + 0.04 * rs.randn(n)
+  Zs, Xs = rs.random_sample((25, fd)), rs.random_sample((25, dd))
+  res = dict(ZZ=ZZ, XX=XX, YY=YY, Zs=Zs, Xs=Xs)
+  np.random.seed(99)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    fitter = EuclideanMFGPFitter(list(ZZ), list(XX), list(YY), options=Namespace(**MF_ADDITIVE_OPTS))
+    _, gp, hps = fitter.fit_gp()
+  dk = gp.kernel.kernel_list[1]
+  assert type(dk).__name__ == 'AdditiveKernel'
+  res['cts_hps'] = np.array(hps[0], dtype=float)
+  res['dscr_hps'] = np.array(hps[1], dtype=float)
+  res['bounds'] = np.array(fitter.cts_hp_bounds, dtype=float)
+  res['group_sizes'] = np.array([len(grp) for grp in dk.groupings])
+  res['groupings_flat'] = np.array([int(c) for grp in dk.groupings for c in grp])
+  res['lml'] = gp.compute_log_marginal_likelihood()
+  res['noise'], res['scale'] = gp.noise_var, gp.kernel.hyperparams['scale']
+  joint = np.concatenate((ZZ, XX), axis=1)
+  res['K'] = gp.kernel(joint, joint)
+  res['K_cross'] = gp.kernel(np.concatenate((Zs, Xs), axis=1), joint)
+  mu, sd = gp.eval_at_fidel(list(Zs), list(Xs), 'std')
+  res['mu'], res['sd'] = mu, sd
+  res['rand_after'] = np.random.random()
+  np.savez_compressed(os.path.join(OUT, 'mf_fitter_additive_f1_d6_n40.npz'), **res)
+  print('wrote mf_fitter_additive_f1_d6_n40: groups', [list(map(int, grp)) for grp in dk.groupings])
+
+
 def gen_pdoo_cases():
   """ The reference's PDOO (utils/doo.py, oper_utils.py:257-271) on closed-form objectives -- value,
       point and the full query sequence -- and its acquisitions maximised with acq_opt_method
@@ -707,6 +749,10 @@ if __name__ == '__main__':
     sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'mffitter':
     gen_mf_fitter_case()
+    gen_mf_fitter_additive_case()
+    sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'mffitter_additive':
+    gen_mf_fitter_additive_case()
     sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'post_sampling':
     gen_post_sampling_cases()
@@ -729,6 +775,7 @@ if __name__ == '__main__':
   gen_mfgp_case()
   gen_poly_expdecay_cases()
   gen_mf_fitter_case()
+  gen_mf_fitter_additive_case()
   gen_pdoo_cases()
   gen_slice_cases()
   gen_post_sampling_cases()

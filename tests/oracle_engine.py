@@ -18,7 +18,22 @@ def to_oracle_spec(spec):
   subs = [O.KernelSpec(kind, len(grp), sc, bw, nu=nu)
           for kind, grp, sc, nu, bw in zip(spec.sub_kinds, spec.groups, spec.sub_scales, spec.sub_nus,
                                            spec.sub_bandwidths)]
-  return O.KernelSpec(spec.kind, spec.dim, spec.scale, groups=[list(g) for g in spec.groups], subs=subs)
+  groups = [list(g) for g in spec.groups]
+  if getattr(spec, 'group_factors', None) is None:
+    return O.KernelSpec(spec.kind, spec.dim, spec.scale, groups=groups, subs=subs)
+  # a product with additive factors (struct dfh_kernel_desc: group_factor / factor_is_sum / factor_scale):
+  # the additive factor becomes an additive kernel over the union of its groups' columns
+  f_groups, f_subs = [], []
+  for f, is_sum in enumerate(spec.factor_sums):
+    members = [g for g, ff in enumerate(spec.group_factors) if ff == f]
+    if not is_sum:
+      f_groups.append(groups[members[0]]); f_subs.append(subs[members[0]])
+      continue
+    cols = [c for g in members for c in groups[g]]
+    local = [[cols.index(c) for c in groups[g]] for g in members]
+    f_groups.append(cols)
+    f_subs.append(O.KernelSpec('additive', len(cols), spec.factor_scales[f], groups=local, subs=[subs[g] for g in members]))
+  return O.KernelSpec('product', spec.dim, spec.scale, groups=f_groups, subs=f_subs)
 
 
 class OracleFittedGP(object):

@@ -36,13 +36,15 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string():
   lib = _lib.load()
-  assert lib.dfh_abi_version() == 1
+  assert lib.dfh_abi_version() == 2
   assert isinstance(_lib.last_error(), str)
 
 
 def test_kernel_desc_layout():
-  """ struct dfh_kernel_desc: 2 x int32, 2 x double, pointer, int32 (+pad), 6 pointers """
-  assert ctypes.sizeof(_lib.KernelDesc) == 88
+  """ struct dfh_kernel_desc: 2 x int32, 2 x double, pointer, int32 (+pad), 6 pointers; ABI version 2: + the
+      three additive-factor pointers at the end """
+  assert ctypes.sizeof(_lib.KernelDesc) == 112
+  assert _lib.KernelDesc.group_factor.offset == 88 and _lib.KernelDesc.factor_scale.offset == 104
   assert _lib.KernelDesc.scale.offset == 8 and _lib.KernelDesc.bw.offset == 24
   assert _lib.KernelDesc.n_groups.offset == 32 and _lib.KernelDesc.group_off.offset == 40
 

@@ -128,3 +128,87 @@ def test_polynomial_groups_in_an_additive_kernel(engine):
     bv, bi, vals = gp.device_gp.add_ucb_group(j, betas[j], cands[j], return_vals=True)
     assert relerr(vals, want[j]) < 1e-10 and relerr(vals_all[j], want[j]) < 1e-10
     assert bi == int(np.argmax(want[j])) == bis[j] and bv == vals[bi] and bvs[j] == vals_all[j][bi]
+
+
+def _nested_pair(rs, fidel_kind='expdecay'):
+  """ scale * k_fidel(z) * [s_add * (k_1(x_g1) + k_2(x_g2) + k_3(x_g3))] * k_extra(x_g4): a product kernel with an
+      ADDITIVE factor in the middle (euclidean_gp.py:696-707), as our classes and as the oracle describe it """
+  from dragonfly_amd import kernel as K
+  d = 2 + 7 + 2
+  coords = [[0, 1], [2, 3, 4, 5, 6, 7, 8], [9, 10]]
+  groupings = [[4, 0, 6], [1, 5], [3, 2]]                      # relative to the factor's own 7 columns
+  pw, bw_f = 2 * rs.random_sample(2) + 0.2, rs.random_sample(2) + 0.5
+  sc_p = rs.random_sample(3) + 0.4
+  bw2, bw3, bw4 = rs.random_sample(2) + 0.4, rs.random_sample(2) + 0.4, rs.random_sample(2) + 0.6
+  if fidel_kind == 'expdecay':
+    fid, fid_o = K.ExpDecayKernel(2, 1.0, 0.15, pw), O.KernelSpec('expdecay', 2, 1.0, pw, nu=0.15)
+  else:
+    fid, fid_o = K.SEKernel(2, 1.0, bw_f), O.KernelSpec('se', 2, 1.0, bw_f)
+  subs = [K.PolyKernel(3, 2, 0.6, sc_p), K.SEKernel(2, 1.3, bw2), K.MaternKernel(2, 2.5, 0.8, bw3)]
+  subs_o = [O.KernelSpec('poly', 3, 0.6, sc_p, nu=2), O.KernelSpec('se', 2, 1.3, bw2), O.KernelSpec('matern', 2, 0.8, bw3, nu=2.5)]
+  if fidel_kind != 'expdecay':          # an all-stationary variant (constant prior variance, one-launch tuning objective)
+    subs[0], subs_o[0] = K.SEKernel(3, 0.6, sc_p), O.KernelSpec('se', 3, 0.6, sc_p)
+  add, add_o = K.AdditiveKernel(1.7, subs, groupings), O.KernelSpec('additive', 7, 1.7, groups=groupings, subs=subs_o)
+  extra, extra_o = K.MaternKernel(2, 1.5, 1.0, bw4), O.KernelSpec('matern', 2, 1.0, bw4, nu=1.5)
+  kern = K.CoordinateProductKernel(d, 2.1, [fid, add, extra], coords)
+  spec = O.KernelSpec('product', d, 2.1, groups=coords, subs=[fid_o, add_o, extra_o])
+  return kern, spec, d
+
+
+@pytest.mark.parametrize('fidel_kind', ['expdecay', 'se'])
+def test_product_kernel_with_an_additive_factor(engine, fidel_kind):
+  """ struct dfh_kernel_desc's group_factor / factor_is_sum / factor_scale: Gram and cross matrices at
+      ragged sizes, the GP (alpha, lml, mean, std with its prior variance, acquisitions, a joint
+      Thompson block) and the batched tuning objective (one-launch path for n <= 128 and the
+      lock-step path) against the oracle """
+  from dragonfly_amd.gp_core import GP
+  rs = np.random.RandomState(3 if fidel_kind == 'se' else 4)
+  kern, spec, d = _nested_pair(rs, fidel_kind)
+  assert kern.has_device_spec()
+  for n1, n2 in ((1, 1), (70, 131), (300, 257)):
+    X1, X2 = rs.random_sample((n1, d)), rs.random_sample((n2, d))
+    assert relerr(kern(X1, X2), spec(X1, X2)) < 1e-13 and relerr(kern(X1), spec(X1)) < 1e-13
+  n, m = 600, 3000
+  X = rs.random_sample((n, d))
+  Y = np.sin(2 * X[:, 2:9].sum(axis=1)) * (1 - 0.4 / (1 + 3 * X[:, :2].sum(axis=1))) + 0.05 * rs.randn(n)
+  mean_c, noise = float(np.median(Y)), float(Y.var() / 15)
+  gp = GP(list(X), list(Y), kern, lambda x: np.array([mean_c] * len(x)), noise)
+  og = O.GPOracle(X, Y, spec, mean_c, noise)
+  assert not gp._generic
+  assert relerr(gp.alpha, og.alpha) < 1e-10 and abs(gp.compute_log_marginal_likelihood() - og.lml()) <= 1e-10 * abs(og.lml())
+  Xs = rs.random_sample((m, d))
+  mu, sd = gp.eval(Xs, 'std')
+  mur, sdr = og.eval(Xs, 'std')
+  assert relerr(mu, mur) < 1e-10 and relerr(sd, sdr) < 1e-10
+  bv, bi, vals = gp.device_gp.acq_argmax('ei', Xs, params=(float(Y.max()), 0.0), mean_const=mean_c, return_vals=True)
+  want = O.acq_values('ei', mur, sdr, float(Y.max()))
+  assert relerr(vals, want) < 1e-10 and bi == int(np.argmax(want))
+  # the tuning objective of a few such kernels in one call: n = 100 (one launch, stationary kernels only) and n = 600
+  from dragonfly_amd.engine import get_engine
+  for nn in (100, 600):
+    specs, want = [], []
+    for s in (0.7, 1.0, 1.9):
+      k2, o2, _ = _nested_pair(np.random.RandomState(int(10 * s)), fidel_kind)
+      k2.hyperparams['scale'] = s; o2.scale = s
+      specs.append(k2.to_spec())
+      want.append(O.GPOracle(X[:nn], Y[:nn], o2, mean_c, noise).lml())
+    got = get_engine().gp_lml_batch(specs, X[:nn], Y[:nn], [mean_c] * 3, [noise] * 3)
+    assert relerr(got, want) < 1e-10, (nn, got, want)
+
+
+def test_bad_additive_factor_descriptions_are_rejected(engine):
+  from dragonfly_amd.engine import KernelSpec
+  X = np.random.RandomState(0).random_sample((6, 4))
+  base = dict(groups=[[0], [1, 2], [3]], sub_kinds=['se', 'se', 'se'], sub_scales=[1.0] * 3, sub_nus=[0.0] * 3,
+              sub_bandwidths=[np.ones(1), np.ones(2), np.ones(1)])
+  ok = KernelSpec('product', 4, 1.0, group_factors=[0, 1, 1], factor_sums=[False, True], factor_scales=[1.0, 2.0], **base)
+  assert engine.kernel_matrix(ok, X).shape == (6, 6)
+  for gf, fs in (([0, 0, 1], [False, True]),        # a plain factor with two groups
+                 ([1, 0, 1], [True, True]),          # factor indices must not decrease
+                 ([0, 2, 2], [False, True, True])):  # ... nor skip
+    bad = KernelSpec('product', 4, 1.0, group_factors=gf, factor_sums=fs, factor_scales=[1.0] * len(fs), **base)
+    with pytest.raises(ValueError):
+      engine.kernel_matrix(bad, X)
+  with pytest.raises(ValueError):                    # additive factors exist in product kernels only
+    engine.kernel_matrix(KernelSpec('additive', 4, 1.0, group_factors=[0, 1, 1], factor_sums=[False, True],
+                                    factor_scales=[1.0, 1.0], **base), X)

@@ -146,3 +146,27 @@ def test_oracle_product_kernel_matches_reference_mfgp():
   assert relerr(mu, g['mu']) < 1e-10 and relerr(sd, g['sd']) < 1e-9
   _, sdh = og.eval_with_hallucinated_observations(ZXs, np.concatenate([g['Zh'], g['Xh']], axis=1), 'std')
   assert relerr(sdh, g['sdh']) < 1e-9
+
+
+def test_oracle_product_kernel_with_an_additive_factor_matches_the_reference():
+  """ the joint kernel of the reference's MF fitter with an additive domain model (a
+      CoordinateProductKernel whose second kernel is an AdditiveKernel, euclidean_gp.py:696-707) and
+      the GP it fits: the oracle's nested description against the reference's Gram matrix / outputs """
+  g = load_golden('mf_fitter_additive_f1_d6_n40')
+  cts = g['cts_hps']
+  # hyper-parameter layout (euclidean_gp.py:454-486): mean? no -- [log scale] [fidelity bandwidths] [domain bandwidths]
+  # preceded by the GP's own [noise] entries; the fixture also stores what they decode to
+  sizes, flat = g['group_sizes'], g['groupings_flat']
+  groups, at = [], 0
+  for s in sizes:
+    groups.append([int(c) for c in flat[at:at + s]]); at += s
+  n_mean_noise = len(cts) - 1 - 1 - 6
+  log_bw = cts[n_mean_noise + 1:]
+  fid_bw, dom_bw = np.exp(log_bw[:1]), np.exp(log_bw[1:])
+  dom = O.KernelSpec('additive', 6, 1.0, groups=groups, subs=[O.KernelSpec('se', len(grp), 1.0, dom_bw[grp]) for grp in groups])
+  spec = O.KernelSpec('product', 7, float(g['scale']), groups=[[0], [1, 2, 3, 4, 5, 6]],
+                      subs=[O.KernelSpec('se', 1, 1.0, fid_bw), dom])
+  joint = np.concatenate((g['ZZ'], g['XX']), axis=1)
+  assert relerr(spec(joint, joint), g['K']) < 1e-13
+  joint_s = np.concatenate((g['Zs'], g['Xs']), axis=1)
+  assert relerr(spec(joint_s, joint), g['K_cross']) < 1e-13
