@@ -671,7 +671,8 @@ template <int KIND, int C, int MP, bool MU = false>
 __global__ __launch_bounds__(256, 2) void kernmat_strip_kernel(KmArgs p, int tiles_per_seg) {
   // 32 rows x 64 (wide packed inputs: 32) columns per wave and tile, at least 2 waves per SIMD (measured
   // 1.40 -> 1.12 ms against 64 x 32 at one wave per SIMD: a lone wave has nothing to cover its own stalls)
-  constexpr int WI = 2, WJ = (C >= 6 ? 2 : 4);
+  // (with the mean riding along, the 64-column tile of the narrow packings would spill registers)
+  constexpr int WI = 2, WJ = ((C >= 6 || MU) ? 2 : 4);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -848,7 +849,7 @@ template <int KIND, int MP>
 int launch_strip(dfh_ctx* ctx, KmArgs a, int C) {
   // enough waves for 256 CUs x 4 SIMDs x 2: split the columns of a 64-row strip into segments
   const long strips = ((long)a.n1 + 31) / 32;
-  const int tile_cols = C >= 6 ? 32 : 64;
+  const int tile_cols = (C >= 6 || a.mu_part) ? 32 : 64;
   const long ntile = ((long)a.n2 + tile_cols - 1) / tile_cols;
   static const long want_waves = []() { const char* e = getenv("DFH_KM_WAVES"); long v = e ? atol(e) : 8192; return v > 0 ? v : 8192; }();
   long segs = (want_waves + strips - 1) / strips;
