@@ -350,7 +350,9 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=3)
-  ap.add_argument('--warmup', type=int, default=1)
+  # two by default: the ROCm runtime's one-off first-use work (code objects, queue resources: a 50 - 60 ms hole
+  # in the first or second fit of a process, docs/NOTES_r03.md) should not land in the timed steps
+  ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--no-c4-full', action='store_true', help='skip the untimed 2 097 152-candidate single-GPU extra (~35 s)')

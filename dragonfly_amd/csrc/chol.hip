@@ -1244,7 +1244,11 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   // pairs: its chain is bound by launch latency, which the strips do not shorten.
   static const int strips_on = []() { const char* e = getenv("DFH_CHOL_STRIPS"); return e ? atoi(e) : 1; }();
   static const int strips_max_wg = []() { const char* e = getenv("DFH_CHOL_STRIPS_MAX_WG"); return e ? atoi(e) : (1 << 30); }();
-  static const int strips_min_wg = []() { const char* e = getenv("DFH_CHOL_STRIPS_MIN_WG"); return e ? atoi(e) : 513; }();
+  // from how many row strips on: 129 in a lock-step batch (round 3, tools/prof_lml.py: 20 - 64 matrices of
+  // n = 600 ... 2000 gain 5 - 20 % over the 513 of round 2; below ~100 strips the pivot steps win), 513 for a
+  // single matrix (which takes the one-launch panel anyway unless that is switched off)
+  static const int strips_min_env = []() { const char* e = getenv("DFH_CHOL_STRIPS_MIN_WG"); return e ? atoi(e) : -1; }();
+  const int strips_min_wg = strips_min_env >= 0 ? strips_min_env : (nbatch > 1 ? 129 : 513);
   double* T = nullptr;
   if (keep_inv) DFH_TRY(scratch_get(ctx, SCR_CHOLT, (size_t)nbatch * strideT * 8, (void**)&T));
   const int64_t nblk_all = (n + NB - 1) / NB;

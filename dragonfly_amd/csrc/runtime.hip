@@ -87,6 +87,13 @@ extern "C" int dfh_ctx_create(int device, dfh_ctx** out) {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live_ctx.insert(ctx);
   }
+  {
+    // idle blocks the cache may keep: 1/16 of the device (18 GB of the MI355X's 288), at least 2 GiB -- the
+    // buffers of an n = 16384 fit (L alone is 2 GiB) have to fit, or every refit pays a 2 GiB hipFree + hipMalloc
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 16 > ctx->pool_idle_limit) ctx->pool_idle_limit = total_b / 16;
+    else (void)hipGetLastError();
+  }
   if (const char* e = getenv("DFH_POOL_MAX_MIB")) ctx->pool_idle_limit = size_t(strtoull(e, nullptr, 10)) << 20;
   *out = ctx;
   return DFH_OK;
