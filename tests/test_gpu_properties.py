@@ -194,3 +194,30 @@ def test_few_row_posterior_is_batch_invariant_and_matches_the_wide_path(engine, 
     mu1, sd1 = gp.predict(Xs[m - 1:m])                    # the last point of the batch, alone
     assert mu1[0] == mu[m - 1] and sd1[0] == sd[m - 1]
   gp.free()
+
+
+@pytest.mark.parametrize('noise_frac', [1e-5, 1e-8])
+def test_resident_lookahead_factorisation_of_an_ill_conditioned_matrix(engine, noise_frac):
+  """ n = 12288, SE in d = 3 with little noise (cond(K + noise I) ~ 1e8 / 1e11): the look-ahead panels solve
+      their rows with explicit block inverses, refined on the device where the inverse's measured quality asks
+      for it -- or the factorisation is repeated by substitution when that is not enough.  Either way the
+      factor must be backward stable: || K + noise I - L L^T || <= 1e-13 ||K||, like LAPACK's. """
+  from dragonfly_amd.engine import KernelSpec
+  n, d = 12288, 3
+  rs = np.random.RandomState(77)
+  X = rs.random_sample((n, d))
+  Y = np.sin(3 * X.sum(axis=1)) + 0.01 * rs.randn(n)
+  spec = KernelSpec('se', d, float(Y.var()), np.full(d, 0.35))
+  noise = float(Y.var() * noise_frac)
+  gp = engine.gp_fit(spec, X, Y, noise)
+  assert max(gp.refine_steps()) >= 1           # (the case is meant to need the refinement: its first block does)
+  K, L = gp.get_K(), gp.get_L()
+  extra = 0.0 if gp.jitter_power is None else 10.0 ** gp.jitter_power * (np.abs(np.diag(K)).max() + noise)
+  R = K - engine.gemm(L, L)
+  R[np.diag_indices(n)] += noise + extra
+  assert np.abs(R).max() / np.abs(K).max() < 1e-13, (np.abs(R).max() / np.abs(K).max(), gp.jitter_power, gp.refine_steps())
+  alpha = gp.get_alpha()
+  res = K.dot(alpha) + (noise + extra) * alpha - Y
+  # the solve's backward error: residual against |K| |alpha| + |y| (alpha itself is large at this conditioning)
+  assert np.abs(res).max() <= 1e-10 * (np.abs(K).max() * np.abs(alpha).sum() + np.abs(Y).max())
+  gp.free()
