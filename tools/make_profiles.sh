@@ -40,10 +40,10 @@ python tools/rocpd_pmc_traffic.py $P/bench_FETCH_SIZE/bench_results.db $P/bench_
 echo "rocprofv3 --kernel-trace --pmc <set> -- python tools/pmc_workload.py   (MI355X, tools/profile_round.sh; one --pmc set per pass)"
 echo "pass 1: SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 ; pass 2: FETCH_SIZE ; pass 3: WRITE_SIZE ; pass 4: SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS"
 echo "GRBM_GUI_ACTIVE is summed over the 8 XCDs (divide by 8 for cycles); MfmaUtil = MFMA_BUSY / (GUI_ACTIVE/8 * 1024 SIMDs); executed TF/s = MOPS_F64*512 flop / duration"
-echo "workload: 3x kernel matrix SE n=16384 d=32 + 2x Matern-2.5 (kernmat_sym_kernel) | 3x cross matrix SE 32768x16384 d=32 + 3x Matern-2.5 65536x4096 d=6 (kernmat_strip_kernel) | 3x SYRK n=15872 k=512 lower | 2x GEMM 8192^3 | one n=4096 factorisation | 2x calibration GEMM 32768x128x16384 (A = 4.295 GB read once + B 16.8 MB per XCD)"
+echo "workload: 3x kernel matrix SE n=16384 d=32 + 2x Matern-2.5 (kernmat_sym_kernel) | 3x cross matrix SE 32768x16384 d=32 + 3x Matern-2.5 65536x4096 d=6 (kernmat_strip_kernel) | 3x SYRK n=15872 k=512 lower | 2x GEMM 8192^3 | one n=4096 factorisation | 2x calibration GEMM 32768x128x16384 (A = 4.295 GB read once + B 16.8 MB per XCD) | round 3: 3x symmetric additive Gram n=4096 d=100 20x5 (kernmat_symmulti_kernel, 134 MB out) | fit n=4096 d=6 Matern-2.5 + 2x EI over 65536 candidates (kernmat_strip_kernel<..,true> with the mean fused in: 2.147 GB out, + k_mu_finish, posterior TRSM)"
 echo "FETCH_SIZE calibration: calibration GEMM expects 4.295 + 8*0.0168 = 4.429 GB  => factor 2 for this kernel's 16 B/lane loads (see the last two gemm dispatches of pass 2)"
 echo "WRITE_SIZE calibration: kernmat writes 16384^2*8 = 2.147 GB (cross matrices: 4.295 GB and 2.147 GB); SYRK writes the 128-tiles of the lower triangle, 1.016 GB; 8192^3 writes 0.537 GB"
 echo
-for p in SQ_VALU_MFMA_BUSY_CYCLES FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT; do echo "== pass $p"; python tools/rocpd_pmc_dispatch.py $P/wl_$p/wl_results.db kernmat gemm_f64 k_pack panel_fused diag_step; echo; done
+for p in SQ_VALU_MFMA_BUSY_CYCLES FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT; do echo "== pass $p"; python tools/rocpd_pmc_dispatch.py $P/wl_$p/wl_results.db kernmat gemm_f64 k_pack k_mu_finish panel_fused diag_step; echo; done
 } > profiles/${R}_pmc_summary.txt
 echo "profiles/${R}_* written"

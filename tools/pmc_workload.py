@@ -60,3 +60,22 @@ for _ in range(2):
   eng.gemm(A3, B3, shape=(M, N, K), out=C3)
 eng.sync()
 print('pmc calibration gemm done')
+# round 3: the symmetric Gram matrix of an additive kernel (config 5's shape: n = 4096, d = 100, 20 groups of
+# 5 -> kernmat_symmulti_kernel) and a posterior over 65536 candidates at n = 4096, d = 6 Matern-2.5 (config 2:
+# the cross-matrix strip kernel with the mean fused in, kernmat_strip_kernel<..., true>, + k_mu_finish)
+n5, d5 = 4096, 100
+groups = [list(range(i, i + 5)) for i in range(0, d5, 5)]
+spec5 = KernelSpec('additive', d5, 1.7, groups=groups, sub_kinds=['se'] * 20, sub_scales=[1.0] * 20, sub_nus=[0.0] * 20,
+                   sub_bandwidths=[np.full(5, 0.2 * np.sqrt(5.0))] * 20)
+X5 = eng.to_device(rs.rand(n5, d5))
+K5 = eng.empty((n5, n5))
+for _ in range(3):
+  eng.kernel_matrix(spec5, X5, None, diag_add=0.1, out=K5)
+X6h = rs.rand(4096, 6)
+Y6 = np.sin(3 * X6h.sum(axis=1)) + 0.05 * rs.randn(4096)
+gp6 = eng.gp_fit(spec6, X6h, Y6 - np.median(Y6), float(Y6.var() / 20))
+Xc6 = eng.to_device(rs.rand(65536, 6))
+for _ in range(2):
+  gp6.acq_argmax('ei', Xc6, params=(float(Y6.max()), 0.0), mean_const=float(np.median(Y6)))
+eng.sync()
+print('pmc round-3 kernels done')
