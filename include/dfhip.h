@@ -188,7 +188,16 @@ int dfh_gp_free(dfh_gp* gp);
 
 #define DFH_GET_L        0   /* n x n lower factor (GP.L)                                     */
 #define DFH_GET_ALPHA    1   /* n (GP.alpha)                                                  */
-#define DFH_GET_K        2   /* Posterior for ANY positive semi-definite kernel the caller evaluates itself: GP.build_posterior
+#define DFH_GET_K        2   /* n x n kernel matrix without noise (GP.K_trtr_wo_noise),
+                                recomputed on demand: the fit factors the Gram matrix in place  */
+/* Copies one of the fitted quantities above into the caller's buffer `out` (host or device
+ * memory, sized as the table says).  These are the attributes the reference reads off a GP from outside
+ * (opt/gpb_acquisitions.py:169,171,367,369; gp/gp_core.py:203).  Handles from dfh_gp_fit_gram
+ * keep no kernel: DFH_GET_K returns DFH_ERR_BAD_ARG for them.                                 */
+int dfh_gp_get(dfh_gp* gp, int what, double* out);
+int64_t dfh_gp_n(dfh_gp* gp);
+
+/* Posterior for ANY positive semi-definite kernel the caller evaluates itself: GP.build_posterior
  * (gp/gp_core.py:155-163) with the Gram matrix from the documented override hook
  * GP._get_training_kernel_matrix (:149-153), and GP.eval (:165-190) with the caller's cross matrix.
  * K is n x n (kernel(X, X), without noise); the handle keeps L, alpha and the block inverses, no
@@ -229,9 +238,6 @@ int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, con
                      int64_t d, const double* y, const double* mean_consts, const double* noise_vars,
                      int flags, double* lml_out /* [nb] */, int32_t* jitter_powers /* [nb] or NULL */);
 
-/* n x n kernel matrix without noise (GP.K_trtr_wo_noise)        */
-int dfh_gp_get(dfh_gp* gp, int what, double* out);
-int64_t dfh_gp_n(dfh_gp* gp);
 /* Triangular solves with the factor (solve_lower/upper_triangular, utils/general_utils.py:208-221,
  * as used at gp_core.py:162-163,180) multiply by explicit inverses of the 512 x 512 diagonal
  * blocks of L; where such an inverse M is not good enough -- max|I - M L_bb| above 1e-13
