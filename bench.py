@@ -101,8 +101,18 @@ class PerProcess(object):
     self.world, self.cpg = n_gpus, cpg
     self.rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
-    self.eng0 = Engine(local_rank)
-    self.comm = parallel.RcclComm.from_env(self.eng0)
+    from dragonfly_amd import _lib
+    shared = (os.environ.get('DFH_MGPU_ALLOW_DUPLICATE_DEVICES', '0') not in ('', '0')
+              and n_gpus > 1 and _lib.device_count() < n_gpus)
+    if shared:
+      # TEST MODE, a box with fewer GPUs than ranks: the ranks share devices and exchange through the host
+      # (RCCL refuses two ranks on one device) -- a dry run of this route's plumbing, not a measurement
+      self.eng0 = Engine(local_rank % _lib.device_count())
+      self.comm = parallel.HostExchangeComm.from_env()
+      self.mode = 'DRY RUN: %d processes sharing %d device(s), host-file exchange instead of RCCL' % (n_gpus, _lib.device_count())
+    else:
+      self.eng0 = Engine(local_rank)
+      self.comm = parallel.RcclComm.from_env(self.eng0)
     self.spec, self.prob = spec, prob
     self.Xd = self.eng0.to_device(prob['X'])
     self.yd = self.eng0.to_device(prob['Y'] - prob['mean_c'])
@@ -182,13 +192,43 @@ def oracle_stages(O, kern, X, Y, mean_c, noise, cand_blocks, U_blocks):
   return t, out
 
 
+class _ReferenceFunctions(object):
+  """ Dragonfly's own functions behind the names oracle_stages() calls (used when the reference is
+      importable: DRAGONFLY_REFERENCE points at a checkout -- never the case on the driver's box). """
+
+  def __init__(self, general_utils):
+    self.gu = general_utils
+    self.solve_lower_triangular = general_utils.solve_lower_triangular      # general_utils.py:214-216
+    self.solve_upper_triangular = general_utils.solve_upper_triangular      # general_utils.py:218-220
+
+  def stable_cholesky(self, M, return_power=False):
+    L = self.gu.stable_cholesky(M)                                          # general_utils.py:166-204
+    return (L, None) if return_power else L       # the reference does not say which power it used
+
+
+def cpu_functions(prob):
+  """ (functions, kernel callable, kind): the reference's own kernel object and linear-algebra helpers
+      when DRAGONFLY_REFERENCE names a checkout that imports ('reference'), else the oracle's
+      restatement of them ('port'). """
+  ref_root = os.environ.get('DRAGONFLY_REFERENCE', '')
+  if ref_root and os.path.isdir(os.path.join(ref_root, 'dragonfly')):
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import make_golden                                    # pylint: disable=import-outside-toplevel,import-error
+    make_golden.import_reference()                        # NumPy-2 shim + import; never edits the reference
+    from dragonfly.gp import kernel as ref_kernel         # pylint: disable=import-outside-toplevel,import-error
+    from dragonfly.utils import general_utils as ref_gu   # pylint: disable=import-outside-toplevel,import-error
+    kern = ref_kernel.SEKernel(DIM, prob['scale'], prob['bw'])              # gp/kernel.py:143-177
+    return _ReferenceFunctions(ref_gu), kern, 'reference', 'dragonfly (SEKernel, stable_cholesky, solve_*_triangular) from %s' % ref_root
+  from oracle import ref_numpy as O                       # pylint: disable=import-outside-toplevel
+  return O, O.KernelSpec('se', DIM, prob['scale'], prob['bw']), 'port', 'oracle/ref_numpy.py'
+
+
 def cpu_baseline_and_parity(prob, cands0, U0, eng, spec, cpg=CANDS_PER_GPU):
   """ cpu_baseline: the oracle on this host's cores -- the FULL n = 16384 fit once and three full
       Thompson blocks of 4096 candidates (median block time x 64 blocks; the blocks are
       independent and identical in work).  parity_vs_oracle: the device on the same inputs. """
-  from oracle import ref_numpy as O
   X, Y, mean_c, noise = prob['X'], prob['Y'], prob['mean_c'], prob['noise']
-  kern = O.KernelSpec('se', DIM, prob['scale'], prob['bw'])
+  O, kern, kind, source = cpu_functions(prob)
   nb = 3
   cb = [cands0[b * TS_BLOCK:(b + 1) * TS_BLOCK] for b in range(nb)]
   ub = [U0[b * TS_BLOCK:(b + 1) * TS_BLOCK] for b in range(nb)]
@@ -219,8 +259,8 @@ def cpu_baseline_and_parity(prob, cands0, U0, eng, spec, cpg=CANDS_PER_GPU):
   except Exception as e:    # pylint: disable=broad-except
     single = {'error': repr(e)}
   cpu = {
-    'value': round(full_ms, 1), 'unit': 'ms', 'cores': int(_blas_threads()), 'kind': 'port',
-    'sample': ('oracle/ref_numpy.py (NumPy %s): the full fit at n=%d (kernel matrix, Cholesky, alpha, lml) '
+    'value': round(full_ms, 1), 'unit': 'ms', 'cores': int(_blas_threads()), 'kind': kind,
+    'sample': (source + ' (NumPy %s): the full fit at n=%d (kernel matrix, Cholesky, alpha, lml) '
                'measured once + %d full Thompson blocks of %d candidates at n=%d; value = fit + %d x median '
                'block time (blocks are independent, equal work); %.1f s of CPU work measured'
                % (np.__version__, N_TRAIN, nb, TS_BLOCK, N_TRAIN, n_blocks, measured_s)),
@@ -329,6 +369,34 @@ def other_configs(eng):
   return out
 
 
+def c4_shards_on_one_gpu(runner, eng, spec, prob, result):
+  """ N = 1, strong scaling: the runner holds all 2 097 152 candidates of config 4 on the device. """
+  from dragonfly_amd import parallel
+  cd, ud, m8 = runner.cd[0], runner.ud[0], CANDS_PER_GPU
+  shard = lambda r: (cd.view(r * m8 * DIM, (m8, DIM)), ud.view(r * m8, (m8,)))
+  times = []
+  for _ in range(3):
+    eng.sync()
+    t0 = time.perf_counter()
+    gp = eng.gp_fit(spec, runner.Xd[0], runner.yd[0], prob['noise'])
+    v0, i0 = gp.thompson(*shard(0), block=TS_BLOCK, mean_const=prob['mean_c'])[:2]
+    eng.sync()
+    times.append((time.perf_counter() - t0) * 1e3)
+    if len(times) < 3:
+      gp.free()
+  vals, idxs = [v0], [int(i0)]
+  for r in range(1, 8):
+    v, i = gp.thompson(*shard(r), block=TS_BLOCK, mean_const=prob['mean_c'])[:2]
+    vals.append(v); idxs.append(int(i) + r * m8)
+  gp.free()
+  v_red, i_red = parallel.reduce_argmax(vals, idxs)
+  return {'workload': 'the eight 262144-candidate shards of config 4 (one per GPU of an 8-GPU run) evaluated one after '
+                      'the other on this GPU and reduced like the ranks\' all-gather',
+          'fit_plus_one_shard_ms': round(sorted(times)[1], 3),
+          'reduced_argmax': int(i_red), 'reduced_best': v_red,
+          'equals_timed_step_over_all_candidates': bool(int(i_red) == int(result['idx']) and v_red == result['best'])}
+
+
 def pmc_traffic():
   """ HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over
       this same command (profiles/rNN_pmc_traffic.json, written by tools/rocpd_pmc_traffic.py).
@@ -356,8 +424,9 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--no-c4-full', action='store_true', help='skip the untimed 2 097 152-candidate single-GPU extra (~35 s)')
-  ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
-                  help='weak: 262144 candidates per GPU (default); strong: the 2 097 152 candidates of config 4 split over the GPUs')
+  ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong',
+                  help='strong (default): the 2 097 152 candidates of BASELINE config 4 split over the GPUs, the same problem '
+                       'at every N; weak: 262144 candidates per GPU (config 4\'s per-GPU shard at every N)')
   args = ap.parse_args()
 
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes)
@@ -500,7 +569,15 @@ def main():
       out['configs'] = other_configs(eng)
       # round 3: config 1 through the mirrors, the tuning / append / tree-search workloads and the whole of
       # config 4 on one GPU -- each with the oracle beside it and an equality / parity flag (bench_extras.py)
-      out['configs'].update(BX.run_all(eng, prob, spec, include_c4_full=not args.no_c4_full))
+      # (the whole of config 4 on one GPU is the timed step itself under --scaling strong; its eight
+      #  per-GPU shards -- what each rank of an 8-GPU run evaluates -- one after the other, reduced as the
+      #  ranks' all-gather is: the same winner; the first shard timed, fit included = the weak-scaling step)
+      if args.scaling == 'strong' and not args.no_c4_full and not per_process:
+        try:
+          out['configs']['C4_shards_on_1gpu'] = c4_shards_on_one_gpu(runner, eng, spec, prob, result)
+        except Exception as e:      # pylint: disable=broad-except
+          out['configs']['C4_shards_on_1gpu'] = {'error': repr(e)}
+      out['configs'].update(BX.run_all(eng, prob, spec, include_c4_full=not args.no_c4_full and args.scaling == 'weak'))
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'], out['parity_vs_oracle'] = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec, cpg)
     elif not args.no_cpu_baseline:

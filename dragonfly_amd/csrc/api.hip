@@ -1624,10 +1624,10 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
   struct Stage1 { double* Kct; double* Xsp; double* Nsp; double* mu; };
   Stage1 st[2];
   hipEvent_t ev_in, ev_ready[2], ev_free[2];
-  DFH_TRY(ctx_event(ctx, 1000, &ev_in));
+  DFH_TRY(ctx_event(ctx, EV_TS_BASE, &ev_in));
   for (int p = 0; p < 2; ++p) {
-    DFH_TRY(ctx_event(ctx, 1001 + p, &ev_ready[p]));
-    DFH_TRY(ctx_event(ctx, 1003 + p, &ev_free[p]));
+    DFH_TRY(ctx_event(ctx, EV_TS_BASE + 1 + p, &ev_ready[p]));
+    DFH_TRY(ctx_event(ctx, EV_TS_BASE + 3 + p, &ev_free[p]));
   }
   DFH_HIP(hipEventRecord(ev_in, mainS));
   DFH_HIP(hipStreamWaitEvent(bulkS, ev_in, 0));        // inputs produced on the main stream are ready

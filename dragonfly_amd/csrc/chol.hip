@@ -1274,7 +1274,6 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   const int64_t nblk = (n + NB - 1) / NB;
   static const bool pair_on = []() { const char* e = getenv("DFH_CHOL_PAIR"); return e ? atoi(e) != 0 : true; }();
   static const long pair_min_rem = []() { const char* e = getenv("DFH_CHOL_PAIR_MIN_REM"); return e ? atol(e) : 6144L; }();
-  DFH_ARG(5 * nblk + 4 < 1000);      // event-pool indices >= 1000 belong to the TS pipeline
 
   // ---- resident look-ahead: which panels, and what it needs (nothing may allocate inside the loop:
   //      hipMalloc can wait for the device, and a gate kernel may be waiting for a launch not yet enqueued) ----
@@ -1295,8 +1294,8 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   }
   static const double refine_tol = []() { const char* e = getenv("DFH_REFINE_TOL"); return e ? atof(e) : 1e-13; }();
   hipEvent_t ev_start, ev_done;
-  DFH_TRY(ctx_event(ctx, 0, &ev_start));
-  DFH_TRY(ctx_event(ctx, 1, &ev_done));
+  DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 0, &ev_start));
+  DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 1, &ev_done));
   DFH_HIP(hipEventRecord(ev_start, M));
   DFH_HIP(hipStreamWaitEvent(P, ev_start, 0));
   DFH_HIP(hipStreamWaitEvent(X, ev_start, 0));
@@ -1317,15 +1316,15 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
                         (int64_t)nbatch * ((rem + PB - 1) / PB) >= strips_min_wg;
     hipEvent_t e_panel, e_trail, e_aux, e_diag, e_trail_prev = nullptr, e_aux_prev2 = nullptr;
     hipEvent_t e_copy, e_copy_prev = nullptr, e_copy_prev2 = nullptr;
-    DFH_TRY(ctx_event(ctx, 2 + 5 * kb, &e_panel));
-    DFH_TRY(ctx_event(ctx, 3 + 5 * kb, &e_trail));
-    DFH_TRY(ctx_event(ctx, 4 + 5 * kb, &e_aux));
-    DFH_TRY(ctx_event(ctx, 5 + 5 * kb, &e_diag));
-    DFH_TRY(ctx_event(ctx, 6 + 5 * kb, &e_copy));
-    if (kb >= 1) DFH_TRY(ctx_event(ctx, 3 + 5 * (kb - 1), &e_trail_prev));
-    if (kb >= 2) DFH_TRY(ctx_event(ctx, 4 + 5 * (kb - 2), &e_aux_prev2));
-    if (kb >= 1) DFH_TRY(ctx_event(ctx, 6 + 5 * (kb - 1), &e_copy_prev));
-    if (kb >= 2) DFH_TRY(ctx_event(ctx, 6 + 5 * (kb - 2), &e_copy_prev2));
+    DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 2 + 5 * kb, &e_panel));
+    DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 3 + 5 * kb, &e_trail));
+    DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 4 + 5 * kb, &e_aux));
+    DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 5 + 5 * kb, &e_diag));
+    DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 6 + 5 * kb, &e_copy));
+    if (kb >= 1) DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 3 + 5 * (kb - 1), &e_trail_prev));
+    if (kb >= 2) DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 4 + 5 * (kb - 2), &e_aux_prev2));
+    if (kb >= 1) DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 6 + 5 * (kb - 1), &e_copy_prev));
+    if (kb >= 2) DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 6 + 5 * (kb - 2), &e_copy_prev2));
     // ---- off the chain (stream X): factor blocks into place, 64-block inverses, 512-block inverse, its quality ----
     auto aux_block = [&](hipEvent_t after, hipStream_t X) -> int {     // (X: the stream it runs on)
       StreamSwap on_x(ctx, X);
@@ -1368,7 +1367,7 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         // for the last 0.45 / 1.2 ms).  update(kb-1) cannot start before update(kb-2) has ended anyway.
         if (kb >= 2) {
           hipEvent_t e_trail_prev2;
-          DFH_TRY(ctx_event(ctx, 3 + 5 * (kb - 2), &e_trail_prev2));
+          DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 3 + 5 * (kb - 2), &e_trail_prev2));
           DFH_HIP(hipStreamWaitEvent(Pc, e_trail_prev2, 0));
         }
         FusedArgs fa;
@@ -1544,7 +1543,7 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   DFH_HIP(hipStreamWaitEvent(M, ev_done, 0));
   {
     hipEvent_t e_aux_last;
-    DFH_TRY(ctx_event(ctx, 4 + 5 * (nblk - 1), &e_aux_last));
+    DFH_TRY(ctx_event(ctx, EV_CHOL_BASE + 4 + 5 * (nblk - 1), &e_aux_last));
     DFH_HIP(hipStreamWaitEvent(M, e_aux_last, 0));
   }
 
@@ -1574,10 +1573,16 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
       rc = DFH_ERR_NOT_PD;
     }
   }
-  if (rc == DFH_OK) {
+  if (kb_lr > 0 && (rc == DFH_OK || rc == DFH_ERR_NOT_PD)) {
     // a resident panel solved its rows with the block inverse and at most LR_REFINE_MAX refinement steps
-    // on the device; an inverse so poor that more are due sends the matrix through the substitution schedule
-    for (int64_t kb = 0; kb < kb_lr; ++kb)
+    // on the device; an inverse so poor that more are due sends the matrix through the substitution
+    // schedule.  That also holds when a LATER pivot came out non-positive: the inaccurately solved
+    // panel may be what broke it, and whether the matrix is positive definite (whether the caller's
+    // stable_cholesky ladder adds jitter, general_utils.py:183-203) is for the substitution schedule
+    // to decide.  The failed pivot's own block and those after it hold no meaningful delta.
+    int64_t kb_hi = kb_lr;
+    if (rc == DFH_ERR_NOT_PD) kb_hi = std::min<int64_t>(kb_lr, (ctx->h_info[0] - 1) / CHOL_NB);  // pivots are 1-based
+    for (int64_t kb = 0; kb < kb_hi; ++kb)
       if (refine_steps(deltas[(size_t)kb]) > LR_REFINE_MAX) {
         dfh_set_error("Cholesky: diagonal block %lld too ill-conditioned for the inverse-based panel solve", (long long)kb);
         return DFH_INTERNAL_RETRY;

@@ -161,6 +161,11 @@ struct StreamSwap {
   ~StreamSwap() { c->stream = old; }
 };
 int ctx_event(dfh_ctx* ctx, size_t idx, hipEvent_t* out);   // lazily created, untimed
+// index ranges of the context's event pool: the Thompson pipeline's five events come first, the
+// factorisation's 2 + 5 per panel follow without an upper limit (the pool grows on demand), so the
+// largest factorisation is set by memory, not by the pool
+constexpr size_t EV_TS_BASE = 0;
+constexpr size_t EV_CHOL_BASE = 8;
 
 struct SectionTimer {
   dfh_ctx* ctx; int which; bool on;

@@ -339,10 +339,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tm, int tn, boo
     }
   }
   if (EXT && is_la) {
-    // the tile is out (the barrier waits for every wave's stores): announce it
+    // announce the tile once it is out: s_barrier does NOT wait for outstanding global stores on
+    // gfx950 (the compiler emits no vmcnt wait ahead of it), so every wave drains its own stores
+    // first; only then may the counter go up
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (tm < 4) __hip_atomic_fetch_add(la_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(la_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -257,30 +257,37 @@ class EuclideanGPFitter(object):
     if self.options.hp_tune_probs == 'adaptive':
       self.hp_tune_sampling_weights[method] += weight_to_add
 
+  def _has_user_mean_func(self):
+    return getattr(self.options, 'mean_func', None) is not None
+
   def _set_up_mean_and_noise_variance_bounds(self):
-    """ gp_core.py:393-416 """
-    if not (hasattr(self.options, 'mean_func') and self.options.mean_func is not None) \
-      and self.options.mean_func_type == 'tune':
-      Y_std = np.sqrt(self.Y_var)
-      if len(self.Y) > 0:
-        Y_median = np.median(self.Y)
-        Y_half_range = 0.5 * (max(self.Y) - min(self.Y))
-      else:
-        Y_median = 0.0
-        Y_half_range = 1.0
-      Y_width = 0.5 * (Y_half_range + Y_std)
-      self.mean_func_bounds = [Y_median - 3 * Y_width, Y_median + 3 * Y_width]
-      self.cts_hp_bounds.append(self.mean_func_bounds)
-      self.param_order.append(["noise_mean", "cts"])
+    """ gp_core.py:393-416.  A tuned constant mean lives within three widths of the median of the
+        labels, the width being the average of half the label range and the label standard deviation
+        (no labels: median 0, half range 1); a tuned noise variance within [0.005, 0.2] Var(Y), searched
+        in logs.  Both come before the kernel's hyper-parameters in the continuous vector. """
+    if self.options.mean_func_type == 'tune' and not self._has_user_mean_func():
+      labels = np.asarray(self.Y, dtype=np.float64)
+      centre, half_range = (np.median(labels), 0.5 * (labels.max() - labels.min())) if labels.size else (0.0, 1.0)
+      width = 0.5 * (half_range + np.sqrt(self.Y_var))
+      self.mean_func_bounds = [centre - 3 * width, centre + 3 * width]
+      self._add_cts_hp("noise_mean", self.mean_func_bounds)      # (sic: the reference's label)
     if self.options.noise_var_type == 'tune':
-      self.noise_var_log_bounds = [np.log(0.005 * self.Y_var), np.log(0.2 * self.Y_var)]
-      self.cts_hp_bounds.append(self.noise_var_log_bounds)
-      self.param_order.append(["noise_var", "cts"])
+      self.noise_var_log_bounds = [np.log(frac * self.Y_var) for frac in (0.005, 0.2)]
+      self._add_cts_hp("noise_var", self.noise_var_log_bounds)
+
+  def _add_cts_hp(self, name, box):
+    self.cts_hp_bounds.append(box)
+    self.param_order.append([name, "cts"])
 
   def _child_set_up(self):
     """ euclidean_gp.py:215-252 """
-    if self.options.kernel_type not in ['se', 'matern', 'default']:
+    if self.options.kernel_type not in ['se', 'matern', 'poly', 'esp', 'default']:
       raise ValueError('Unknown kernel_type. Should be either se, matern or poly.')
+    if self.options.kernel_type == 'poly':
+      raise NotImplementedError('Not implemented Poly kernel yet.')       # euclidean_gp.py:280-282: nor has the reference
+    if self.options.kernel_type == 'esp':
+      raise NotImplementedError('esp kernels are outside the device path (SURVEY.md section 2); '
+                                'use the reference fitter for them.')
     if self.options.noise_var_type not in ['tune', 'label', 'value']:
       raise ValueError('Unknown noise_var_type. Should be either tune, label or value.')
     if self.options.mean_func_type not in ['mean', 'median', 'const', 'zero', 'tune']:
@@ -366,34 +373,36 @@ class EuclideanGPFitter(object):
       self._X_dev = get_engine().to_device(_as_2d_array(self.X))
     return self._X_dev
 
+  # mean_func_type -> the constant a fitted GP takes as its prior mean (gp_core.py:510-521); 'tune'
+  # reads it off the hyper-parameter vector instead, anything else (e.g. 'zero') is 0
+  _CONSTANT_MEANS = {
+    'mean': lambda fitter: np.mean(fitter.Y),
+    'median': lambda fitter: np.median(fitter.Y),
+    'upper_bound': lambda fitter: np.mean(fitter.Y) + 3 * np.std(fitter.Y),
+    'const': lambda fitter: fitter.options.mean_func_const,
+  }
+
   def _mean_and_noise_from_hps(self, gp_cts_hps):
-    """ gp_core.py:506-538: (mean_func, its constant value or None, noise_var, remaining cts hps) """
-    mean_func_const_value = None
-    if hasattr(self.options, 'mean_func') and self.options.mean_func is not None:
-      mean_func = self.options.mean_func
+    """ gp_core.py:506-538: peels the mean value and the log noise variance -- whichever of the two are
+        tuned, in that order -- off the front of the continuous hyper-parameters.  Returns (mean_func,
+        its constant value or None for a user mean function, noise_var, remaining hyper-parameters). """
+    rest = gp_cts_hps
+    if self._has_user_mean_func():
+      mean_func, const = self.options.mean_func, None
     else:
-      if self.options.mean_func_type == 'mean':
-        mean_func_const_value = np.mean(self.Y)
-      elif self.options.mean_func_type == 'median':
-        mean_func_const_value = np.median(self.Y)
-      elif self.options.mean_func_type == 'upper_bound':
-        mean_func_const_value = np.mean(self.Y) + 3 * np.std(self.Y)
-      elif self.options.mean_func_type == 'const':
-        mean_func_const_value = self.options.mean_func_const
-      elif self.options.mean_func_type == 'tune':
-        mean_func_const_value = np.asarray(gp_cts_hps[0]).item()
-        gp_cts_hps = gp_cts_hps[1:]
+      if self.options.mean_func_type == 'tune':
+        const, rest = np.asarray(rest[0]).item(), rest[1:]
       else:
-        mean_func_const_value = 0
-      mean_func = ConstantMean(mean_func_const_value)
-    if self.options.noise_var_type == 'tune':
-      noise_var = np.exp(gp_cts_hps[0])
-      gp_cts_hps = gp_cts_hps[1:]
-    elif self.options.noise_var_type == 'label':
+        const = self._CONSTANT_MEANS.get(self.options.mean_func_type, lambda fitter: 0)(self)
+      mean_func = ConstantMean(const)
+    noise_var_type = self.options.noise_var_type
+    if noise_var_type == 'tune':
+      noise_var, rest = np.exp(rest[0]), rest[1:]
+    elif noise_var_type == 'label':
       noise_var = self.options.noise_var_label * (self.Y.std() ** 2)
     else:
       noise_var = self.options.noise_var_value
-    return mean_func, mean_func_const_value, noise_var, gp_cts_hps
+    return mean_func, const, noise_var, rest
 
   def build_gp(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None, *args, **kwargs):
     """ gp_core.py:501-543 """
@@ -532,21 +541,16 @@ class EuclideanGPFitter(object):
     if hp_tune_criterion != 'ml':
       raise ValueError('hp_tune_criterion should be ml or post_sampling.')
     if self.ml_hp_tune_opt_method in ['direct', 'rand', 'pdoo']:
-      best_cts_hps = None
-      best_dscr_hps = None
-      best_other_params = None
-      best_hps_val = -np.inf
+      # every combination of the discrete hyper-parameters gets its own continuous search; the first
+      # combination reaching the highest likelihood wins (gp_core.py:789-803)
+      winner = (-np.inf, None, None, None)
       for dscr_hps in itertools_product(*self.dscr_hp_vals):
-        opt_cts_val, opt_cts_hps, opt_other_params = \
-           self._optimise_cts_hps_for_given_dscr_hps(dscr_hps)
-        if opt_cts_val > best_hps_val:
-          best_cts_hps = list(opt_cts_hps)
-          best_dscr_hps = list(dscr_hps)
-          best_other_params = opt_other_params
-          best_hps_val = opt_cts_val
+        value, cts_hps, other_params = self._optimise_cts_hps_for_given_dscr_hps(dscr_hps)
+        if value > winner[0]:
+          winner = (value, list(cts_hps), list(dscr_hps), other_params)
+      _, best_cts_hps, best_dscr_hps, best_other_params = winner
       opt_gp = self.build_gp(best_cts_hps, best_dscr_hps, other_gp_params=best_other_params)
-      opt_hps = (best_cts_hps, best_dscr_hps)
-      return 'fitted_gp', opt_gp, opt_hps
+      return 'fitted_gp', opt_gp, (best_cts_hps, best_dscr_hps)
     if self._uses_additive_model():
       sample_cts_hps, sample_dscr_hps, sample_other_gp_params, sample_probs = \
         self._sample_hps_for_rand_exp_sampling_in_add_model()

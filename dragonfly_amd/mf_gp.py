@@ -82,53 +82,57 @@ class EuclideanMFGP(MFGP):
 
   def __init__(self, ZZ, XX, YY, mf_kernel, kernel_scale, fidel_kernel, domain_kernel,
                mean_func, noise_var, *args, **kwargs):
-    if len(ZZ) != 0:
-      self.fidel_dim = len(ZZ[0])
-      self.domain_dim = len(XX[0])
-    if fidel_kernel is not None and domain_kernel is not None:
-      self.fidel_kernel = fidel_kernel
-      self.domain_kernel = domain_kernel
-      self.fidel_dim = fidel_kernel.dim
-      self.domain_dim = domain_kernel.dim
-    elif 'fidel_dim' in kwargs and 'domain_dim' in kwargs:
-      self.fidel_dim = kwargs.pop('fidel_dim')
-      self.domain_dim = kwargs.pop('domain_dim')
+    both_kernels = fidel_kernel is not None and domain_kernel is not None
+    if both_kernels:
+      # the two factor kernels decide the split (and are what get_fidel_kernel / get_domain_kernel hand out)
+      self.fidel_kernel, self.domain_kernel = fidel_kernel, domain_kernel
+      self.fidel_dim, self.domain_dim = fidel_kernel.dim, domain_kernel.dim
     else:
-      raise Exception('Specify fidel_dim and domain_dim.')
+      # a ready-made joint kernel: the split has to be named, the data alone do not decide it
+      # (euclidean_gp.py:364-368)
+      try:
+        self.fidel_dim, self.domain_dim = kwargs.pop('fidel_dim'), kwargs.pop('domain_dim')
+      except KeyError:
+        raise Exception('Specify fidel_dim and domain_dim.')
+    joint_dim = self.fidel_dim + self.domain_dim
+    # joint point = [z, x]: fidelity coordinates first
     self.fidel_coords = list(range(self.fidel_dim))
-    self.domain_coords = list(range(self.fidel_dim, self.fidel_dim + self.domain_dim))
+    self.domain_coords = list(range(self.fidel_dim, joint_dim))
     if mf_kernel is None:
-      mf_kernel = gp_kernel.CoordinateProductKernel(self.fidel_dim + self.domain_dim,
-                                                    kernel_scale, [fidel_kernel, domain_kernel],
+      mf_kernel = gp_kernel.CoordinateProductKernel(joint_dim, kernel_scale, [fidel_kernel, domain_kernel],
                                                     [self.fidel_coords, self.domain_coords])
     super(EuclideanMFGP, self).__init__(ZZ, XX, YY, mf_kernel, mean_func, noise_var,
                                         *args, **kwargs)
 
   def _test_fidel_domain_dims(self, test_fidel_dim, test_domain_dim):
-    """ euclidean_gp.py:379-385 """
-    if test_fidel_dim != self.fidel_dim or test_domain_dim != self.domain_dim:
+    """ euclidean_gp.py:379-385: the reference's message for points of the wrong shape """
+    if (test_fidel_dim, test_domain_dim) != (self.fidel_dim, self.domain_dim):
       raise ValueError('ZZ, XX dimensions should be (%d, %d). Given (%d, %d)'%( \
                        self.fidel_dim, self.domain_dim, test_fidel_dim, test_domain_dim))
 
   def get_ZX_from_ZZ_XX(self, ZZ, XX):
-    """ euclidean_gp.py:387-403 """
-    ordering = np.argsort(self.fidel_coords + self.domain_coords)
+    """ euclidean_gp.py:387-403.  With the fidelity coordinates first the reference's re-ordering of
+        the concatenated coordinates is the identity, so the joint point is the concatenation: a list
+        of rows for a list of points, one vector for a single point, [] for no points. """
     if hasattr(ZZ, '__iter__') and len(ZZ) == 0:
       return []
-    if hasattr(ZZ[0], '__iter__'):
-      self._test_fidel_domain_dims(len(ZZ[0]), len(XX[0]))
-      ZX_unordered = np.concatenate((np.array(ZZ), np.array(XX)), axis=1)
-      return list(ZX_unordered[:, ordering])
-    self._test_fidel_domain_dims(len(ZZ), len(XX))
-    return np.concatenate((ZZ, XX))[ordering]
+    single = not hasattr(ZZ[0], '__iter__')
+    if single:
+      self._test_fidel_domain_dims(len(ZZ), len(XX))
+      return np.concatenate((ZZ, XX))
+    self._test_fidel_domain_dims(len(ZZ[0]), len(XX[0]))
+    return list(np.hstack((np.asarray(ZZ), np.asarray(XX))))
+
+  def _training_rows(self, rows, data_idxs):
+    return list(rows[:self.num_tr_data]) if data_idxs is None else [rows[i] for i in data_idxs]
 
   def get_domain_pts(self, data_idxs=None):
-    data_idxs = data_idxs if data_idxs is not None else range(self.num_tr_data)
-    return [self.XX[i] for i in data_idxs]
+    """ euclidean_gp.py:405-408 """
+    return self._training_rows(self.XX, data_idxs)
 
   def get_fidel_pts(self, data_idxs=None):
-    data_idxs = data_idxs if data_idxs is not None else range(self.num_tr_data)
-    return [self.ZZ[i] for i in data_idxs]
+    """ euclidean_gp.py:410-413 """
+    return self._training_rows(self.ZZ, data_idxs)
 
 
 # Options of the multi-fidelity fitter (euclidean_gp.py:75-130); the 'esp' kernels are not part of

@@ -185,6 +185,100 @@ class RcclComm(object):
       pass
 
 
+class HostExchangeComm(object):
+  """ TEST MODE (DFH_MGPU_ALLOW_DUPLICATE_DEVICES=1): the communicator interface of RcclComm for
+      several processes that share ONE device.  RCCL refuses to form a communicator with two ranks
+      on the same GPU, so a one-GPU box cannot run `torch.distributed.run --nproc-per-node N
+      bench.py` over RCCL; with this stand-in the launcher route of bench.py -- environment, shard
+      arithmetic, global indices, the reduce, the rank-0 JSON -- is exercised there all the same.
+      The pairs travel through files in the private rendezvous directory, one file per rank and
+      collective, named by a nonce rank 0 publishes; the reduce is the library's (dfh_reduce_argmax).
+      Never selected unless the switch is set: a production launch goes through RcclComm. """
+
+  def __init__(self, rank, world_size, key=None, timeout=600.0):
+    self.rank, self.size, self.timeout = int(rank), int(world_size), timeout
+    nonce, self._id_path = exchange_unique_id(self.rank, lambda: os.urandom(16), key=key, timeout=timeout, nbytes=16)
+    self._stem = os.path.join(_rendezvous_dir(), 'dfhip_hostx_%s' % nonce.hex())
+    self._seq = 0
+    self._mine = []
+
+  @classmethod
+  def from_env(cls, key=None):
+    return cls(int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), key=key)
+
+  def _allgather(self, row):
+    """ every rank's row (float64 vector of equal length), in rank order """
+    row = np.ascontiguousarray(row, dtype=np.float64).reshape(-1)
+    name = lambda r: '%s_%d_%d.bin' % (self._stem, self._seq, r)
+    tmp = name(self.rank) + '.tmp'
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+    with os.fdopen(fd, 'wb') as f:
+      f.write(row.tobytes())
+    os.replace(tmp, name(self.rank))
+    out = np.empty((self.size, len(row)))
+    deadline = time.time() + self.timeout
+    for r in range(self.size):
+      while True:
+        try:
+          with open(name(r), 'rb') as f:
+            blob = f.read()
+          if len(blob) == row.nbytes:
+            out[r] = np.frombuffer(blob, dtype=np.float64)
+            break
+        except OSError:
+          pass
+        if time.time() > deadline:
+          raise RuntimeError('HostExchangeComm: rank %d never wrote collective %d.' % (r, self._seq))
+        time.sleep(0.001)
+    # every rank has WRITTEN this collective, hence finished READING the one before: its files can go
+    for path in self._mine:
+      try:
+        os.remove(path)
+      except OSError:
+        pass
+    self._mine = [name(self.rank)]
+    self._seq += 1
+    return out
+
+  def allgather_argmax(self, local_val, local_idx):
+    pair = np.empty(2)
+    pair[0] = float(local_val)
+    pair[1:].view(np.int64)[0] = int(local_idx)          # the index travels as its 8 bytes
+    rows = self._allgather(pair)
+    return reduce_argmax(rows[:, 0], np.ascontiguousarray(rows[:, 1]).view(np.int64))
+
+  def allgather_rows(self, row, is_owner):
+    row = np.ascontiguousarray(row, dtype=np.float64).reshape(-1)
+    rows = self._allgather(np.concatenate([[1.0 if is_owner else 0.0], row]))
+    owners = np.nonzero(rows[:, 0] == 1.0)[0]
+    if len(owners) == 0:
+      raise RuntimeError('allgather_rows: no rank owns the row.')
+    return rows[owners[0], 1:].copy()
+
+  def allreduce_max(self, values):
+    return self._allgather(np.atleast_1d(values)).max(axis=0)
+
+  def barrier(self):
+    self._allgather([0.0])
+
+  def close(self):
+    """ A rank that closes has finished every read; rank 0 waits until all have and clears the files. """
+    if self._seq < 0:
+      return
+    self._seq = -1
+    import glob      # pylint: disable=import-outside-toplevel
+    open('%s_done_%d' % (self._stem, self.rank), 'wb').close()
+    if self.rank == 0:
+      deadline = time.time() + self.timeout
+      while len(glob.glob(self._stem + '_done_*')) < self.size and time.time() < deadline:
+        time.sleep(0.001)
+      for path in glob.glob(self._stem + '_*') + [self._id_path]:
+        try:
+          os.remove(path)
+        except OSError:
+          pass
+
+
 # ---- one process, N devices -----------------------------------------------------------------
 def _ptr_array(items):
   arr = (C.c_void_p * len(items))()

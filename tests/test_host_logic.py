@@ -173,8 +173,10 @@ def test_fitter_set_up_matches_reference_bounds():
   assert g.ml_hp_tune_opt_method == 'direct' and g.hp_tune_max_evals == min(1e4, max(500, 6 * 50))
   with pytest.raises(ValueError):
     EuclideanGPFitter(list(X), list(Y), options=Namespace(ml_hp_tune_opt='anneal'))
-  with pytest.raises(ValueError):
+  with pytest.raises(NotImplementedError):      # euclidean_gp.py:280-282: 'Not implemented Poly kernel yet.'
     EuclideanGPFitter(list(X), list(Y), options=Namespace(kernel_type='poly'))
+  with pytest.raises(ValueError):               # euclidean_gp.py:222-223
+    EuclideanGPFitter(list(X), list(Y), options=Namespace(kernel_type='expdecay'))
 
 
 def test_domain_stub():
