@@ -44,6 +44,20 @@ import bench_extras as BX       # noqa: E402  pylint: disable=wrong-import-posit
 N_TRAIN, DIM, TS_BLOCK, CANDS_PER_GPU = BC.N_TRAIN, BC.DIM, BC.TS_BLOCK, BC.CANDS_PER_GPU
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak: 256 CU x 128 flop/clk x 2.4 GHz
 HBM_PEAK_TBS = 8.0
+# vector fp64: 256 CU x 64 lanes x 2.4 GHz instructions/s (an FMA counted once; it shares the pipe with the MFMAs)
+FP64_VALU_PEAK_TOPS = 39.3
+VALU_OPS_PER_ELEMENT = {'se': 28.0, 'matern': 45.0}     # epilogue of one kernel-matrix element
+
+
+def fp64_pipe_frac(kind, packed_width, elements, parts_per_element, ms):
+  """ Kernel-matrix kernels whose epilogue (exp / Matern polynomial per element and part) outweighs their
+      HBM traffic are bound by the fp64 pipe, which MFMA and VALU share: the time the pipe needs at its
+      peaks, -2 X1 X2^T on the matrix cores + the epilogue on the vector unit, over the measured time. """
+  t_mfma = 2.0 * packed_width * elements / (FP64_MFMA_PEAK_TFLOPS * 1e12)
+  t_valu = VALU_OPS_PER_ELEMENT[kind] * parts_per_element * elements / (FP64_VALU_PEAK_TOPS * 1e12)
+  return {'bound': 'fp64 pipe (valu_f64 epilogue + MFMA share it)', 'min_ms_mfma': round(t_mfma * 1e3, 4),
+          'min_ms_valu': round(t_valu * 1e3, 4), 'frac_of_fp64_pipe_peak': round((t_mfma + t_valu) / (ms * 1e-3), 4),
+          'frac_of_valu_peak': round(t_valu / (ms * 1e-3), 4)}
 PMC_TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
@@ -51,6 +65,24 @@ def rel(a, b):
   a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
   den = float(np.max(np.abs(b))) if b.size else 1.0
   return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+ELEM_MASK = 1e-3
+
+
+def rel_elem(a, b):
+  """ element-wise relative error (hard part 1): max |a_i - b_i| / |b_i| over the entries
+      with |b_i| >= ELEM_MASK * max|b| (entries near zero have no meaningful relative error) """
+  a, b = np.asarray(a, dtype=float).ravel(), np.asarray(b, dtype=float).ravel()
+  if b.size == 0:
+    return 0.0
+  keep = np.abs(b) >= ELEM_MASK * np.max(np.abs(b))
+  return float(np.max(np.abs(a[keep] - b[keep]) / np.abs(b[keep]))) if keep.any() else 0.0
+
+
+def both(a, b):
+  """ [norm-wise, element-wise] """
+  return [rel(a, b), rel_elem(a, b)]
 
 
 # ---- the two ways to run N GPUs --------------------------------------------------------------
@@ -61,7 +93,14 @@ class InProcess(object):
   def __init__(self, n_gpus, prob, spec, cpg):
     from dragonfly_amd import parallel
     self.world, self.rank, self.cpg = n_gpus, 0, cpg
-    self.mg = parallel.MultiEngine(n_gpus)        # raises if fewer GPUs are visible
+    from dragonfly_amd import _lib
+    ids = None
+    if os.environ.get('DFH_MGPU_ALLOW_DUPLICATE_DEVICES', '0') not in ('', '0') and _lib.device_count() < n_gpus:
+      # TEST MODE, a box with fewer GPUs than ranks: contexts share devices, the pairs are reduced on the host
+      # (RCCL refuses duplicate devices) -- a dry run of this route's plumbing, not a measurement
+      ids = [r % _lib.device_count() for r in range(n_gpus)]
+      self.mode = 'DRY RUN: %d contexts sharing %d device(s), host reduce instead of RCCL' % (n_gpus, _lib.device_count())
+    self.mg = parallel.MultiEngine(n_gpus, device_ids=ids)        # raises if fewer GPUs are visible (outside the test mode)
     self.eng0 = self.mg.engines[0]
     self.spec, self.prob = spec, prob
     self.Xd = [e.to_device(prob['X']) for e in self.mg.engines]
@@ -148,7 +187,7 @@ def _blas_threads():
     return os.cpu_count()
 
 
-def oracle_stages(O, kern, X, Y, mean_c, noise, cand_blocks, U_blocks):
+def oracle_stages(O, kern, X, Y, mean_c, noise, cand_blocks, U_blocks, posterior_chunks=()):
   """ The oracle (oracle/ref_numpy.py: the reference's NumPy/SciPy path restated) stage by stage:
       the fit, then per Thompson block cross matrices / triangular solve / covariance / block
       factorisation + draw.  Returns (timings, results). """
@@ -189,6 +228,15 @@ def oracle_stages(O, kern, X, Y, mean_c, noise, cand_blocks, U_blocks):
     per_block.append(tb)
     out['blocks'].append(dict(mu=mu, sd=np.sqrt(np.diag(cov)), draw=s, argmax=arg, jitter_power=pw))
   t['blocks'] = per_block
+  # posterior mean / std only (GP.eval(X, 'std'), gp_core.py:165-190) on further candidate chunks
+  out['posterior'] = []
+  t0 = time.perf_counter()
+  for Xc in posterior_chunks:
+    K_tetr = kern(Xc, X)
+    V = O.solve_lower_triangular(L, K_tetr.T)
+    cov = kern(Xc, Xc) - V.T.dot(V)
+    out['posterior'].append(dict(mu=mean_c + K_tetr.dot(alpha), sd=np.sqrt(np.diag(cov))))
+  t['posterior'] = time.perf_counter() - t0
   return t, out
 
 
@@ -233,9 +281,13 @@ def cpu_baseline_and_parity(prob, cands0, U0, eng, spec, cpg=CANDS_PER_GPU):
   cb = [cands0[b * TS_BLOCK:(b + 1) * TS_BLOCK] for b in range(nb)]
   ub = [U0[b * TS_BLOCK:(b + 1) * TS_BLOCK] for b in range(nb)]
   kern(X[:256], X[:256]); np.linalg.cholesky(np.eye(64))          # warm-up (first BLAS call)
+  # config 3's candidate stage (posterior over RandomState(203).random_sample((65536, 32))): the oracle on the
+  # first and the last 4096 of them (its O(m^2) covariance forces chunks anyway), the device on all 65536
+  Xs3 = BC.config3_candidates(65536)
+  pc = [Xs3[:TS_BLOCK], Xs3[-TS_BLOCK:]]
   t_all0 = time.perf_counter()
-  t, ref = oracle_stages(O, kern, X, Y, mean_c, noise, cb, ub)
-  measured_s = time.perf_counter() - t_all0
+  t, ref = oracle_stages(O, kern, X, Y, mean_c, noise, cb, ub, posterior_chunks=pc)
+  measured_s = time.perf_counter() - t_all0 - t['posterior']
   fit_s = t['kernel'] + t['chol'] + t['solve']
   block_s = sorted(sum(tb.values()) for tb in t['blocks'])
   n_blocks = cpg // TS_BLOCK
@@ -274,22 +326,84 @@ def cpu_baseline_and_parity(prob, cands0, U0, eng, spec, cpg=CANDS_PER_GPU):
   mu, sd = gp.predict(cands0[:m3])
   mu = mu + mean_c
   _, _, samp, jps = gp.thompson(cands0[:m3], U0[:m3], block=TS_BLOCK, mean_const=mean_c, return_samples=True)
+  cat = lambda key: np.concatenate([b[key] for b in ref['blocks']])
+  alpha_d = gp.get_alpha()
   par = {
     'what': 'device vs oracle on the bench inputs: n=%d fit; mu / sd / joint TS draw on the first %d candidates '
-            '(blocks of %d); max|a-b|/max|b|' % (N_TRAIN, m3, TS_BLOCK),
+            '(blocks of %d); *_rel: norm-wise max|a-b|/max|b|; *_rel_elem: element-wise max|a_i-b_i|/|b_i| over the '
+            'entries with |b_i| >= %g max|b|' % (N_TRAIN, m3, TS_BLOCK, ELEM_MASK),
     'lml_rel': abs(gp.lml - ref['lml']) / abs(ref['lml']),
-    'alpha_rel': rel(gp.get_alpha(), ref['alpha']),
-    'mu_rel': rel(mu, np.concatenate([b['mu'] for b in ref['blocks']])),
-    'sd_rel': rel(sd, np.concatenate([b['sd'] for b in ref['blocks']])),
-    'ts_draw_rel': rel(samp, np.concatenate([b['draw'] for b in ref['blocks']])),
+    'alpha_rel': rel(alpha_d, ref['alpha']), 'alpha_rel_elem': rel_elem(alpha_d, ref['alpha']),
+    'mu_rel': rel(mu, cat('mu')), 'mu_rel_elem': rel_elem(mu, cat('mu')),
+    'sd_rel': rel(sd, cat('sd')), 'sd_rel_elem': rel_elem(sd, cat('sd')),
+    'ts_draw_rel': rel(samp, cat('draw')), 'ts_draw_rel_elem': rel_elem(samp, cat('draw')),
     'ts_argmax_equal': [int(np.argmax(samp[b * TS_BLOCK:(b + 1) * TS_BLOCK])) == ref['blocks'][b]['argmax']
                         for b in range(nb)],
     'jitter_power_fit': [gp.jitter_power, ref['jitter_power']],
     'refine_steps_per_block': gp.refine_steps(),
     'jitter_power_blocks': [list(jps), [b['jitter_power'] for b in ref['blocks']]],
   }
+  # ---- config 3's posterior over all 65536 seed-203 candidates: device time, parity on the oracle's chunks ----
+  Xs3d = eng.to_device(Xs3)
+  gp.predict(Xs3d)
+  eng.sync()
+  ts = []
+  for _ in range(3):
+    t0 = time.perf_counter()
+    mu3, sd3 = gp.predict(Xs3d)
+    eng.sync()
+    ts.append((time.perf_counter() - t0) * 1e3)
+  Xs3d.free()
+  mu3 = mu3 + mean_c
+  ms3 = sorted(ts)[1]
+  mu_o = np.concatenate([b['mu'] for b in ref['posterior']])
+  sd_o = np.concatenate([b['sd'] for b in ref['posterior']])
+  pick = np.r_[0:TS_BLOCK, len(Xs3) - TS_BLOCK:len(Xs3)]
+  c3 = {'workload': 'config 3 candidate stage: posterior mean + std (GP.eval(X, "std"), gp_core.py:165-190) over '
+                    'RandomState(203).random_sample((65536, 32)) at n=16384; results copied to the host',
+        'm': int(len(Xs3)), 'ms': round(ms3, 3), 'candidates_per_s': round(len(Xs3) / (ms3 * 1e-3), 1),
+        'frac_of_fp64_mfma_peak_incl_cross_matrix_and_copies': round(float(N_TRAIN) ** 2 * len(Xs3) / (ms3 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        'parity_rows': 'the first and the last %d candidates (the oracle needs %.1f s for them)' % (TS_BLOCK, t['posterior']),
+        'mu_rel': both(mu3[pick], mu_o), 'sd_rel': both(sd3[pick], sd_o), 'rel_format': '[norm-wise, element-wise]'}
   gp.free()
-  return cpu, par
+  return cpu, par, c3
+
+
+def accuracy_vs_truth(eng, prob, spec, n=4096, m=1024):
+  """ SURVEY.md section 7, hard part 1(c): device AND oracle against the extended-precision truth
+      (oracle/ld_truth.c: x87 long double, rounded once), norm-wise and element-wise.  The truth costs O(n^3)
+      long-double operations, so this runs on the first n training points of config 3 (same kernel, noise and
+      mean) with m seed-203 candidates and one joint Thompson draw over them. """
+  from oracle import ref_longdouble as T
+  from oracle import ref_numpy as O
+  X, Y, mean_c, noise = prob['X'][:n], prob['Y'][:n], prob['mean_c'], prob['noise']
+  Xs = BC.config3_candidates(m)
+  U = np.random.RandomState(304).standard_normal(m)
+  og = O.GPOracle(X, Y, O.KernelSpec('se', DIM, prob['scale'], prob['bw']), mean_c, noise)
+  mu_o, sd_o = og.eval(Xs, 'std')
+  draw_o = og.draw_samples_blocked(Xs, U, m)
+  _, cov_o = og.eval(Xs, 'covar')
+  _, pw = O.stable_cholesky(cov_o, return_power=True)
+  jit = 0.0 if pw is None else (10.0 ** pw) * float(np.diag(cov_o).max())
+  t0 = time.perf_counter()
+  tr = T.gp_truth('se', prob['bw'], prob['scale'], X, Y - mean_c, noise, Xs, mean_c, 0.0, ts_normals=U, ts_jitter=jit)
+  truth_s = time.perf_counter() - t0
+  gp = eng.gp_fit(spec, X, Y - mean_c, noise)
+  mu_d, sd_d = gp.predict(Xs)
+  mu_d = mu_d + mean_c
+  _, _, draw_d, pw_d = gp.thompson(Xs, U, block=m, mean_const=mean_c, return_samples=True)
+  dev = dict(alpha=gp.get_alpha(), lml=[gp.lml], mu=mu_d, sd=sd_d, ts_draw=draw_d)
+  orc = dict(alpha=og.alpha, lml=[og.lml()], mu=mu_o, sd=sd_o, ts_draw=draw_o)
+  tru = dict(alpha=tr['alpha'], lml=[tr['lml']], mu=tr['mu'], sd=tr['sd'], ts_draw=tr['draw'])
+  gp.free()
+  out = {'what': 'first %d training points of config 3, %d seed-203 candidates, one joint Thompson draw; truth = the same '
+                 'mathematics in x87 long double (%.1f s); every entry [norm-wise, element-wise over |b_i| >= %g max|b|]'
+                 % (n, m, truth_s, ELEM_MASK),
+         'ts_jitter_power': [None if pw_d[0] is None else int(pw_d[0]), pw]}
+  for key in ('alpha', 'lml', 'mu', 'sd', 'ts_draw'):
+    out[key] = {'device_vs_oracle': both(dev[key], orc[key]), 'device_vs_truth': both(dev[key], tru[key]),
+                'oracle_vs_truth': both(orc[key], tru[key])}
+  return out
 
 
 # ---- other BASELINE configs (untimed extras) ---------------------------------------------------
@@ -363,6 +477,9 @@ def other_configs(eng):
     'trsm_frac_of_fp64_mfma_peak': round(float(n) * n * M / (s['trsm'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
     'kernel_matrix_frac_of_hbm_peak': round(8.0 * n * n / (s['kernmat'] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
     'chol_frac_of_fp64_mfma_peak': round(float(n) ** 3 / 3 / (s['chol'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+    # twenty exponentials per element: this Gram matrix is bound by the vector fp64 unit, not by its 134 MB of HBM
+    # writes (lower-triangle tiles are computed, n (n + 64) / 2 elements, and mirrored)
+    'kernel_matrix_fp64_pipe': fp64_pipe_frac('se', 8 * G, n * (n + 64) / 2.0, G, s['kernmat']),
   }
   for a in (Xd, yd, flat):
     a.free()
@@ -491,6 +608,8 @@ def main():
                  'launch': runner.mode},
       'candidates_per_s': round(cpg * world / (ms_per_step * 1e-3), 1),
       'sections_ms_extra_untimed_step_rank0': {k: round(v, 3) for k, v in sections.items() if v > 0},
+      # the cross matrices K(X*, X) at d = 32 (kernmat_strip_kernel, posterior mean fused in): fp64-pipe-bound
+      'cross_matrix_fp64_pipe': fp64_pipe_frac('se', DIM, float(cpg) * N_TRAIN, 1, sections['cross']) if sections.get('cross', 0) > 0 else None,
       'result': {'lml': result['lml'], 'ts_best': result['best'], 'ts_argmax': int(result['idx'])},
       'roofline': {
         'bound': 'mfma', 'kernel': 'gemm_f64_kernel<NT,128x128> (v_mfma_f64_16x16x4_f64)',
@@ -512,6 +631,8 @@ def main():
         },
       },
       'device': eng.name(),
+      # factorisations that had to be repeated on the hand-off-free schedule so far in this process (expected: 0)
+      'chol_fallbacks': eng.counters()['chol_fallbacks'],
     }
     if not args.no_extras and world == 1:       # (ranks of a multi-process run stay in step: no rank-0-only extras)
       # conditioning of the matrix that was factored (quoted next to the parity numbers):
@@ -579,7 +700,9 @@ def main():
           out['configs']['C4_shards_on_1gpu'] = {'error': repr(e)}
       out['configs'].update(BX.run_all(eng, prob, spec, include_c4_full=not args.no_c4_full and args.scaling == 'weak'))
     if not args.no_cpu_baseline and world == 1:
-      out['cpu_baseline'], out['parity_vs_oracle'] = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec, cpg)
+      out['cpu_baseline'], out['parity_vs_oracle'], c3 = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec, cpg)
+      out.setdefault('configs', {})['C3_posterior'] = c3
+      out['accuracy_vs_truth'] = accuracy_vs_truth(eng, prob, spec)
     elif not args.no_cpu_baseline:
       out['cpu_baseline'] = None
   runner.close()

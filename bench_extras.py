@@ -273,10 +273,67 @@ def config4_full_one_gpu(eng, prob, spec, steps=2):
           'argmax_equals_reduce_over_8_shards': bool(i_full == int(i_red) and v_full == v_red)}
 
 
+def hallucinated_batch(eng, workers=8, m_parity=8192):
+  """ A synchronous batch at size (opt/gpb_acquisitions.py:90-115: every earlier recommendation is a
+      hallucinated in-progress point of the next, gp/gp_core.py:192-220): config 2's GP (n = 4096, Matern-2.5),
+      EI with the hallucinated std, q = 0 .. workers-1 extra rows.  The reference re-factors the (n+q) x (n+q)
+      matrix per call; the device appends q rows to the factor.  Device over all 65536 candidates (timed per q);
+      the same batch over the first m_parity candidates against the oracle (choice and EI values). """
+  from dragonfly_amd.engine import KernelSpec
+  from oracle import ref_numpy as O
+  c = BC.config2()
+  spec = KernelSpec('matern', c['d'], c['scale'], c['bw'], nu=c['nu'])
+  Xd, yd = eng.to_device(c['X']), eng.to_device(c['Y'] - c['mean_c'])
+  gp = eng.gp_fit(spec, Xd, yd, c['noise'])
+
+  def device_batch(cands_host, cands_dev):
+    picks, vals, ms = [], [], []
+    for _ in range(workers):
+      eng.sync()
+      t0 = time.perf_counter()
+      bv, bi, ev = gp.acq_argmax('ei', cands_dev, params=(c['best'], 0.0), mean_const=c['mean_c'],
+                                 X_halluc=np.array([cands_host[i] for i in picks]) if picks else None, return_vals=True)
+      eng.sync()
+      ms.append((time.perf_counter() - t0) * 1e3)
+      picks.append(int(bi)); vals.append(ev)
+    return picks, vals, ms
+  cd = eng.to_device(c['cands'])
+  device_batch(c['cands'], cd)                              # warm-up
+  picks_all, _, ms_all = device_batch(c['cands'], cd)
+  sub = np.ascontiguousarray(c['cands'][:m_parity])
+  sd = eng.to_device(sub)
+  picks_d, vals_d, _ = device_batch(sub, sd)
+  og = O.GPOracle(c['X'], c['Y'], O.KernelSpec('matern', c['d'], c['scale'], c['bw'], nu=c['nu']), c['mean_c'], c['noise'])
+  picks_o, rels, ms_o = [], [], []
+  for w in range(workers):
+    t0 = time.perf_counter()
+    mus, sds = [], []
+    for i0 in range(0, m_parity, 4096):
+      chunk = sub[i0:i0 + 4096]
+      if picks_o:
+        mu, s_h = og.eval_with_hallucinated_observations(chunk, sub[picks_o], 'std')
+      else:
+        mu, s_h = og.eval(chunk, 'std')
+      mus.append(mu); sds.append(s_h)
+    ev = O.acq_values('ei', np.concatenate(mus), np.concatenate(sds), c['best'])
+    ms_o.append((time.perf_counter() - t0) * 1e3)
+    rels.append(_rel(vals_d[w], ev))
+    picks_o.append(O.argmax_first(ev)[1])
+  for a in (cd, sd, Xd, yd):
+    a.free()
+  gp.free()
+  return {'workload': 'synchronous batch of %d by EI with hallucinated in-progress points on config 2\'s GP (n=4096, d=6, '
+                      'Matern-2.5): q = 0..%d extra rows' % (workers, workers - 1),
+          'device_ms_per_q_over_65536_candidates': [round(v, 3) for v in ms_all], 'device_batch_ms': round(sum(ms_all), 3),
+          'device_picks_over_65536': picks_all,
+          'oracle_ms_per_q_over_%d_candidates' % m_parity: [round(v, 1) for v in ms_o],
+          'picks_equal_vs_oracle_over_%d' % m_parity: bool(picks_d == picks_o), 'ei_rel_per_q': rels}
+
+
 def run_all(eng, prob, spec, include_c4_full=True):
   out = {}
   for name, fn in (('C1', lambda: config1(eng)), ('hp_tuning', lambda: hp_tuning(eng)), ('append', lambda: append(eng)),
-                   ('pdoo', lambda: pdoo(eng))):
+                   ('pdoo', lambda: pdoo(eng)), ('hallucinated_batch', lambda: hallucinated_batch(eng))):
     try:
       out[name] = fn()
     except Exception as e:      # pylint: disable=broad-except

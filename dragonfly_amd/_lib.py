@@ -127,6 +127,7 @@ SIGNATURES = {
                                     C.c_double, c_double_p, c_int64_p, c_double_p, c_int64_p]),
   'dfh_mgpu_allgather_argmax': (C.c_int, [C.c_void_p, c_double_p, c_int64_p, c_double_p, c_int64_p]),
   'dfh_ctx_timings': (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+  'dfh_ctx_counters': (C.c_int, [C.c_void_p, c_int64_p]),
   'dfh_ctx_gemm_profile': (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
 }
 
@@ -142,10 +143,12 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
-  if not os.path.exists(LIB_PATH):
+  # DFH_LIB: another build of the same sources (the diagnostics build libdfhip_dbg.so of kernel work)
+  path = os.environ.get('DFH_LIB') or LIB_PATH
+  if not os.path.exists(path):
     raise ImportError('%s not found. Build it with `python -m dragonfly_amd.build` '
-                      '(hipcc, gfx950). dragonfly_amd has no CPU fallback.' % LIB_PATH)
-  lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+                      '(hipcc, gfx950). dragonfly_amd has no CPU fallback.' % path)
+  lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
   for name, (restype, argtypes) in SIGNATURES.items():
     fn = getattr(lib, name)
     fn.restype = restype

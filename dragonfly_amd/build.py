@@ -2,8 +2,9 @@
 
     python -m dragonfly_amd.build [--force] [--debug-hooks]
 
---debug-hooks also compiles the diagnostics entry points of include/dfhip_debug.h (tools/dbg_*.py);
-the default library exports exactly the C-ABI of include/dfhip.h.
+--debug-hooks builds a SECOND library, dragonfly_amd/libdfhip_dbg.so (objects in csrc/_obj_dbg), that
+also holds the diagnostics entry points of include/dfhip_debug.h (tools/dbg_*.py; selected at run time
+with DFH_LIB=/path/to/libdfhip_dbg.so); libdfhip.so exports exactly the C-ABI of include/dfhip.h.
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container;
 the resulting dragonfly_amd/libdfhip.so travels with the repository snapshot to the GPU box.
@@ -44,6 +45,8 @@ def _stale(target, deps):
 def build(force=False, verbose=True, debug_hooks=False):
   """Compile every HIP translation unit for gfx950 and link libdfhip.so. Returns its path."""
   hipcc = _hipcc()
+  OBJ_DIR = os.path.join(CSRC, '_obj_dbg' if debug_hooks else '_obj')         # pylint: disable=invalid-name
+  LIB_PATH = os.path.join(HERE, 'libdfhip_dbg.so' if debug_hooks else 'libdfhip.so')   # pylint: disable=invalid-name
   os.makedirs(OBJ_DIR, exist_ok=True)
   flags = CXXFLAGS + (['-DDFH_DEBUG_HOOKS'] if debug_hooks else []) + os.environ.get('DFH_EXTRA_CXXFLAGS', '').split()
   stamp = os.path.join(OBJ_DIR, 'flags.txt')

@@ -292,10 +292,13 @@ int halluc_prepare(dfh_gp* gp, const double* Xh_user, int64_t q, Halluc* h) {
   DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, gp->Xp, gp->Np, gp->n, false, 0.0, h->Wt, gp->n));
   DFH_TRY(trsm_rows(ctx, gp->L, gp->n, gp->n, gp->inv, h->Wt, q, gp->n, gp->refine.data()));
   // S = K(Xh,Xh) + (noise + jitter) I - Wt Wt^T ; Lh = chol(S)
-  DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, h->Xhp, h->Nhp, q, true, gp->noise_var, h->Lh, q));
-  DFH_TRY(gemm_f64(ctx, 0, q, q, gp->n, -1.0, h->Wt, gp->n, h->Wt, gp->n, 1.0, h->Lh, q, h->Lh, q));
+  const std::function<int()> build_S = [&]() -> int {
+    DFH_TRY(kernmat_packed(ctx, kd, 0, kd.n_parts, true, h->Xhp, h->Nhp, q, h->Xhp, h->Nhp, q, true, gp->noise_var, h->Lh, q));
+    return gemm_f64(ctx, 0, q, q, gp->n, -1.0, h->Wt, gp->n, h->Wt, gp->n, 1.0, h->Lh, q, h->Lh, q);
+  };
+  DFH_TRY(build_S());
   int64_t piv = 0;
-  int rc = cholesky_device(ctx, h->Lh, q, q, nullptr, &piv);
+  int rc = cholesky_device(ctx, h->Lh, q, q, nullptr, &piv, 1, 0, 0, nullptr, false, &build_S);
   if (rc == DFH_ERR_NOT_PD)
     dfh_set_error("augmented (hallucinated) kernel matrix is not positive definite at pivot %lld",
                   (long long)(gp->n + piv));
@@ -725,7 +728,8 @@ extern "C" int dfh_gp_fit_gram(dfh_ctx* ctx, const double* K, int64_t n, const d
       DFH_TRY(build_M());
       SectionTimer t(ctx, DFH_T_CHOL);
       int64_t piv = 0;
-      const int rc = cholesky_device(ctx, gp->L, n, n, gp->inv, &piv, 1, 0, 0, gp->refine.data());
+      const std::function<int()> rebuild_M = build_M;      // (a hand-off time-out repeats on the safe schedule)
+      const int rc = cholesky_device(ctx, gp->L, n, n, gp->inv, &piv, 1, 0, 0, gp->refine.data(), false, &rebuild_M);
       if (rc == DFH_OK) return gp_alpha_and_lml(gp, dy, lml);
       if (rc != DFH_ERR_NOT_PD) return rc;
       project = true;
@@ -904,10 +908,13 @@ extern "C" int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const do
       }
       {
         SectionTimer t(ctx, DFH_T_CHOL);
-        DFH_TRY(kernmat_packed(ctx, kd, 0, parts, true, Xpn, Npn, q, Xpn, Npn, q, true, g2->noise_var, S, n2));
-        DFH_TRY(gemm_f64(ctx, GEMM_LOWER, q, q, n, -1.0, Bm, n2, Bm, n2, 1.0, S, n2, S, n2));
+        const std::function<int()> build_S = [&]() -> int {
+          DFH_TRY(kernmat_packed(ctx, kd, 0, parts, true, Xpn, Npn, q, Xpn, Npn, q, true, g2->noise_var, S, n2));
+          return gemm_f64(ctx, GEMM_LOWER, q, q, n, -1.0, Bm, n2, Bm, n2, 1.0, S, n2, S, n2);
+        };
+        DFH_TRY(build_S());
         int64_t piv = 0;
-        const int rc = cholesky_device(ctx, S, q, n2, nullptr, &piv);
+        const int rc = cholesky_device(ctx, S, q, n2, nullptr, &piv, 1, 0, 0, nullptr, false, &build_S);
         if (rc == DFH_OK) {
           // inverses of the 512-blocks: untouched blocks are copied, the rest recomputed from L'
           const int64_t kb0 = n / NB;            // first diagonal block that contains a new row
@@ -1707,13 +1714,19 @@ extern "C" int dfh_gp_ts(dfh_gp* gp, const double* Xs, int64_t m, int64_t block,
       if (nb == 1) {
         DFH_TRY(single_block(g0 * B, B, Lb, blk_idx + g0));
       } else {
-        for (int b = 0; b < nb; ++b) DFH_TRY(sigma_kernel((g0 + b) * B, B, Lb + b * B * B));
-        GemmBatch bs;
-        bs.count = nb; bs.sA = bs.sB = B * n; bs.sCin = bs.sCout = B * B;
-        const double* Vt = Kct + g0 * B * n;
-        DFH_TRY(gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, Lb, B, Lb, B, &bs));
+        // (also the rebuild closure of the factorisation: small groups take the one-launch panels, whose
+        //  hand-offs are bounded waits -- on expiry, e.g. with other contexts crowding the device, the group
+        //  is rebuilt and factored on the schedule without inter-workgroup waits)
+        const std::function<int()> build_group = [&]() -> int {
+          for (int b = 0; b < nb; ++b) DFH_TRY(sigma_kernel((g0 + b) * B, B, Lb + b * B * B));
+          GemmBatch bs;
+          bs.count = nb; bs.sA = bs.sB = B * n; bs.sCin = bs.sCout = B * B;
+          const double* Vt = Kct + g0 * B * n;
+          return gemm_f64(ctx, GEMM_LOWER, B, B, n, -1.0, Vt, n, Vt, n, 1.0, Lb, B, Lb, B, &bs);
+        };
+        DFH_TRY(build_group());
         int64_t piv[CHOL_MAX_BATCH] = {0};
-        int rc = cholesky_device(ctx, Lb, B, B, nullptr, piv, nb, B * B);
+        int rc = cholesky_device(ctx, Lb, B, B, nullptr, piv, nb, B * B, 0, nullptr, false, &build_group);
         if (rc != DFH_OK && rc != DFH_ERR_NOT_PD) return rc;
         for (int b = 0; b < nb; ++b) {
           if (piv[b] == 0) { if (jitter_powers_out) jitter_powers_out[blk_idx + g0 + b] = INT32_MIN; continue; }

@@ -250,9 +250,41 @@ __device__ __forceinline__ void f64_consume_block(double4_t (&acc)[4], int lane,
 // diagonal); returns the first bad column of the wave's own block or -1.  stage: the pivot block as staged in LDS (row stride
 // SPP); tbuf: 64 x 17 doubles of LDS private to this wave (layout change consumer -> owner).
 // ring_timeout: a word of LDS, zeroed by the caller before its barrier, set if a column never came up.
+// Inverse of wave w's 16 x 16 diagonal block of the factor (a[]: the wave's scaled columns, my_r = 1 / L[c][c] in
+// lane c): see the comment inside factor64_waves.
+__device__ __forceinline__ void factor64_inverse16(const double (&a)[16], int lane, int w, double* lbb, double* linv,
+                                                   double* rdiag, double my_r) {
+  if ((lane >> 4) == w) {
+    const int il = lane & 15;
+    double* lb = lbb + w * (16 * 17);
+    double* li = linv + w * (16 * 17);
+    rdiag[lane] = my_r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) lb[il * 17 + kk] = a[kk];
+    COMPILER_BARRIER();                              // same wave: LDS executes its operations in order
+    double sv[16], rd[16], yv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sv[i] = (i == il) ? 1.0 : 0.0; rd[i] = rdiag[16 * w + i]; }
+    // (results are stored after the loop: a store inside it may alias the block's loads for all the
+    //  compiler knows, which puts an LDS round trip into every step)
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double y = sv[kk] * rd[kk];
+      yv[kk] = y;
+#pragma unroll
+      for (int i = kk + 1; i < 16; ++i) sv[i] = fma(-lb[i * 17 + kk], y, sv[i]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) li[kk * 17 + il] = yv[kk];
+  }
+}
+
+// DEFER3: wave 3 returns before the inverse of its 16 x 16 block (the last thing on the chain, ~4.3k cycles) with
+// *my_r_out set; the caller runs factor64_inverse16 for it after the factor itself has been handed on.
+template <bool DEFER3 = false>
 __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
                                               double* ring, double* lbb, double* linv, double* rdiag,
-                                              int* ring_timeout, long long* dbg_stamp = nullptr) {
+                                              int* ring_timeout, long long* dbg_stamp = nullptr, double* my_r_out = nullptr) {
   int bad = -1;
   if (w == 0) {
 #pragma unroll
@@ -319,29 +351,11 @@ __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, 
   // exposed.  (A helper wave following the owner's published, unscaled columns -- the inverse needs
   // only u and 1/d -- was tried to hide that one too; the follower ran at ~440 cycles per column
   // against the owner's 225 and ended later.)
-  if ((lane >> 4) == w) {
-    const int il = lane & 15;
-    double* lb = lbb + w * (16 * 17);
-    double* li = linv + w * (16 * 17);
-    rdiag[lane] = my_r;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) lb[il * 17 + kk] = a[kk];
-    COMPILER_BARRIER();                              // same wave: LDS executes its operations in order
-    double sv[16], rd[16], yv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sv[i] = (i == il) ? 1.0 : 0.0; rd[i] = rdiag[16 * w + i]; }
-    // (results are stored after the loop: a store inside it may alias the block's loads for all the
-    //  compiler knows, which puts an LDS round trip into every step)
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const double y = sv[kk] * rd[kk];
-      yv[kk] = y;
-#pragma unroll
-      for (int i = kk + 1; i < 16; ++i) sv[i] = fma(-lb[i * 17 + kk], y, sv[i]);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) li[kk * 17 + il] = yv[kk];
+  if (DEFER3 && w == 3) {
+    *my_r_out = my_r;
+    return bad;
   }
+  factor64_inverse16(a, lane, w, lbb, linv, rdiag, my_r);
   if (dbg_stamp) dbg_stamp[3] = (long long)__builtin_amdgcn_s_memtime();
   return bad;
 }
@@ -691,10 +705,11 @@ __global__ __launch_bounds__(256, 1) void panel_strip_kernel(const double* __res
 // which the dispatcher starts first.  This replaces the sixteen dependent launches of a panel
 // (eight pivot steps, eight K = 64 updates) whose gaps and HBM round trips were the factorisation's
 // chain.
+constexpr int FUSED_SYNC_INTS = 24;
 struct FusedArgs {
   double* D; long lda;
   double* Lfac; double* Linv16;
-  int* sync;                 // per matrix: flag[8], prog[8]
+  int* sync;                 // per matrix: flag[8], prog[8], flag2[8] (the inverse of L_ss's last 16 x 16 block, published late)
   int epoch;
   int nbk;                   // order of the diagonal block (512, or less for the last panel: identity padding)
   int rows_below;            // rows under the diagonal block (only below a full one)
@@ -706,7 +721,21 @@ struct FusedArgs {
   // started in *resident, and -- wait_ptr != null -- only then waits for *wait_ptr >= wait_target
   // (the trailing update of another stream has written the diagonal block) before touching the matrix
   int* resident; const int* wait_ptr; int wait_target;
+  // hand-off protocol inside the launch.  0: plain stores + release fence (buffer_wbl2: the XCD's whole L2 is
+  // written back, dirty C tiles of a trailing update running beside the panel included) / acquire fence
+  // (buffer_inv) + plain loads.  1: what is handed over goes out with write-through stores and comes in
+  // with agent-coherent loads (sc1), the flags are relaxed: no cache-wide maintenance on the chain.
+  int sc1;
+  int prog_sleep;               // s_sleep argument of the polls that are not on the chain (waits for another strip's X_cJ)
+#ifdef DFH_DEBUG_HOOKS
+  long long* stamps = nullptr;  // dfh_debug_panel_stamps: [strip][64] s_memrealtime (100 MHz) at the points marked FSTAMP
+#endif
 };
+#ifdef DFH_DEBUG_HOOKS
+#define FSTAMP(a, g, i) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(g) * 64 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FSTAMP(a, g, i) do {} while (0)
+#endif
 
 // Bounded: a workgroup only ever waits for workgroups of the same launch with a smaller index (started
 // before it by the dispatcher as observed, not by contract) or for another launch that needs none of
@@ -731,6 +760,40 @@ __device__ __forceinline__ void fused_publish(int* p, int value) {
   if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the sc1 protocol (FusedArgs::sc1): data with write-through stores / agent-coherent loads ...
+__device__ __forceinline__ void st_out(double* p, double v, bool sc1) {
+  if (sc1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ double ld_in(const double* p, bool sc1) {
+  return sc1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// ... the flag goes up once every wave's write-through stores have been acknowledged (s_barrier alone does not
+// wait for outstanding stores on gfx950: each wave drains its own first), and is read without a fence
+__device__ __forceinline__ void fused_publish_sc1(int* p, int value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (relaxed: true for the waits off the chain -- every poll is a round trip to the memory side of the fabric, and
+//  sixty strips polling one line at full rate slow the loads and stores of the strip that IS on the chain)
+__device__ __forceinline__ void fused_wait_sc1(const int* p, int target, const FusedArgs& a, bool relaxed = false,
+                                               unsigned what = SYNC_ST_FUSED) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > a.spin_limit) { atomicOr(a.status, (unsigned long long)what); break; }
+      if ((spins & 63) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      if (relaxed) {
+        for (int z = 0; z < a.prog_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <int J>
 __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[32], int s, bool diag, double* Rw,
                                            long rows_left, double* ssm) {
@@ -745,12 +808,14 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
   int* flag = a.sync; int* prog = a.sync + 8;
   if (J < s) {
     fused_wait(flag + J, a.epoch, a);
+    FSTAMP(a, blockIdx.x, 1 + 4 * J);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Lj[(w + 4 * r) * SK_LD + lane] = a.Lfac[J * PB * PB + (w + 4 * r) * PB + lane];
     for (int i = tid; i < 4 * 16 * 16; i += 256)
       li[(i >> 8) * (16 * SK_TD) + ((i >> 4) & 15) * SK_TD + (i & 15)] =
           a.Linv16[J * (4 * 16 * 17) + (i >> 8) * (16 * 17) + ((i >> 4) & 15) * 17 + (i & 15)];
     __syncthreads();
+    FSTAMP(a, blockIdx.x, 2 + 4 * J);
     // ---- row solve of block J (as in panel_strip_kernel) ----
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -784,6 +849,7 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
     for (int i = 0; i < 16; ++i)
       if (i < rows_left) Rw[(long)i * a.lda + J * PB + lane] = Xw[i * SK_LD + lane];
     if (diag) fused_publish(prog + s, a.epoch * 16 + J + 1);   // X_sJ is out (later diagonal strips and the rows below read it)
+    FSTAMP(a, blockIdx.x, 3 + 4 * J);
     double xa[16];
 #pragma unroll
     for (int st = 0; st < 16; ++st) xa[st] = -Xw[l15 * SK_LD + 4 * st + kq];
@@ -809,20 +875,214 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
                                                                     acc[4 * c + (i & 3)], 0, 0, 0);
     }
     __syncthreads();                                   // Xall / Lj / li are free for the next step
+    FSTAMP(a, blockIdx.x, 4 + 4 * J);
   }
 }
 
+// Round 4: the same step with the strip held TRANSPOSED in the accumulators,
+//     accT[t][r] of lane (kq, l15) = strip element (row l15 of the wave's 16, column 16 t + kq + 4 r),
+// i.e. the D layout of v_mfma_f64_16x16x4 for the transposed tile: D[kq + 4 r][l15] = T[l15][kq + 4 r].  In
+// that layout an accumulator tile IS the B operand of a product that contracts over the strip's columns
+// (B[k][n], k = kq + 4 r for the r-th of four MFMAs, n = l15), so
+//     X_b^T = Linv_bb T_b^T,     T_b'^T -= L_b'b X_b^T  (b' > b, right-looking),     A_c^T -= L_cJ X^T
+// take their A operands (rows of L / Linv, one ds_read_b64 per lane) from LDS and their B operands straight
+// from registers: the row solve no longer changes layout through LDS between its four 16-column stages.
+// Measured on the row-per-accumulator form (tools/dbg_panel.py, 100 MHz stamps): 4.25 us of a 22.5 us hop
+// were this solve -- 40 MFMAs at ~200 cycles each, eight LDS write -> read round trips.
+// acc^T[4 C + i] -= L_i X^T over the k-steps [KS0, KS1) of a 64-column block (k-step ks: columns 4 ks + kq of
+// X = -xn), i = 0 .. 3: the order of panel_strip_kernel's update (k-step outer, the four tiles inner, ONE
+// accumulator chain per tile), with the A operands read AHEAD MFMAs early: one wave per SIMD, nothing else
+// hides the LDS latency.
+// (C: the block; a compile-time constant at every call site after unrolling -- the accumulator index must be static)
+template <int KS0, int KS1>
+__device__ __forceinline__ void strip_update_t(double4_t (&acc)[32], const int C, const double* L, const double4_t (&xn)[4], int l15, int kq) {
+  constexpr int N = (KS1 - KS0) * 4, AHEAD = 6;
+  double aq[N];
+#pragma unroll
+  for (int q = 0; q < AHEAD && q < N; ++q) aq[q] = L[(16 * (q & 3) + l15) * SK_LD + 4 * (KS0 + (q >> 2)) + kq];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    if (q + AHEAD < N) aq[q + AHEAD] = L[(16 * ((q + AHEAD) & 3) + l15) * SK_LD + 4 * (KS0 + ((q + AHEAD) >> 2)) + kq];
+    const int ks = KS0 + (q >> 2);
+    acc[4 * C + (q & 3)] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], xn[ks >> 2][ks & 3], acc[4 * C + (q & 3)], 0, 0, 0);
+#ifndef DFH_NO_SGB
+    if (q + AHEAD < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one DS read ...
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // ... one MFMA
+#endif
+  }
+}
+
+template <int J>
+__device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc)[32], int s, bool diag, double* Rw,
+                                             long rows_left, double* ssm) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform, and known to be: the row-store addresses built on it stay scalar.  (With a vector w the strip's
+  // row pointer was spilled and every one of the sixteen X row stores waited -- vmcnt(0) -- for its reload behind
+  // the previous write-through store: 5 us per step.)
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, l15 = lane & 15;
+  double* Lj = ssm;                                                // [64][SK_LD]
+  double* Lc = ssm + PB * SK_LD;                                   // [64][SK_LD]
+  double* Xall = ssm + 2 * PB * SK_LD;                             // [64][SK_LD]: the four waves' solved rows
+  double* Xw = Xall + w * (16 * SK_LD);
+  double* li = ssm + 2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD;
+  int* flag = a.sync; int* prog = a.sync + 8;
+  constexpr bool sc1 = true;        // the transposed panel always hands over with write-through stores / coherent loads
+  if (J < s) {
+    fused_wait_sc1(flag + J, a.epoch, a, !(diag && J == s - 1));
+    FSTAMP(a, blockIdx.x, 1 + 4 * J);
+    {
+      double pre[16], prei[4];                         // all loads in flight before the first LDS write
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pre[r] = ld_in(a.Lfac + J * PB * PB + (w + 4 * r) * PB + lane, sc1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tid + 256 * r;
+        prei[r] = ld_in(a.Linv16 + J * (4 * 16 * 17) + (i >> 8) * (16 * 17) + ((i >> 4) & 15) * 17 + (i & 15), sc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Lj[(w + 4 * r) * SK_LD + lane] = pre[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tid + 256 * r;
+        li[(i >> 8) * (16 * SK_TD) + ((i >> 4) & 15) * SK_TD + (i & 15)] = prei[r];
+      }
+    }
+    __syncthreads();
+    FSTAMP(a, blockIdx.x, 2 + 4 * J);
+    // ---- row solve of block J, 16-column stages, right-looking; xn[b] = -X_b^T ----
+    // (the accumulator tiles of block J are only ever read from here on: the solved block lives in xn and in LDS, so
+    //  that no accumulator tile is written by the vector unit -- they stay in the AGPR half of the register file)
+    double4_t xn[4], odd[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) odd[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // the strip's LAST step (the one on the chain): X_s,s-1 is announced late, and three quarters of the
+    // own-block product A_ss -= X X^T run BEFORE the fourth solve stage, while the inverse that stage needs is
+    // still on its way (second flag of strip J)
+    const bool last_step = diag && J == s - 1;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b == 3 && last_step) {
+        FSTAMP(a, blockIdx.x, 48);
+        __syncthreads();                               // columns 0 .. 47 of all four waves' X_sJ are in Xall
+        FSTAMP(a, blockIdx.x, 49);
+        if constexpr (J + 1 < 8) strip_update_t<0, 12>(acc, J + 1, Xall, xn, l15, kq);
+      }
+      if (b == 3 && last_step) FSTAMP(a, blockIdx.x, 50);
+      // T_b^T = the tile (which carries the even-numbered k-steps of the earlier stages' updates) + the odd chain:
+      // the association of panel_strip_kernel / diag_step64_kernel / fused_step (two accumulators per product,
+      // added at the end), so that every schedule of the factorisation rounds alike -- results do not depend on
+      // how a candidate set is cut into shards, chunks and lock-step groups (tests/test_gpu_mgpu.py).
+      // It leaves the accumulator file for the vector registers here: the tile is dead from now on, so the
+      // product below does not need a 33rd tile of accumulators (which the compiler found by spilling one)
+      const double4_t tsum = (b == 0) ? acc[4 * J + b] : acc[4 * J + b] + odd[b];
+      double tb0 = tsum[0], tb1 = tsum[1], tb2 = tsum[2], tb3 = tsum[3];
+      asm volatile("" : "+v"(tb0), "+v"(tb1), "+v"(tb2), "+v"(tb3));
+      double i0, i1, i2, i3;                                       // Linv_bb[l15][k], k = kq + 4 r
+      if (b < 3) {
+        const double* lib = li + b * (16 * SK_TD) + l15 * SK_TD + kq;
+        i0 = lib[0]; i1 = lib[4]; i2 = lib[8]; i3 = lib[12];
+      } else {
+        // the last block's inverse arrives under its own flag (see the end of panel_fused_kernel), straight
+        // into registers: every wave polls for itself, no workgroup barrier on the way
+        if (lane == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(a.sync + 16 + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch) {
+            if (++spins > a.spin_limit) { atomicOr(a.status, (unsigned long long)SYNC_ST_FUSED); break; }
+            if ((spins & 63) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (last_step) FSTAMP(a, blockIdx.x, 51);
+        const double* gi = a.Linv16 + J * (4 * 16 * 17) + 3 * (16 * 17) + l15 * 17 + kq;
+        i0 = ld_in(gi, sc1); i1 = ld_in(gi + 4, sc1); i2 = ld_in(gi + 8, sc1); i3 = ld_in(gi + 12, sc1);
+      }
+      double4_t p = {0.0, 0.0, 0.0, 0.0}, p2 = {0.0, 0.0, 0.0, 0.0};
+      p = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, tb0, p, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, tb1, p2, 0, 0, 0);
+      p = __builtin_amdgcn_mfma_f64_16x16x4f64(i2, tb2, p, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(i3, tb3, p2, 0, 0, 0);
+      p = p + p2;                                                  // X_b^T
+      xn[b] = -p;
+      // the solved block's row-major image in LDS (coalesced store below; A operand of the own-block product)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xw[l15 * SK_LD + 16 * b + kq + 4 * r] = p[r];
+#pragma unroll
+      for (int b2 = b + 1; b2 < 4; ++b2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double lv = Lj[(16 * b2 + l15) * SK_LD + 16 * b + kq + 4 * r];                 // L[16 b2 + l15][16 b + k]
+          if (r & 1) odd[b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, xn[b][r], odd[b2], 0, 0, 0);
+          else acc[4 * J + b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, xn[b][r], acc[4 * J + b2], 0, 0, 0);
+        }
+    }
+    COMPILER_BARRIER();                              // same wave: LDS executes its operations in order
+    if (rows_left >= 16) {                             // (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st_out(Rw + (long)i * a.lda + J * PB + lane, Xw[i * SK_LD + lane], sc1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < rows_left) st_out(Rw + (long)i * a.lda + J * PB + lane, Xw[i * SK_LD + lane], sc1);
+    }
+    // X_sJ is out (later diagonal strips and the rows below read it).  In the strip's LAST step -- the one on the
+    // chain -- the announcement waits until the own-block product below has been issued: nobody needs X_s,s-1
+    // before L_ss exists, and the wait for the stores' acknowledgement (1.5 us) leaves the chain.
+    if (diag && !last_step) fused_publish_sc1(prog + s, a.epoch * 16 + J + 1);
+    FSTAMP(a, blockIdx.x, 3 + 4 * J);
+    const int c_hi = diag ? s : 7;                     // last block this strip still needs
+#pragma unroll
+    for (int c = J + 1; c < 8; ++c) {
+      if (c > c_hi) break;
+      const double* L;
+      const bool own = diag && c == s;
+      if (own) {
+        if (last_step) FSTAMP(a, blockIdx.x, 52);
+        __syncthreads();                               // all four waves' rows of X_sJ are in Xall
+        if (last_step) FSTAMP(a, blockIdx.x, 53);
+        L = Xall;                                      // own diagonal block: A_ss -= X_sJ X_sJ^T (lower tiles only)
+      } else {
+        // strip c has published X_cJ (its barrier also frees Lc)
+        fused_wait_sc1(prog + c, a.epoch * 16 + J + 1, a, true);
+        double pre[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pre[r] = ld_in(a.D + (long)(c * PB + w + 4 * r) * a.lda + J * PB + lane, sc1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Lc[(w + 4 * r) * SK_LD + lane] = pre[r];
+        __syncthreads();
+        L = Lc;
+      }
+      // (the own block's tiles right of the diagonal are computed too -- garbage nobody reads, as in the other
+      //  schedules; the waves that would skip them wait for wave 3 at the next barrier anyway)
+      if (own && last_step) strip_update_t<12, 16>(acc, c, L, xn, l15, kq);      // k-steps 0 .. 11: before the fourth solve stage (above)
+      else strip_update_t<0, 16>(acc, c, L, xn, l15, kq);
+    }
+    // (the last step's X_s,s-1 is announced from the kernel's tail, behind the staging barrier: by then the
+    //  stores' acknowledgement, 1.5 - 2 us for write-through, has arrived without anybody waiting for it)
+    if (last_step) FSTAMP(a, blockIdx.x, 54);
+    __syncthreads();                                   // Xall / Lj / li are free for the next step
+    FSTAMP(a, blockIdx.x, 4 + 4 * J);
+  }
+}
+
+template <bool TR>
 __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double ssm[];
   a.D += (long)blockIdx.y * a.strideD;
   a.Lfac += (long)blockIdx.y * a.strideL;
   a.Linv16 += (long)blockIdx.y * a.strideI;
-  a.sync += (long)blockIdx.y * 16;
+  a.sync += (long)blockIdx.y * FUSED_SYNC_INTS;
   a.info += blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (NOT through readfirstlane here, unlike in fused_step_t: with a scalar w the diagnostics build of this kernel
+  //  flagged pivot 5 of a diagonally dominant block -- factor64_waves went wrong -- while the product build of the
+  //  same source passed the GPU suite; tools/r4_run10.sh.  Not understood; the vector form is the one both builds
+  //  agree on, and both builds run the factorisation tests.)
+  const int w = tid >> 6;
   const int kq = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.x;
   const int nd = (a.nbk + PB - 1) / PB;              // diagonal strips (8 for a full panel)
+  if (TR) a.sc1 = 1;                                 // the transposed panel's hand-offs are write-through / coherent loads
   if (a.resident) {
     if (tid == 0) __hip_atomic_fetch_add(a.resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.wait_ptr) fused_wait(a.wait_ptr, a.wait_target, a, SYNC_ST_GATE);
@@ -832,25 +1092,65 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   double* Rw = a.D + ((long)g * PB + 16 * w) * a.lda;               // this wave's 16 rows of the panel
   const long rows_left = (long)(a.nbk + a.rows_below) - ((long)g * PB + 16 * w);
   double4_t acc[32];
+  const bool full_tr = TR && a.nbk == 8 * PB && rows_left >= 16;      // (wave-uniform)
+  if (full_tr) {
+    // full panel, all sixteen rows present: one base address per lane and immediate offsets; the blocks a
+    // diagonal strip never touches are not loaded, its own block is cut to the lower triangle
+    const double* rp = Rw + (long)l15 * a.lda + kq;
+    const int row = 16 * w + l15;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const bool need = !diag || c <= s;
+      const bool own = diag && c == s;
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        double4_t v = {0.0, 0.0, 0.0, 0.0};
+        if (need) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rp[16 * (4 * c + ti) + 4 * r];
+          if (own) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (16 * ti + kq + 4 * r <= row) ? v[r] : 0.0;
+          }
+        }
+        acc[4 * c + ti] = v;
+      }
+    }
+  } else
 #pragma unroll
   for (int t = 0; t < 32; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 16 * w + kq + 4 * r, c = t >> 2, col = 16 * (t & 3) + l15;
+      // TR: lane (kq, l15) holds row l15, columns 16 t + kq + 4 r; otherwise rows kq + 4 r, column 16 t + l15
+      const int rl = TR ? l15 : kq + 4 * r;              // row within the wave's 16
+      const int cl = TR ? kq + 4 * r : l15;              // column within the 16-column tile
+      const int row = 16 * w + rl, c = t >> 2, col = 16 * (t & 3) + cl;
       // a diagonal strip needs its blocks up to its own, of that one only the lower triangle; rows and
       // columns beyond the block's order (last panel) are identity padding
-      const bool want = (kq + 4 * r < rows_left) && (16 * t + l15 < a.nbk) && (!diag || c < s || (c == s && col <= row));
-      const bool pad_one = diag && c == s && col == row && (kq + 4 * r >= rows_left);
-      acc[t][r] = want ? Rw[(long)(kq + 4 * r) * a.lda + 16 * t + l15] : (pad_one ? 1.0 : 0.0);
+      const bool want = (rl < rows_left) && (16 * t + cl < a.nbk) && (!diag || c < s || (c == s && col <= row));
+      const bool pad_one = diag && c == s && col == row && (rl >= rows_left);
+      acc[t][r] = want ? Rw[(long)rl * a.lda + 16 * t + cl] : (pad_one ? 1.0 : 0.0);
     }
-  fused_step<0>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<1>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<2>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<3>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<4>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<5>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<6>(a, acc, s, diag, Rw, rows_left, ssm);
-  fused_step<7>(a, acc, s, diag, Rw, rows_left, ssm);
+  FSTAMP(a, g, 0);
+  if constexpr (TR) {
+    fused_step_t<0>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<1>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<2>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<3>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<4>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<5>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<6>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step_t<7>(a, acc, s, diag, Rw, rows_left, ssm);
+  } else {
+    fused_step<0>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<1>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<2>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<3>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<4>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<5>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<6>(a, acc, s, diag, Rw, rows_left, ssm);
+    fused_step<7>(a, acc, s, diag, Rw, rows_left, ssm);
+  }
   if (!diag) return;
   // ---- factor the strip's own diagonal block and publish it (LDS of the strip machinery is free) ----
   double* Sp = ssm;                                  // [64][SPP] staged block, then the factor image
@@ -875,19 +1175,29 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 16 * w + kq + 4 * r, col = 16 * t4 + l15;
+      const int row = 16 * w + (TR ? l15 : kq + 4 * r), col = 16 * t4 + (TR ? kq + 4 * r : l15);
       Sp[row * SPP + col] = (col <= row) ? v[r] : 0.0;
     }
   }
   if (tid < PB) ring[tid * PB] = 0.0;
+  if (TR && s > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of X_s,s-1 are out
   __syncthreads();
+  if (TR && s > 0 && tid == 0)                         // ... all four waves': announce them (see fused_step_t)
+    __hip_atomic_store(a.sync + 8 + s, a.epoch * 16 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  FSTAMP(a, g, 40);
   double av[16];
   double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
-  const int bad = factor64_waves(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout);
+  // TR: the inverse of the last 16 x 16 block -- the only one of the four that is not hidden behind later columns,
+  // ~4.3k cycles at the end of the chain -- is computed AFTER the factor has been handed on, and published under a
+  // second flag: the next strip needs it for the last of its four solve stages only, ~3 us after it saw the first
+  double my_r3 = 1.0;
+  const int bad = factor64_waves<TR>(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout, nullptr, &my_r3);
   if (lane == 0) s_badv[w] = bad;
 #pragma unroll
   for (int j = 0; j < 16; ++j) Sp[lane * SPP + perm16(16 * w + j)] = av[j];
+  FSTAMP(a, g, 41);        // (thread 0 = wave 0: done with its columns long before wave 3)
   __syncthreads();
+  FSTAMP(a, g, 42);
   const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
   if (s_ring_timeout && tid == 0) atomicOr(a.status, (unsigned long long)SYNC_ST_RING);
   if (s_bad >= 0 && tid == 0) {
@@ -900,12 +1210,25 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   {
     double* Lout = a.Lfac + (long)s * PB * PB;
     const int pk = perm16(lane);
+    const bool sc1 = TR || a.sc1 != 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Lout[(w + 4 * r) * PB + lane] = Sp[(w + 4 * r) * SPP + pk];
+    for (int r = 0; r < 16; ++r) st_out(Lout + (w + 4 * r) * PB + lane, Sp[(w + 4 * r) * SPP + pk], sc1);
     double* Iout = a.Linv16 + (long)s * (4 * 16 * 17);
-    for (int i = tid; i < 4 * 16 * 17; i += 256) Iout[i] = linv[i];
+    for (int i = tid; i < (TR ? 3 : 4) * 16 * 17; i += 256) st_out(Iout + i, linv[i], sc1);
   }
-  fused_publish(a.sync + s, a.epoch);                 // published even after a failed pivot: nobody may hang
+  // published even after a failed pivot: nobody may hang
+  if (TR || a.sc1) fused_publish_sc1(a.sync + s, a.epoch); else fused_publish(a.sync + s, a.epoch);
+  FSTAMP(a, g, 43);
+  if constexpr (TR) {
+    if (w == 3) {
+      factor64_inverse16(av, lane, 3, lbb, linv, rdiag, my_r3);
+      COMPILER_BARRIER();                              // same wave: LDS executes its operations in order
+      double* Iout3 = a.Linv16 + (long)s * (4 * 16 * 17) + 3 * (16 * 17);
+      for (int i = lane; i < 16 * 17; i += 64) st_out(Iout3 + i, linv[3 * (16 * 17) + i], true);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the whole wave's stores are acknowledged
+      if (lane == 0) __hip_atomic_store(a.sync + 16 + s, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 constexpr int FUSED_SMEM_STRIP = (2 * PB * SK_LD + 4 * 16 * SK_LD + 4 * 16 * SK_TD + 4 * 16 * SK_TD) * 8;
@@ -1227,9 +1550,9 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   const int64_t strideT = NB * NB;
   const int64_t strideI = 2 * (NB / PB) * (4 * 16 * 17);         // 16 x 16 inverses of those blocks, same parity scheme
   double* Lscr_all = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)nbatch * (strideL + strideI + 8) * 8, (void**)&Lscr_all));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, ((size_t)nbatch * (strideL + strideI) + (size_t)nbatch * FUSED_SYNC_INTS / 2 + 2) * 8, (void**)&Lscr_all));
   double* Iscr_all = Lscr_all + (int64_t)nbatch * strideL;
-  int* fsync_all = reinterpret_cast<int*>(Iscr_all + (int64_t)nbatch * strideI);     // [nbatch][16] counters of the fused panels
+  int* fsync_all = reinterpret_cast<int*>(Iscr_all + (int64_t)nbatch * strideI);     // [nbatch][FUSED_SYNC_INTS] counters of the fused panels
   // One launch per panel (panel_fused_kernel) for single matrices / small batches: n = 4096 2.92 -> 2.50 ms,
   // 8192 8.05 -> 7.07, 16384 34.8 -> 33.4.  Large lock-step batches keep the pivot steps + strips: their
   // workgroups would spend the diagonal chain's 190 us spinning.
@@ -1237,7 +1560,13 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   // (lock-step batches of up to 16 gain 5-14 % from it as well -- tools/time_lml_batch.py --, 32 and more lose)
   static const int fused_max_batch = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : 16; }();
   const bool fused_mode = fused_on && nbatch <= fused_max_batch && !safe;   // safe: no inter-workgroup hand-offs
-  if (fused_mode) DFH_HIP(hipMemsetAsync(fsync_all, 0, (size_t)nbatch * 16 * sizeof(int), ctx->stream));
+  // DFH_CHOL_FUSED_TR=0: the round-3 form of the one-launch panel (strip rows in the accumulators' rows)
+  static const bool fused_tr = env_int("DFH_CHOL_FUSED_TR", 1) != 0;
+  void (*const fused_kernel)(FusedArgs) = fused_tr ? panel_fused_kernel<true> : panel_fused_kernel<false>;
+  // DFH_CHOL_FUSED_SC1=0: hand-offs inside the launch with release / acquire fences (FusedArgs::sc1)
+  static const int fused_sc1 = env_int("DFH_CHOL_FUSED_SC1", 1) != 0 ? 1 : 0;
+  static const int fused_prog_sleep = env_int("DFH_CHOL_PROG_SLEEP", 8);
+  if (fused_mode) DFH_HIP(hipMemsetAsync(fsync_all, 0, (size_t)nbatch * FUSED_SYNC_INTS * sizeof(int), ctx->stream));
   // Panel strips (panel_strip_kernel) for lock-step batches: there the pivot steps are throughput-bound
   // (64 matrices x 64 workgroups, each re-factoring the pivot block, one workgroup per CU) and the
   // K = 64 panel updates HBM-bound (1.85 GB per step).  A single matrix keeps the pivot-step / GEMM
@@ -1267,7 +1596,9 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_STEP_SMEM));
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strip_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_SMEM));
-    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel),
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM));
     attr_set = true;
   }
@@ -1375,10 +1706,11 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         fa.nbk = (int)NB; fa.rows_below = 0; fa.info = d_info; fa.pivot_base = (long)k0;
         fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
         fa.status = d_status; fa.spin_limit = spin_limit;
+        fa.sc1 = fused_sc1; fa.prog_sleep = fused_prog_sleep;
         fa.resident = sy;
         fa.wait_ptr = kb > 0 ? sy - 4 + 1 : nullptr;   // the sixteen... ten lower tiles of this diagonal block, out of update(kb-1)
         fa.wait_target = 10;
-        hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(NB / PB), 1), dim3(256), FUSED_SMEM, Pc, fa);
+        hipLaunchKernelGGL(fused_kernel, dim3((unsigned)(NB / PB), 1), dim3(256), FUSED_SMEM, Pc, fa);
         DFH_LAUNCH_CHECK();
         DFH_HIP(hipEventRecord(e_diag, Pc));
       }
@@ -1463,8 +1795,8 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         fa.nbk = (int)nbk; fa.rows_below = (int)rem; fa.info = d_info; fa.pivot_base = (long)k0;
         fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
         fa.status = d_status; fa.spin_limit = spin_limit;
-        fa.resident = nullptr; fa.wait_ptr = nullptr; fa.wait_target = 0;
-        hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)((nbk + PB - 1) / PB + (rem + PB - 1) / PB), (unsigned)nbatch),
+        fa.resident = nullptr; fa.wait_ptr = nullptr; fa.wait_target = 0; fa.sc1 = fused_sc1; fa.prog_sleep = fused_prog_sleep;
+        hipLaunchKernelGGL(fused_kernel, dim3((unsigned)((nbk + PB - 1) / PB + (rem + PB - 1) / PB), (unsigned)nbatch),
                            dim3(256), FUSED_SMEM, P, fa);
         DFH_LAUNCH_CHECK();
       }
@@ -1608,8 +1940,12 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
     return cholesky_device_impl(ctx, A, n, lda, keep_inv, info_pivot, nbatch, strideA, strideKeep, refine_out,
                                 inv64_only, allow_lr, safe);
   };
-  int rc = attempt(rebuild != nullptr, force_safe);
-  if (rc != DFH_INTERNAL_RETRY) return rc;
+  const bool cooling = ctx->chol_cooldown > 0;
+  if (cooling) --ctx->chol_cooldown;
+  int rc = attempt(rebuild != nullptr && !cooling, force_safe || cooling);
+  if (rc != DFH_INTERNAL_RETRY) { if (!cooling) ctx->chol_fallback_streak = 0; return rc; }
+  ++ctx->chol_fallbacks;
+  if (++ctx->chol_fallback_streak >= 2) { ctx->chol_cooldown = 32; ctx->chol_fallback_streak = 0; }
   static const bool verbose = env_int("DFH_CHOL_VERBOSE", 0) != 0;
   if (verbose) fprintf(stderr, "dfhip: factorisation of n = %lld repeated on the safe schedule: %s\n", (long long)n, dfh_last_error());
   if (!rebuild || force_safe) return DFH_ERR_HIP;
@@ -1850,6 +2186,65 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
   long long zero[8] = {0};
   DFH_HIP(hipMemcpy(d_info + CHOL_MAX_BATCH, zero, sizeof(zero), hipMemcpyHostToDevice));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return DFH_OK;
+}
+// Diagnostics hook: `reps` launches of the one-launch panel on a synthetic SPD 512 x 512 block with `rows_below`
+// rows under it; ms_out[reps] per launch (HIP events), stamps_out [(8 + strips below)][64] from the last launch.
+extern "C" int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, double* ms_out, long long* stamps_out) {
+  DFH_ARG(ctx && reps > 0 && rows_below >= 0 && ms_out && stamps_out);
+  DFH_HIP(hipSetDevice(ctx->device));
+  static const bool fused_tr = env_int("DFH_CHOL_FUSED_TR", 1) != 0;
+  void (*const fused_kernel)(FusedArgs) = fused_tr ? panel_fused_kernel<true> : panel_fused_kernel<false>;
+  DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM));
+  const int64_t nn = 512, rows = nn + rows_below;
+  const int nwg = (int)(nn / PB + (rows_below + PB - 1) / PB);
+  std::vector<double> h((size_t)rows * nn);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < nn; ++j) h[i * nn + j] = (i < nn && j > i) ? 0.0 : 0.02 * (rnd() - 0.5);
+  for (int64_t i = 0; i < nn; ++i) { for (int64_t j = 0; j < i; ++j) h[j * nn + i] = h[i * nn + j]; h[i * nn + i] = 3.0 + rnd(); }
+  double *master = nullptr, *D = nullptr, *scr = nullptr;
+  long long* d_st = nullptr;
+  DFH_HIP(hipMalloc(&master, h.size() * 8));
+  DFH_HIP(hipMalloc(&D, h.size() * 8));
+  const size_t scr_doubles = 8 * PB * PB + 8 * (4 * 16 * 17) + 64;
+  DFH_HIP(hipMalloc(&scr, scr_doubles * 8));
+  DFH_HIP(hipMalloc(&d_st, (size_t)nwg * 64 * 8));
+  DFH_HIP(hipMemcpy(master, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  DFH_HIP(hipMemset(scr, 0, scr_doubles * 8));
+  long long* d_info = reinterpret_cast<long long*>(ctx->d_info);
+  hipEvent_t e0, e1;
+  DFH_HIP(hipEventCreate(&e0)); DFH_HIP(hipEventCreate(&e1));
+  hipStream_t S = ctx->side;
+  for (int r = 0; r < reps; ++r) {
+    DFH_HIP(hipMemcpyAsync(D, master, h.size() * 8, hipMemcpyDeviceToDevice, S));
+    DFH_HIP(hipMemsetAsync(d_info, 0, 8 * (CHOL_MAX_BATCH + 16), S));
+    DFH_HIP(hipMemsetAsync(d_st, 0, (size_t)nwg * 64 * 8, S));
+    FusedArgs fa;
+    fa.D = D; fa.lda = nn; fa.Lfac = scr; fa.Linv16 = scr + 8 * PB * PB;
+    fa.sync = reinterpret_cast<int*>(scr + 8 * PB * PB + 8 * (4 * 16 * 17)); fa.epoch = r + 1;
+    fa.nbk = (int)nn; fa.rows_below = rows_below; fa.info = d_info; fa.pivot_base = 0;
+    fa.strideD = 0; fa.strideL = 0; fa.strideI = 0;
+    fa.status = reinterpret_cast<unsigned long long*>(d_info + CHOL_MAX_BATCH + 8); fa.spin_limit = SPIN_LIMIT_DEFAULT;
+    fa.resident = nullptr; fa.wait_ptr = nullptr; fa.wait_target = 0; fa.sc1 = env_int("DFH_CHOL_FUSED_SC1", 1) != 0 ? 1 : 0;
+    fa.prog_sleep = env_int("DFH_CHOL_PROG_SLEEP", 8);
+    fa.stamps = d_st;
+    DFH_HIP(hipEventRecord(e0, S));
+    hipLaunchKernelGGL(fused_kernel, dim3((unsigned)nwg, 1), dim3(256), FUSED_SMEM, S, fa);
+    DFH_HIP(hipEventRecord(e1, S));
+    DFH_HIP(hipStreamSynchronize(S));
+    float ms = 0.f;
+    DFH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    ms_out[r] = ms;
+  }
+  DFH_HIP(hipMemcpy(stamps_out, d_st, (size_t)nwg * 64 * 8, hipMemcpyDeviceToHost));
+  long long bad = 0;
+  DFH_HIP(hipMemcpy(&bad, d_info, 8, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(master); (void)hipFree(D); (void)hipFree(scr); (void)hipFree(d_st);
+  if (bad != 0) { dfh_set_error("debug panel: pivot %lld failed", bad); return DFH_ERR_NOT_PD; }
   return DFH_OK;
 }
 #endif  // DFH_DEBUG_HOOKS

@@ -59,6 +59,12 @@ struct dfh_ctx {
   hipStream_t aux = nullptr;         // off-critical-path work of the factorisation (block inverses)
   hipStream_t bulk_normal = nullptr; // normal-priority twin of `side` (experiments: DFH_CHOL_LR_NORMAL_PRIO)
   std::vector<hipEvent_t> evpool;    // untimed events for cross-stream ordering
+  // factorisations that were repeated on the schedule without inter-workgroup hand-offs (a bounded wait
+  // expired, or a block inverse was too poor for the resident panels) -- dfh_ctx_counters; after two in a row
+  // the next calls go straight to that schedule (chol_cooldown of them), so that a crowded device does not pay
+  // the time-out of ~1 s on every fit
+  int64_t chol_fallbacks = 0;
+  int chol_fallback_streak = 0, chol_cooldown = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
   std::vector<DevBuf> scratch;

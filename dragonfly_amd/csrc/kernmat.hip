@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
         if (se) {
           double t = acc[i][j][r] - (0.5 * nb[lc] + 0.5 * nai);
           t = t > 0.0 ? 0.0 : t;
-          kv = pd.scale_c * exp_fast(t, ec);
+          kv = pd.scale_c * exp_fast_neg(t, ec);       // t <= 0: no exponent clamp needed (two VALU ops of ~26)
         } else {
           double dsq = (nb[lc] + nai) - 2.0 * acc[i][j][r];
           dsq = dsq < 0.0 ? 0.0 : dsq;

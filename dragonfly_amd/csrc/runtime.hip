@@ -269,6 +269,14 @@ extern "C" int dfh_timer_end(dfh_ctx* ctx, double* ms) {
   return DFH_OK;
 }
 
+extern "C" int dfh_ctx_counters(dfh_ctx* ctx, int64_t* out) {
+  DFH_ARG(ctx && out);
+  out[0] = ctx->chol_fallbacks;
+  out[1] = ctx->chol_cooldown;
+  out[2] = 0; out[3] = 0;
+  return DFH_OK;
+}
+
 extern "C" int dfh_ctx_timings(dfh_ctx* ctx, int enable, double* ms_out) {
   DFH_ARG(ctx != nullptr);
   if (ms_out) memcpy(ms_out, ctx->t_ms, sizeof(ctx->t_ms));

@@ -347,6 +347,13 @@ class Engine(object):
     check(self.lib.dfh_ctx_timings(self.ctx, 1 if enable else 0, arr))
     return dict(zip(_lib.T_NAMES, list(arr)))
 
+  def counters(self):
+    """ {'chol_fallbacks': factorisations repeated on the hand-off-free schedule, 'chol_cooldown': how many
+        of the next ones skip the hand-off schedules} (dfh_ctx_counters) """
+    arr = (C.c_int64 * 4)()
+    check(self.lib.dfh_ctx_counters(self.ctx, arr))
+    return {'chol_fallbacks': int(arr[0]), 'chol_cooldown': int(arr[1])}
+
   def gemm_profile(self, enable=True, fetch=True):
     """ Per-variant {launches, ms (sum of launch durations), flop, busy_ms (union of the launch
         intervals), bytes (algorithmic)} of the GEMM kernel since the last call (HIP events). """

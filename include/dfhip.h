@@ -422,6 +422,13 @@ int dfh_mgpu_allgather_argmax(dfh_mgpu* mg, const double* vals, const int64_t* i
 #define DFH_T_COUNT    8
 int dfh_ctx_timings(dfh_ctx* ctx, int enable, double* ms_out /* [DFH_T_COUNT] or NULL */);
 
+/* Counters of the context since it was created (diagnostics; nothing in the reference corresponds):
+ * out[0] = factorisations repeated on the schedule without inter-workgroup hand-offs because a bounded
+ * wait expired or a resident panel's block inverse was too poor (the result is the same, the call slower);
+ * out[1] = how many of the next factorisations go straight to that schedule (set after two such repeats in
+ * a row, e.g. on a device shared with other work); out[2..3] reserved (0).                          */
+int dfh_ctx_counters(dfh_ctx* ctx, int64_t* out /* [4] */);
+
 /* Per-launch HIP-event timing of the fp64 MFMA GEMM kernel (the dominant kernel of the path),
  * recorded on the stream each launch goes to.  Returns the totals since the last call in
  * stats_out[8][5] = per kernel variant {launches, sum of launch durations in ms, algorithmic

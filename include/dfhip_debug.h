@@ -1,7 +1,7 @@
 /*
  * dfhip_debug.h -- diagnostics hooks of libdfhip.so.  NOT part of the product C-ABI (include/dfhip.h):
- * they exist only in a library built with -DDFH_DEBUG_HOOKS (`python -m dragonfly_amd.build
- * --debug-hooks`), are used by tools/dbg_*.py during kernel work, and replace nothing in the
+ * they exist only in libdfhip_dbg.so, built with -DDFH_DEBUG_HOOKS (`python -m dragonfly_amd.build
+ * --debug-hooks`, loaded with DFH_LIB=...), are used by tools/dbg_*.py during kernel work, and replace nothing in the
  * reference.
  */
 #ifndef DFHIP_DEBUG_H
@@ -19,6 +19,10 @@ int dfh_debug_write_bw(dfh_ctx* ctx, double gbytes, double* out);
 /* `reps` back-to-back launches of the 64-wide pivot step of the Cholesky factorisation on a
  * synthetic block: ms per launch and in-kernel cycle stamps.                                    */
 int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, double* ms_per_launch, long long* cycles_out);
+/* `reps` launches of the one-launch panel (panel_fused_kernel) on a synthetic SPD 512 x 512 block with
+ * `rows_below` rows under it: ms_out[reps] per launch; stamps_out[(8 + ceil(rows_below/64))][64] =
+ * s_memrealtime (100 MHz) at the marked points of the last launch (tools/dbg_panel.py decodes them). */
+int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, double* ms_out, long long* stamps_out);
 #ifdef __cplusplus
 }
 #endif

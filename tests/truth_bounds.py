@@ -9,15 +9,40 @@ met by ANY correct implementation; the bound is then what tests/test_gpu_conditi
 
 computed per case and per quantity, never a blanket literal.  Only single SE / Matern kernels have
 a truth; everything else is held to 1e-10 outright."""
+import os
+
 import numpy as np
 
 from conftest import relerr
 
 FLOOR = 1e-10
+# How far from 1e-10 a bound may ever move.  The committed run (profiles/r04_truth_bounds_applied.json) relaxed
+# bounds in two tests: 2.0e-3 for the log marginal likelihoods of Gram matrices that only factor with the
+# stable_cholesky ladder's jitter (test_gpu_hp_tuning.py::test_lml_batch_jitter_ladder_per_candidate: the
+# reference's own lml is 1.0e-3 from the extended-precision value there) and 4.2e-7 for Matern nu = 0.5 on a
+# symmetric Gram matrix (test_gpu_golden.py, matern05_d2_n30).  A new case that needs more than this ceiling
+# is a finding to look at, not a number to wave through.
+CEILING = 5e-3
+
+APPLIED = []      # (bound, test id) for every bound above the floor that a test of this run used
 
 
 def bound(ref, truth, floor=FLOOR, factor=2.0):
-  return max(floor, factor * relerr(ref, truth))
+  value = max(floor, factor * relerr(ref, truth))
+  if value > floor:
+    APPLIED.append((float(value), os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]))
+  assert value <= CEILING, 'the reference is %.1e from the truth here: beyond the committed ceiling %.0e' % (value / factor, CEILING)
+  return value
+
+
+def applied_summary():
+  """ What the run relaxed: the largest bound per test, largest first. """
+  worst = {}
+  for value, test in APPLIED:
+    worst[test] = max(value, worst.get(test, 0.0))
+  rows = sorted(worst.items(), key=lambda kv: -kv[1])
+  return {'floor': FLOOR, 'ceiling': CEILING, 'bounds_above_floor': len(APPLIED), 'tests_with_relaxed_bounds': len(rows),
+          'largest_bound_applied': rows[0][1] if rows else FLOOR, 'per_test_largest': [{'test': t, 'bound': v} for t, v in rows]}
 
 
 def gp_case_bounds(kind, nu, bw, scale, X, Y, mean_c, noise, Xs, ref, best=None, ts_U=None, Xh=None):

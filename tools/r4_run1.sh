@@ -18,6 +18,7 @@ DFH_MGPU_ALLOW_DUPLICATE_DEVICES=1 timeout 600 python -m torch.distributed.run -
 DFH_BENCH_PER_PROCESS=1 timeout 600 python bench.py --gpus 1 --steps 1 --warmup 1 --no-extras --no-cpu-baseline \
   > $O/dryrun_perprocess_1_rccl.json 2> $O/dryrun_perprocess_1_rccl.err; echo "perprocess 1 (RCCL) rc=$?"
 for n in 4096 8192 16384; do timeout 120 python tools/time_chol.py $n; done > $O/time_chol.txt 2>&1
+for rb in 0 3584; do DFH_LIB=$PWD/dragonfly_amd/libdfhip_dbg.so timeout 120 python tools/dbg_panel.py $rb; done > $O/dbg_panel.txt 2>&1
 timeout 200 python tools/time_kernmat.py > $O/time_kernmat.txt 2>&1
 ( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 tail -c 600 $O/gpu_tests.log; tail -c 1500 $O/install_on_gpu.log

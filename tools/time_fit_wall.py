@@ -10,6 +10,11 @@ X = rs.random_sample((n, d)); Y = (X ** 2).dot((np.arange(d) + 1.0) / d) + 0.01 
 spec = KernelSpec('se', d, float(Y.var()), 0.2 * np.sqrt(d) * (0.5 + np.arange(d) / 32.0))
 Xd, yd = eng.to_device(X), eng.to_device(Y - np.median(Y))
 noise = float(Y.var() / 20)
+pre = int(os.environ.get('PRE_N', '0'))
+if pre:      # a smaller fit first: does it absorb the one-off stall of the first large fit?
+  eng.sync(); t0 = time.perf_counter()
+  eng.gp_fit(spec, Xd.view(0, (pre, d)), yd.view(0, (pre,)), noise).free()
+  eng.sync(); print('pre-fit n=%d: %.1f ms' % (pre, (time.perf_counter() - t0) * 1e3))
 ts = []
 prev = None
 for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
