@@ -58,7 +58,7 @@ def fp64_pipe_frac(kind, packed_width, elements, parts_per_element, ms):
   return {'bound': 'fp64 pipe (valu_f64 epilogue + MFMA share it)', 'min_ms_mfma': round(t_mfma * 1e3, 4),
           'min_ms_valu': round(t_valu * 1e3, 4), 'frac_of_fp64_pipe_peak': round((t_mfma + t_valu) / (ms * 1e-3), 4),
           'frac_of_valu_peak': round(t_valu / (ms * 1e-3), 4)}
-PMC_TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+PMC_TRAFFIC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def rel(a, b):

@@ -15,8 +15,8 @@ rec['schedule_note'] = ('--pmc serialises kernels, so the counter passes run wit
 json.dump(rec, open(sys.argv[1], 'w'), indent=1)
 PY
 {
-echo "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-c4-full --steps 2 --warmup 1   (MI355X, tools/profile_round.sh; rocpd database summarised by tools/rocpd_stats.py)"
-echo "4 steps in the trace: 1 warm-up + 2 timed + 1 untimed section-timing step.  bench.py's own JSON line from this same run:"
+echo "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1   (MI355X, tools/profile_round.sh; rocpd database summarised by tools/rocpd_stats.py)"
+echo "4 steps in the trace: 1 warm-up + 2 timed + 1 untimed section-timing step (each: the n = 16384 fit + all 2 097 152 candidates of config 4).  bench.py's own JSON line from this same run:"
 grep -h '^{"metric' $P/trace.log
 echo
 python tools/rocpd_stats.py $P/trace/bench_results.db
@@ -33,7 +33,7 @@ for s in range(4):
   print('  step %d: %d launches, avg %.1f us, total %.1f ms' % (s, len(seg), sum(seg) / len(seg), sum(seg) / 1e3))
 PY
 echo
-echo "PMC passes over the same command (DFH_CHOL_LR=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --no-cpu-baseline --no-c4-full --steps 1 --warmup 0; kernels are serialised under --pmc, so the schedule that hands tiles over between concurrent kernels is off in these passes):"
+echo "PMC passes over the same command (DFH_CHOL_LR=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0; kernels are serialised under --pmc, so the schedule that hands tiles over between concurrent kernels is off in these passes):"
 python tools/rocpd_pmc_traffic.py $P/bench_FETCH_SIZE/bench_results.db $P/bench_WRITE_SIZE/bench_results.db
 } > profiles/${R}_bench_kernel_stats.txt
 {

@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/prof
 if [ "$MODE" = "all" ]; then rm -rf $OUT; elif [ "$MODE" = "bench-only" ]; then rm -rf $OUT/trace $OUT/bench_FETCH_SIZE $OUT/bench_WRITE_SIZE; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --no-cpu-baseline --no-c4-full"
+B="python $REPO/bench.py --no-cpu-baseline --no-extras"
 if [ "$MODE" != "wl-only" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B --steps 2 --warmup 1 > $OUT/trace.log 2>&1
 grep -h "^{\"metric" $OUT/trace.log | cut -c1-4000 > $OUT/bench_under_trace.json
