@@ -273,7 +273,7 @@ def config4_full_one_gpu(eng, prob, spec, steps=2):
           'argmax_equals_reduce_over_8_shards': bool(i_full == int(i_red) and v_full == v_red)}
 
 
-def hallucinated_batch(eng, workers=8, m_parity=8192):
+def hallucinated_batch(eng, workers=8, m_parity=4096):
   """ A synchronous batch at size (opt/gpb_acquisitions.py:90-115: every earlier recommendation is a
       hallucinated in-progress point of the next, gp/gp_core.py:192-220): config 2's GP (n = 4096, Matern-2.5),
       EI with the hallucinated std, q = 0 .. workers-1 extra rows.  The reference re-factors the (n+q) x (n+q)
