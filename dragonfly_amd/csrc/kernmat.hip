@@ -50,6 +50,7 @@ struct KmArgs {
   double outer;
   int apply_outer, symmetric;
   int product;                 // MULTI: parts are multiplied (CoordinateProductKernel) instead of summed
+  int nt_stores;               // kernmat_sym_kernel: write the matrix with streaming stores
   double diag_add;
   double* K; long ldk;
   // lock-step batch over blockIdx.z (symmetric single-part kernel only): element strides of the
@@ -464,8 +465,15 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
       const long row = row_base + r, col = col_base + c2;
       const long nrow = mirror ? nB : p.n1, ncol = mirror ? p.n1 : nB;
       if (row < nrow && col + 1 < ncol) {
-        *reinterpret_cast<double2_t*>(Kout + row * p.ldk + col) =
-            *reinterpret_cast<const double2_t*>(St + r * SP + c2);
+        // streaming (non-temporal) stores for the wide kernels: the matrix is written once and is far larger than
+        // L2 + MALL; measured 16384^2: d = 32 SE 0.444 -> 0.428 ms, Matern 0.554 -> 0.53, but d = 6 Matern 0.402 ->
+        // 0.418 (tools/r4_run15.sh) -- hence only from a packed width of 16 on (KmArgs::nt_stores)
+        if (p.nt_stores)
+          __builtin_nontemporal_store(*reinterpret_cast<const double2_t*>(St + r * SP + c2),
+                                      reinterpret_cast<double2_t*>(Kout + row * p.ldk + col));
+        else
+          *reinterpret_cast<double2_t*>(Kout + row * p.ldk + col) =
+              *reinterpret_cast<const double2_t*>(St + r * SP + c2);
       } else if (row < nrow && col < ncol) {
         Kout[row * p.ldk + col] = St[r * SP + c2];
         if (col + 1 < ncol) Kout[row * p.ldk + col + 1] = St[r * SP + c2 + 1];
@@ -1659,6 +1667,7 @@ int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob,
   a.n1 = (int)n; a.n2 = (int)n; a.P = kd.P; a.n_parts_total = kd.n_parts;
   a.parts = kd.d_parts; a.part_lo = 0; a.part_hi = 1;
   a.outer = kd.outer_scale; a.apply_outer = 1; a.symmetric = 1; a.diag_add = 0.0; a.product = 0;
+  a.nt_stores = 0;             // (lock-step batches of small matrices: they are factored right away, out of the caches)
   a.K = K; a.ldk = ldk;
   a.sXp = sXp; a.sNp = sNp; a.sK = sK; a.sBlob = sBlob; a.diag_adds = d_diag_adds;
   const int64_t T = (n + 63) / 64;
@@ -1686,6 +1695,10 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   a.outer = kd.outer_scale; a.apply_outer = apply_outer ? 1 : 0; a.product = kd.product ? 1 : 0;
   a.symmetric = symmetric ? 1 : 0; a.diag_add = diag_add;
   a.K = K; a.ldk = ldk;
+  {
+    static const int nt_env = []() { const char* e = getenv("DFH_KM_NT"); return e ? atoi(e) : -1; }();
+    a.nt_stores = nt_env >= 0 ? (nt_env != 0) : (kd.P >= 16 && n1 * n2 >= (int64_t)4096 * 4096);
+  }
   const bool multi = kd.multi;
   static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
   bool& attr_set = attr_set_dev[ctx->device];

@@ -140,3 +140,53 @@ def test_unique_id_file_rendezvous_two_processes(tmp_path):
   assert all(p.returncode == 0 for p in procs), outs
   digests = [o.split()[-1] for o in outs]
   assert digests[0] == digests[1] and len(digests[0]) == 40, outs
+
+
+HOSTX_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    from dragonfly_amd import parallel
+    comm = parallel.HostExchangeComm.from_env(key=os.environ['KEY'])
+    rank, world = comm.rank, comm.size
+    rs = np.random.RandomState(5)
+    ok = True
+    for trial in range(25):
+      m = int(rs.randint(1, 50))
+      vals = rs.randint(0, 4, size=m).astype(float)
+      if trial %% 5 == 0:
+        vals[rs.randint(0, m)] = np.nan
+      lo, hi = parallel.shard_bounds(m, rank, world, align=(8 if trial %% 2 else 1))
+      if hi > lo:
+        j = int(np.argmax(vals[lo:hi])); lv, li = vals[lo + j], lo + j
+      else:
+        lv, li = float('nan'), -1
+      v, i = comm.allgather_argmax(lv, li)
+      ok &= (i == int(np.argmax(vals)))
+      ok &= (v != v) if np.isnan(vals[i]) else (v == vals[i])
+    ok &= float(comm.allreduce_max([float(rank), -float(rank)])[0]) == world - 1
+    row = comm.allgather_rows(np.arange(4.0) + rank, rank == world - 1)
+    ok &= row[0] == world - 1
+    comm.barrier()
+    comm.close()
+    print('OK' if ok else 'MISMATCH')
+''')
+
+
+def test_host_exchange_comm_three_processes(tmp_path):
+  """ parallel.HostExchangeComm (the test-mode stand-in bench.py uses when several launcher processes share
+      one device, where RCCL refuses to form a communicator): same interface and same reduce as RcclComm,
+      three real processes, files in a private directory; nothing is left behind """
+  script = tmp_path / 'hostx_worker.py'
+  script.write_text(HOSTX_WORKER % ROOT)
+  rdzv = tmp_path / 'rdzv'
+  rdzv.mkdir(mode=0o700)
+  procs = []
+  for r in range(3):
+    env = dict(os.environ, RANK=str(r), WORLD_SIZE='3', KEY='hostx-test', DFH_RDZV_DIR=str(rdzv))
+    procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+  outs = [p.communicate(timeout=120) for p in procs]
+  for p, (out, err) in zip(procs, outs):
+    assert p.returncode == 0, err[-2000:]
+    assert out.strip().endswith('OK'), (out, err[-500:])
+  assert os.listdir(str(rdzv)) == []
