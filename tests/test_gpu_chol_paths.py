@@ -34,6 +34,12 @@ VARIANTS = {
   'forced-handoff-timeout': {'DFH_TEST_SPIN_LIMIT': '0'},
   'forced-handoff-timeout+resident': {'DFH_TEST_SPIN_LIMIT': '0', 'DFH_CHOL_LR_MIN_REM': '640'},
   'no-handoffs': {'DFH_CHOL_SAFE': '1'},
+  # round 4: the one-launch panel in its round-3 form (strip rows in the accumulators' rows; fences or
+  # write-through hand-offs), and the transposed form in lock-step batches / with lazy polling
+  'fused-panels-round3-form': {'DFH_CHOL_FUSED_TR': '0', 'DFH_CHOL_FUSED_SC1': '0'},
+  'fused-panels-round3-form+write-through': {'DFH_CHOL_FUSED_TR': '0', 'DFH_CHOL_FUSED_SC1': '1'},
+  'fused-panels-round3-form-in-batches': {'DFH_CHOL_FUSED_TR': '0', 'DFH_CHOL_FUSED_MAX_BATCH': '64'},
+  'transposed-panels-lazy-polling': {'DFH_CHOL_PROG_SLEEP': '64', 'DFH_CHOL_FUSED_MAX_BATCH': '64'},
 }
 
 
