@@ -1557,8 +1557,11 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
   // 8192 8.05 -> 7.07, 16384 34.8 -> 33.4.  Large lock-step batches keep the pivot steps + strips: their
   // workgroups would spend the diagonal chain's 190 us spinning.
   static const int fused_on = []() { const char* e = getenv("DFH_CHOL_FUSED"); return e ? atoi(e) : 1; }();
-  // (lock-step batches of up to 16 gain 5-14 % from it as well -- tools/time_lml_batch.py --, 32 and more lose)
-  static const int fused_max_batch = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : 16; }();
+  // (round 3: lock-step batches of up to 16 gained 5-14 % from it as well, 32 and more lost.  Round 4, with the
+  //  transposed panel -- tools/time_lml_batch.py, tools/r4_run18.sh: 32 matrices gain 4 % (n = 3000) to 20 % (n = 600),
+  //  64 matrices 7-21 % up to n = 1500 and nothing at n = 3000: up to 32 matrices always, up to 64 while n <= 2048)
+  static const int fused_max_batch_env = []() { const char* e = getenv("DFH_CHOL_FUSED_MAX_BATCH"); return e ? atoi(e) : -1; }();
+  const int fused_max_batch = fused_max_batch_env >= 0 ? fused_max_batch_env : (n <= 2048 ? 64 : 32);
   const bool fused_mode = fused_on && nbatch <= fused_max_batch && !safe;   // safe: no inter-workgroup hand-offs
   // DFH_CHOL_FUSED_TR=0: the round-3 form of the one-launch panel (strip rows in the accumulators' rows)
   static const bool fused_tr = env_int("DFH_CHOL_FUSED_TR", 1) != 0;
