@@ -410,11 +410,10 @@ class EuclideanGPFitter(object):
       raise ValueError('gp_hyperparams should be of length %d. Given length: %d.'%(
           self.num_hps, len(gp_cts_hps) + len(gp_dscr_hps)))
     mean_func, _, noise_var, gp_cts_hps = self._mean_and_noise_from_hps(gp_cts_hps)
-    ret_gp, ret_cts_hps, ret_dscr_hps = self._child_build_gp(mean_func, noise_var, \
-       gp_cts_hps, gp_dscr_hps, other_gp_params=other_gp_params, *args, **kwargs)
-    assert len(ret_cts_hps) == 0
-    assert len(ret_dscr_hps) == 0
-    return ret_gp
+    built = self._child_build_gp(mean_func, noise_var, gp_cts_hps, gp_dscr_hps,
+                                 other_gp_params=other_gp_params, *args, **kwargs)
+    assert all(len(left_over) == 0 for left_over in built[1:])     # every hyper-parameter found its place
+    return built[0]
 
   def _kernel_from_hps(self, gp_cts_hps, gp_dscr_hps, other_gp_params=None):
     """ euclidean_gp.py:325-336: the kernel of a candidate, and the left-over hyper-parameters. """
@@ -567,22 +566,21 @@ class EuclideanGPFitter(object):
     self.hp_tune_results = {}
     for method in self.methods_to_use:
       ret = self.fit_gp(num_samples, method)
-      if ret[0] in ('fitted_gp', 'post_fitted_gp'):
-        self.hp_tune_results[method] = (ret[0], ret[1])
-      elif ret[0] == 'sample_hps_with_probs':
-        sample_hps = list(zip(ret[1], ret[2], ret[3]))
-        sample_probs = ret[-1]
-        if sum(sample_probs > 0) >= num_samples:
-          to_replace = self.options.rand_exp_sampling_replace
-        else:
-          to_replace = True
-        use_hps_idxs = np.random.choice(len(sample_hps), size=(num_samples,),
-                                        replace=to_replace, p=sample_probs)
-        self.hp_tune_results[method] = (ret[0], [sample_hps[idx] for idx in use_hps_idxs])
-      elif ret[0] == 'post_sample_hps_with_probs':
-        self.hp_tune_results[method] = (ret[0], list(zip(ret[1], ret[2], ret[3])))
+      kind = ret[0]
+      if kind in ('fitted_gp', 'post_fitted_gp'):
+        kept = ret[1]
+      elif kind == 'sample_hps_with_probs':
+        # num_samples of the weighted candidates; without replacement only if the option says so AND enough
+        # of them carry weight (gp_core.py:762-770)
+        candidates, probs = list(zip(*ret[1:4])), ret[-1]
+        replace = True if sum(probs > 0) < num_samples else self.options.rand_exp_sampling_replace
+        picks = np.random.choice(len(candidates), size=(num_samples,), replace=replace, p=probs)
+        kept = [candidates[idx] for idx in picks]
+      elif kind == 'post_sample_hps_with_probs':
+        kept = list(zip(*ret[1:4]))
       else:
-        raise ValueError('Unknown option %s for results of fit_gp.' % (ret[0]))
+        raise ValueError('Unknown option %s for results of fit_gp.' % (kind))
+      self.hp_tune_results[method] = (kind, kept)
 
   def get_next_gp(self):
     """ gp_core.py:728-741 """
