@@ -1075,9 +1075,10 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   a.info += blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   // (NOT through readfirstlane here, unlike in fused_step_t: with a scalar w the diagnostics build of this kernel
-  //  flagged pivot 5 of a diagonally dominant block -- factor64_waves went wrong -- while the product build of the
-  //  same source passed the GPU suite; tools/r4_run10.sh.  Not understood; the vector form is the one both builds
-  //  agree on, and both builds run the factorisation tests.)
+  //  flagged pivot 5 of a diagonally dominant block -- columns 0..3 of strip 0's 64 x 64 block right, NaN from
+  //  column 4 on (tools/dbg_panel.py compares the published blocks with LAPACK) -- while the product build of the
+  //  same source passed the GPU suite; tools/r4_run10.sh.  Not understood (the owner steps' ISA reads right);
+  //  the vector form is the one both builds agree on, and both builds run the whole GPU suite.)
   const int w = tid >> 6;
   const int kq = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.x;
@@ -2193,6 +2194,15 @@ extern "C" int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, doubl
 }
 // Diagnostics hook: `reps` launches of the one-launch panel on a synthetic SPD 512 x 512 block with `rows_below`
 // rows under it; ms_out[reps] per launch (HIP events), stamps_out [(8 + strips below)][64] from the last launch.
+// A_out (optional, [(512 + rows_below) x 512]): the input block; Lfac_out (optional, [8][64][64]): the factored
+// 64 x 64 diagonal blocks as the strips published them -- for a host-side comparison with LAPACK.
+extern "C" int dfh_debug_panel_data(double* A_out, double* Lfac_out);
+static std::vector<double> g_dbg_A, g_dbg_L;
+extern "C" int dfh_debug_panel_data(double* A_out, double* Lfac_out) {
+  if (A_out) for (size_t i = 0; i < g_dbg_A.size(); ++i) A_out[i] = g_dbg_A[i];
+  if (Lfac_out) for (size_t i = 0; i < g_dbg_L.size(); ++i) Lfac_out[i] = g_dbg_L[i];
+  return (int)g_dbg_A.size();
+}
 extern "C" int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, double* ms_out, long long* stamps_out) {
   DFH_ARG(ctx && reps > 0 && rows_below >= 0 && ms_out && stamps_out);
   DFH_HIP(hipSetDevice(ctx->device));
@@ -2243,6 +2253,9 @@ extern "C" int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, do
     ms_out[r] = ms;
   }
   DFH_HIP(hipMemcpy(stamps_out, d_st, (size_t)nwg * 64 * 8, hipMemcpyDeviceToHost));
+  g_dbg_A = h;
+  g_dbg_L.resize((size_t)8 * PB * PB);
+  DFH_HIP(hipMemcpy(g_dbg_L.data(), scr, g_dbg_L.size() * 8, hipMemcpyDeviceToHost));
   long long bad = 0;
   DFH_HIP(hipMemcpy(&bad, d_info, 8, hipMemcpyDeviceToHost));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -23,6 +23,9 @@ int dfh_debug_diag_step(dfh_ctx* ctx, int reps, int rows_below, double* ms_per_l
  * `rows_below` rows under it: ms_out[reps] per launch; stamps_out[(8 + ceil(rows_below/64))][64] =
  * s_memrealtime (100 MHz) at the marked points of the last launch (tools/dbg_panel.py decodes them). */
 int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, double* ms_out, long long* stamps_out);
+/* input block and published 64 x 64 factor blocks of the last dfh_debug_panel_stamps call (either may be NULL);
+ * returns the number of doubles of the input block.                                                        */
+int dfh_debug_panel_data(double* A_out, double* Lfac_out);
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,18 @@ reps = 20
 nwg = 8 + (rows + 63) // 64
 ms = (C.c_double * reps)(); st = (C.c_longlong * (nwg * 64))()
 rc = lib.dfh_debug_panel_stamps(eng.ctx, reps, rows, ms, st)
+# the published diagonal factor blocks against LAPACK
+lib.dfh_debug_panel_data.restype = C.c_int
+lib.dfh_debug_panel_data.argtypes = [C.c_void_p, C.c_void_p]
+A = np.empty((512 + rows, 512)); Lf = np.empty((8, 64, 64))
+lib.dfh_debug_panel_data(A.ctypes.data_as(C.c_void_p), Lf.ctypes.data_as(C.c_void_p))
+Lref = np.linalg.cholesky(A[:512])
+for s in range(8):
+  blk = Lref[64 * s:64 * s + 64, 64 * s:64 * s + 64]
+  err = np.abs(np.tril(Lf[s]) - blk)
+  i, j = np.unravel_index(np.argmax(err), err.shape)
+  print('factor block %d: max |L - LAPACK| = %.2e at (%d, %d)%s' % (s, err.max(), i, j, '' if err.max() < 1e-12 else '   <-- WRONG; first bad column %d'
+        % int(np.argmax((err > 1e-12).any(axis=0)))))
 t = np.array(list(st), dtype=np.int64).reshape(nwg, 64) * 0.01      # microseconds
 if rc != 0:
   from dragonfly_amd import _lib
