@@ -76,7 +76,7 @@ def rel_elem(a, b):
   a, b = np.asarray(a, dtype=float).ravel(), np.asarray(b, dtype=float).ravel()
   if b.size == 0:
     return 0.0
-  keep = np.abs(b) >= ELEM_MASK * np.max(np.abs(b))
+  keep = (np.abs(b) >= ELEM_MASK * np.max(np.abs(b))) & (b != 0)
   return float(np.max(np.abs(a[keep] - b[keep]) / np.abs(b[keep]))) if keep.any() else 0.0
 
 

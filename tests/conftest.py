@@ -37,7 +37,7 @@ def relerr_elem(a, b):
   b = np.asarray(b, dtype=float).ravel()
   if not b.size:
     return 0.0
-  keep = np.abs(b) >= ELEM_MASK * np.max(np.abs(b))
+  keep = (np.abs(b) >= ELEM_MASK * np.max(np.abs(b))) & (b != 0)
   return float(np.max(np.abs(a[keep] - b[keep]) / np.abs(b[keep]))) if keep.any() else 0.0
 
 
