@@ -727,6 +727,7 @@ struct FusedArgs {
   // with agent-coherent loads (sc1), the flags are relaxed: no cache-wide maintenance on the chain.
   int sc1;
   int prog_sleep;               // s_sleep argument of the polls that are not on the chain (waits for another strip's X_cJ)
+  int g0;                       // strip index of the launch's first workgroup (0; or 8: a launch of the rows-below strips alone)
 #ifdef DFH_DEBUG_HOOKS
   long long* stamps = nullptr;  // dfh_debug_panel_stamps: [strip][64] s_memrealtime (100 MHz) at the points marked FSTAMP
 #endif
@@ -808,14 +809,14 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
   int* flag = a.sync; int* prog = a.sync + 8;
   if (J < s) {
     fused_wait(flag + J, a.epoch, a);
-    FSTAMP(a, blockIdx.x, 1 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 1 + 4 * J);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Lj[(w + 4 * r) * SK_LD + lane] = a.Lfac[J * PB * PB + (w + 4 * r) * PB + lane];
     for (int i = tid; i < 4 * 16 * 16; i += 256)
       li[(i >> 8) * (16 * SK_TD) + ((i >> 4) & 15) * SK_TD + (i & 15)] =
           a.Linv16[J * (4 * 16 * 17) + (i >> 8) * (16 * 17) + ((i >> 4) & 15) * 17 + (i & 15)];
     __syncthreads();
-    FSTAMP(a, blockIdx.x, 2 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 2 + 4 * J);
     // ---- row solve of block J (as in panel_strip_kernel) ----
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -849,7 +850,7 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
     for (int i = 0; i < 16; ++i)
       if (i < rows_left) Rw[(long)i * a.lda + J * PB + lane] = Xw[i * SK_LD + lane];
     if (diag) fused_publish(prog + s, a.epoch * 16 + J + 1);   // X_sJ is out (later diagonal strips and the rows below read it)
-    FSTAMP(a, blockIdx.x, 3 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 3 + 4 * J);
     double xa[16];
 #pragma unroll
     for (int st = 0; st < 16; ++st) xa[st] = -Xw[l15 * SK_LD + 4 * st + kq];
@@ -875,7 +876,7 @@ __device__ __forceinline__ void fused_step(const FusedArgs& a, double4_t (&acc)[
                                                                     acc[4 * c + (i & 3)], 0, 0, 0);
     }
     __syncthreads();                                   // Xall / Lj / li are free for the next step
-    FSTAMP(a, blockIdx.x, 4 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 4 + 4 * J);
   }
 }
 
@@ -930,7 +931,7 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
   constexpr bool sc1 = true;        // the transposed panel always hands over with write-through stores / coherent loads
   if (J < s) {
     fused_wait_sc1(flag + J, a.epoch, a, !(diag && J == s - 1));
-    FSTAMP(a, blockIdx.x, 1 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 1 + 4 * J);
     {
       double pre[16], prei[4];                         // all loads in flight before the first LDS write
 #pragma unroll
@@ -949,7 +950,7 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
       }
     }
     __syncthreads();
-    FSTAMP(a, blockIdx.x, 2 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 2 + 4 * J);
     // ---- row solve of block J, 16-column stages, right-looking; xn[b] = -X_b^T ----
     // (the accumulator tiles of block J are only ever read from here on: the solved block lives in xn and in LDS, so
     //  that no accumulator tile is written by the vector unit -- they stay in the AGPR half of the register file)
@@ -963,12 +964,12 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (b == 3 && last_step) {
-        FSTAMP(a, blockIdx.x, 48);
+        FSTAMP(a, blockIdx.x + a.g0, 48);
         __syncthreads();                               // columns 0 .. 47 of all four waves' X_sJ are in Xall
-        FSTAMP(a, blockIdx.x, 49);
+        FSTAMP(a, blockIdx.x + a.g0, 49);
         if constexpr (J + 1 < 8) strip_update_t<0, 12>(acc, J + 1, Xall, xn, l15, kq);
       }
-      if (b == 3 && last_step) FSTAMP(a, blockIdx.x, 50);
+      if (b == 3 && last_step) FSTAMP(a, blockIdx.x + a.g0, 50);
       // T_b^T = the tile (which carries the even-numbered k-steps of the earlier stages' updates) + the odd chain:
       // the association of panel_strip_kernel / diag_step64_kernel / fused_step (two accumulators per product,
       // added at the end), so that every schedule of the factorisation rounds alike -- results do not depend on
@@ -993,7 +994,7 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        if (last_step) FSTAMP(a, blockIdx.x, 51);
+        if (last_step) FSTAMP(a, blockIdx.x + a.g0, 51);
         const double* gi = a.Linv16 + J * (4 * 16 * 17) + 3 * (16 * 17) + l15 * 17 + kq;
         i0 = ld_in(gi, sc1); i1 = ld_in(gi + 4, sc1); i2 = ld_in(gi + 8, sc1); i3 = ld_in(gi + 12, sc1);
       }
@@ -1029,7 +1030,7 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
     // chain -- the announcement waits until the own-block product below has been issued: nobody needs X_s,s-1
     // before L_ss exists, and the wait for the stores' acknowledgement (1.5 us) leaves the chain.
     if (diag && !last_step) fused_publish_sc1(prog + s, a.epoch * 16 + J + 1);
-    FSTAMP(a, blockIdx.x, 3 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 3 + 4 * J);
     const int c_hi = diag ? s : 7;                     // last block this strip still needs
 #pragma unroll
     for (int c = J + 1; c < 8; ++c) {
@@ -1037,9 +1038,9 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
       const double* L;
       const bool own = diag && c == s;
       if (own) {
-        if (last_step) FSTAMP(a, blockIdx.x, 52);
+        if (last_step) FSTAMP(a, blockIdx.x + a.g0, 52);
         __syncthreads();                               // all four waves' rows of X_sJ are in Xall
-        if (last_step) FSTAMP(a, blockIdx.x, 53);
+        if (last_step) FSTAMP(a, blockIdx.x + a.g0, 53);
         L = Xall;                                      // own diagonal block: A_ss -= X_sJ X_sJ^T (lower tiles only)
       } else {
         // strip c has published X_cJ (its barrier also frees Lc)
@@ -1059,9 +1060,9 @@ __device__ __forceinline__ void fused_step_t(const FusedArgs& a, double4_t (&acc
     }
     // (the last step's X_s,s-1 is announced from the kernel's tail, behind the staging barrier: by then the
     //  stores' acknowledgement, 1.5 - 2 us for write-through, has arrived without anybody waiting for it)
-    if (last_step) FSTAMP(a, blockIdx.x, 54);
+    if (last_step) FSTAMP(a, blockIdx.x + a.g0, 54);
     __syncthreads();                                   // Xall / Lj / li are free for the next step
-    FSTAMP(a, blockIdx.x, 4 + 4 * J);
+    FSTAMP(a, blockIdx.x + a.g0, 4 + 4 * J);
   }
 }
 
@@ -1081,7 +1082,7 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   //  the vector form is the one both builds agree on, and both builds run the whole GPU suite.)
   const int w = tid >> 6;
   const int kq = lane >> 4, l15 = lane & 15;
-  const int g = blockIdx.x;
+  const int g = blockIdx.x + a.g0;   // (g0: the launch may hold only the rows-below strips, see cholesky_device_impl)
   const int nd = (a.nbk + PB - 1) / PB;              // diagonal strips (8 for a full panel)
   if (TR) a.sc1 = 1;                                 // the transposed panel's hand-offs are write-through / coherent loads
   if (a.resident) {
@@ -1710,7 +1711,7 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         fa.nbk = (int)NB; fa.rows_below = 0; fa.info = d_info; fa.pivot_base = (long)k0;
         fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
         fa.status = d_status; fa.spin_limit = spin_limit;
-        fa.sc1 = fused_sc1; fa.prog_sleep = fused_prog_sleep;
+        fa.sc1 = fused_sc1; fa.prog_sleep = fused_prog_sleep; fa.g0 = 0;
         fa.resident = sy;
         fa.wait_ptr = kb > 0 ? sy - 4 + 1 : nullptr;   // the sixteen... ten lower tiles of this diagonal block, out of update(kb-1)
         fa.wait_target = 10;
@@ -1786,6 +1787,13 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         if (e_copy_prev2) DFH_HIP(hipStreamWaitEvent(P, e_copy_prev2, 0));
       }
       const bool fused = fused_mode;                  // full panels, and the (last) partial one: identity padding
+      // (experiment, default OFF: measured slower -- n = 4096 2.16 -> 2.81 ms, 8192 6.28 -> 8.97 -- because the
+      //  rows-below launch on a normal-priority stream queues behind the trailing update's pending workgroups,
+      //  and a second high-priority stream made every schedule slower, presumably by sharing hardware queues;
+      //  tools/r4_run24.sh, docs/NOTES_r04.md)
+      static const bool split_on = env_int("DFH_CHOL_FUSED_SPLIT", 0) != 0;
+      const bool split = fused && split_on && nbatch == 1 && nbk == NB && rem > 0;
+      hipStream_t Q = ctx->bulk_normal;
       // Experiment switch (off): no look-ahead at all above DFH_CHOL_SERIAL_MIN_REM rows -- the one-launch
       // panel cannot be placed while the update runs and, pending, slows it (K = 1024 updates at 52 TF/s
       // against 64 alone); starting it only when the update has finished nevertheless LOSES (n = 16384
@@ -1800,9 +1808,28 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         fa.strideD = strideA; fa.strideL = strideL; fa.strideI = strideI;
         fa.status = d_status; fa.spin_limit = spin_limit;
         fa.resident = nullptr; fa.wait_ptr = nullptr; fa.wait_target = 0; fa.sc1 = fused_sc1; fa.prog_sleep = fused_prog_sleep;
-        hipLaunchKernelGGL(fused_kernel, dim3((unsigned)((nbk + PB - 1) / PB + (rem + PB - 1) / PB), (unsigned)nbatch),
-                           dim3(256), FUSED_SMEM, P, fa);
-        DFH_LAUNCH_CHECK();
+        fa.g0 = 0;
+        if (!split) {
+          hipLaunchKernelGGL(fused_kernel, dim3((unsigned)((nbk + PB - 1) / PB + (rem + PB - 1) / PB), (unsigned)nbatch),
+                             dim3(256), FUSED_SMEM, P, fa);
+          DFH_LAUNCH_CHECK();
+        } else {
+          // Round 4: the eight diagonal strips and the strips of the rows below as TWO launches of the same kernel
+          // (the second with g0 = 8, on stream Q behind the larger part of the previous panel's look-ahead product):
+          // the diagonal chain of this panel then waits only for the 512 x 512 block it factors, not for the whole
+          // block column (rem x 512 x 512 at 24 TF/s in 64 x 64 tiles: 55 - 80 us of every panel of an n = 4096
+          // factorisation, tools/r4_run23.sh).  Both launches talk through the panel's flags as before; Q takes
+          // over everything P was made to wait for through e_copy.
+          DFH_HIP(hipEventRecord(e_copy, P));
+          hipLaunchKernelGGL(fused_kernel, dim3((unsigned)(NB / PB), 1), dim3(256), FUSED_SMEM, P, fa);
+          DFH_LAUNCH_CHECK();
+          DFH_HIP(hipStreamWaitEvent(Q, e_copy, 0));
+          fa.g0 = (int)(NB / PB);
+          hipLaunchKernelGGL(fused_kernel, dim3((unsigned)((rem + PB - 1) / PB), 1), dim3(256), FUSED_SMEM, Q, fa);
+          DFH_LAUNCH_CHECK();
+          DFH_HIP(hipEventRecord(e_diag, Q));
+          DFH_HIP(hipStreamWaitEvent(P, e_diag, 0));
+        }
       }
       // ---- 64-wide pivot steps: factor, solve every row below, update the rest of the panel ----
       for (int64_t j0 = 0; j0 < (fused ? 0 : nbk); j0 += PB) {
@@ -1842,7 +1869,18 @@ static int cholesky_device_impl(dfh_ctx* ctx, double* A, int64_t n, int64_t lda,
         if (e_trail_prev) DFH_HIP(hipStreamWaitEvent(P, e_trail_prev, 0));
         const int64_t nb1 = rem < NB ? rem : NB;
         double* C1 = A + (k0 + nbk) * lda + (k0 + nbk);   // rows k+1.., block column k+1
-        DFH_TRY(gemm_f64(ctx, 0, rem, nb1, kw, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
+        if (!split || rem <= nb1) {
+          DFH_TRY(gemm_f64(ctx, 0, rem, nb1, kw, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
+        } else {
+          // the next diagonal block on the chain's stream, the rows under it on Q (the next panel's rows-below
+          // launch follows them there)
+          DFH_TRY(gemm_f64(ctx, GEMM_LOWER, nb1, nb1, kw, -1.0, A21, lda, A21, lda, 1.0, C1, lda, C1, lda, &bA));
+          StreamSwap on_q(ctx, Q);
+          DFH_HIP(hipStreamWaitEvent(Q, e_panel, 0));
+          if (e_trail_prev) DFH_HIP(hipStreamWaitEvent(Q, e_trail_prev, 0));
+          DFH_TRY(gemm_f64(ctx, 0, rem - nb1, nb1, kw, -1.0, A21 + nb1 * lda, lda, A21, lda, 1.0, C1 + nb1 * lda, lda,
+                           C1 + nb1 * lda, lda, &bA));
+        }
       }
     }
     DFH_TRY(aux_block(e_panel, X));
@@ -2242,7 +2280,7 @@ extern "C" int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, do
     fa.strideD = 0; fa.strideL = 0; fa.strideI = 0;
     fa.status = reinterpret_cast<unsigned long long*>(d_info + CHOL_MAX_BATCH + 8); fa.spin_limit = SPIN_LIMIT_DEFAULT;
     fa.resident = nullptr; fa.wait_ptr = nullptr; fa.wait_target = 0; fa.sc1 = env_int("DFH_CHOL_FUSED_SC1", 1) != 0 ? 1 : 0;
-    fa.prog_sleep = env_int("DFH_CHOL_PROG_SLEEP", 8);
+    fa.prog_sleep = env_int("DFH_CHOL_PROG_SLEEP", 8); fa.g0 = 0;
     fa.stamps = d_st;
     DFH_HIP(hipEventRecord(e0, S));
     hipLaunchKernelGGL(fused_kernel, dim3((unsigned)nwg, 1), dim3(256), FUSED_SMEM, S, fa);

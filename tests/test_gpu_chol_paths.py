@@ -39,6 +39,8 @@ VARIANTS = {
   'fused-panels-round3-form': {'DFH_CHOL_FUSED_TR': '0', 'DFH_CHOL_FUSED_SC1': '0'},
   'fused-panels-round3-form+write-through': {'DFH_CHOL_FUSED_TR': '0', 'DFH_CHOL_FUSED_SC1': '1'},
   'fused-panels-round3-form-in-batches': {'DFH_CHOL_FUSED_TR': '0', 'DFH_CHOL_FUSED_MAX_BATCH': '64'},
+  'split-panels': {'DFH_CHOL_FUSED_SPLIT': '1'},
+  'split-panels+paired': {'DFH_CHOL_FUSED_SPLIT': '1', 'DFH_CHOL_PAIR_MIN_REM': '0'},
   'transposed-panels-lazy-polling': {'DFH_CHOL_PROG_SLEEP': '64', 'DFH_CHOL_FUSED_MAX_BATCH': '64'},
 }
 
