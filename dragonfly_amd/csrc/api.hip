@@ -1121,14 +1121,12 @@ __global__ __launch_bounds__(256) void k_lml_finish_small64(const double* __rest
   }
 }
 
-extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* X,
-                                int64_t n, int64_t d, const double* y, const double* mean_consts,
-                                const double* noise_vars, int flags, double* lml_out,
-                                int32_t* jitter_powers) {
-  DFH_ARG(ctx && descs && nb >= 0 && X && y && noise_vars && lml_out && n >= 1 && d >= 1);
-  if (nb == 0) return DFH_OK;
-  for (int c = 0; c < nb; ++c) DFH_ARG(descs[c].dim == d);
-  DFH_HIP(hipSetDevice(ctx->device));
+// The lock-step schedule: groups of up to CHOL_MAX_BATCH candidates through the batched cholesky_device (any n);
+// cand_base: index of descs[0] in the caller's list (error messages).
+static int lml_batch_lockstep(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* dX,
+                              int64_t n, int64_t d, const double* y, const double* mean_consts,
+                              const double* noise_vars, int flags, double* lml_out,
+                              int32_t* jitter_powers, int cand_base) {
   const int64_t NB = CHOL_NB;
   const int64_t nblk = (n + NB - 1) / NB;
   const int64_t ldK = (n + 1) & ~(int64_t)1;                 // even leading dimension: 16-byte row starts
@@ -1140,30 +1138,7 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   const int64_t by_mem = std::max<int64_t>(1, (int64_t)(group_gib * 1073741824.0 / ((double)strideK * 8.0)));
   const int G = (int)std::min<int64_t>(std::min<int64_t>(nb, CHOL_MAX_BATCH), by_mem);
   std::vector<KernDev> kds((size_t)G);       // device images live in one scratch blob: nothing to free
-  const double *dX = nullptr, *dy = nullptr;
-  DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
-  static const bool tiny_enabled = []() { const char* e = getenv("DFH_LML_TINY"); return e ? atoi(e) != 0 : true; }();
-  if (tiny_enabled && n <= TINY_MAX_N) {
-    // small problems: pack, Gram matrix, stable_cholesky and the solve of every candidate in ONE
-    // launch (kernmat.hip: k_lml_tiny)
-    std::vector<KernDev> all((size_t)nb);
-    for (int c = 0; c < nb; ++c) DFH_TRY(kerndev_build_host(&descs[c], &all[c]));
-    if (lml_tiny_applies(all.data(), nb, n)) {
-      std::vector<double> y_host((size_t)n), ld_dot((size_t)nb * 2);
-      if (is_device_ptr(y)) {
-        DFH_HIP(hipMemcpyAsync(y_host.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        DFH_HIP(hipStreamSynchronize(ctx->stream));
-      } else {
-        std::memcpy(y_host.data(), y, (size_t)n * 8);
-      }
-      SectionTimer t(ctx, DFH_T_CHOL);
-      DFH_TRY(lml_tiny_batch(ctx, all.data(), nb, dX, n, d, y_host.data(), noise_vars, mean_consts,
-                             !(flags & DFH_FIT_NO_JITTER), ld_dot.data(), jitter_powers));
-      for (int c = 0; c < nb; ++c)     // gp_core.py:224-226
-        lml_out[c] = -0.5 * ld_dot[2 * c + 1] - ld_dot[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);
-      return DFH_OK;
-    }
-  }
+  const double* dy = nullptr;
   DFH_TRY(to_device(ctx, y, (size_t)n * 8, SCR_STAGE_B, &dy));
   double *Kb = nullptr, *invb = nullptr, *vecs = nullptr, *red = nullptr, *dpar = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * strideK * 8, (void**)&Kb));
@@ -1235,7 +1210,7 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
         if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;
         if (piv[c] == 0) continue;
         if (flags & DFH_FIT_NO_JITTER) {
-          dfh_set_error("Matrix is not positive definite (candidate %d, pivot %lld)", c0 + c, (long long)piv[c]);
+          dfh_set_error("Matrix is not positive definite (candidate %d, pivot %lld)", cand_base + c0 + c, (long long)piv[c]);
           return DFH_ERR_NOT_PD;
         }
         auto rebuild = [&]() -> int { return build_M(c); };
@@ -1308,6 +1283,147 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
     }
   }
   return DFH_OK;
+}
+
+// One workgroup per candidate (chol.hip: lml_wg_kernel), 128 < n <= LMLWG_MAX_N: per group of up to one candidate
+// per CU three launches -- pack, Gram matrices, factor + forward solve + reductions -- and one copy back.  A
+// candidate whose matrix does not factor as it stands (or whose augmented pivot fails) is handed to the
+// lock-step schedule on its own, which runs the stable_cholesky ladder exactly as before.
+static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* dX,
+                        int64_t n, int64_t d, const double* y, const double* mean_consts,
+                        const double* noise_vars, int flags, double* lml_out, int32_t* jitter_powers) {
+  const int64_t nbt = (n + 1 + 63) / 64, NP = 64 * nbt, sK = NP * NP;
+  static const double group_gib = []() { const char* e = getenv("DFH_LML_GROUP_GIB"); double v = e ? atof(e) : 8.0; return v > 0.0 ? v : 8.0; }();
+  static const int group_max = []() { const char* e = getenv("DFH_LML_WG_GROUP"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int64_t by_mem = std::max<int64_t>(1, (int64_t)(group_gib * 1073741824.0 / ((double)sK * 8.0)));
+  const int64_t by_cu = group_max > 0 ? group_max : std::max(1, ctx->n_cu);
+  const int G = (int)std::min<int64_t>(std::min<int64_t>(nb, by_cu), by_mem);
+  const double* dy = nullptr;
+  DFH_TRY(to_device(ctx, y, (size_t)n * 8, SCR_STAGE_B, &dy));
+  std::vector<double> y_host((size_t)n);
+  if (is_device_ptr(y)) {
+    DFH_HIP(hipMemcpyAsync(y_host.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    std::memcpy(y_host.data(), y, (size_t)n * 8);
+  }
+  double *Kb = nullptr, *red = nullptr, *dpar = nullptr;
+  long long* dinfo = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * sK * 8, (void**)&Kb));
+  DFH_TRY(scratch_get(ctx, SCR_OUT2, (size_t)std::max(256, G * 16), (void**)&red));
+  DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)std::max(256, G * 24), (void**)&dpar));   // {aug. diagonal, mean, noise} per candidate
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)std::max(256, G * 8), (void**)&dinfo));
+  std::vector<KernDev> kds((size_t)G);
+  std::vector<double> hred((size_t)G * 2), hpar((size_t)G * 3);
+  std::vector<long long> hinfo((size_t)G);
+  std::vector<char> skip((size_t)G, 0);
+  std::vector<int> redo;                       // candidates for the lock-step schedule
+  for (int c0 = 0; c0 < nb; c0 += G) {
+    const int g = std::min(G, nb - c0);
+    int64_t Pmax = 0, parts_max = 0;
+    size_t blob_bytes = 0;
+    bool uniform = true;                       // structurally identical single-part kernels
+    for (int c = 0; c < g; ++c) {
+      kds[c] = KernDev();
+      DFH_TRY(kerndev_build_host(&descs[c0 + c], &kds[c]));
+      Pmax = std::max<int64_t>(Pmax, kds[c].P);
+      parts_max = std::max<int64_t>(parts_max, kds[c].n_parts);
+      blob_bytes += kerndev_blob_bytes(kds[c]);
+      uniform = uniform && !kds[c].multi && kds[c].n_parts == 1 && kds[c].P == kds[0].P &&
+                kerndev_blob_bytes(kds[c]) == kerndev_blob_bytes(kds[0]);
+    }
+    void* blob = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_AUG2, blob_bytes, &blob));
+    DFH_TRY(kerndev_upload_many(ctx, kds.data(), g, blob, blob_bytes));
+    double *Xpb = nullptr, *Npb = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_XS, (size_t)g * n * Pmax * 8, (void**)&Xpb));
+    DFH_TRY(scratch_get(ctx, SCR_XS2, (size_t)g * n * parts_max * 8, (void**)&Npb));
+    const int64_t sXp = n * Pmax, sNp = n * parts_max;
+    for (int c = 0; c < g; ++c) {
+      // the augmented row's diagonal entry: c = 1 + |y - m|^2 / s2 > z.z (the eigenvalues of K + s2 I are >= s2)
+      const double m = mean_consts ? mean_consts[c0 + c] : 0.0, s2 = noise_vars[c0 + c];
+      double r2 = 0.0;
+      for (int64_t i = 0; i < n; ++i) { const double r = y_host[(size_t)i] - m; r2 = fma(r, r, r2); }
+      hpar[c] = 1.0 + r2 / s2;
+      hpar[g + c] = m;
+      hpar[2 * g + c] = s2;
+      // (no noise, or a ratio beyond the double range: nothing bounds z.z -- such a candidate takes the lock-step schedule)
+      skip[c] = !(s2 > 0.0) || !std::isfinite(hpar[c]);
+      if (skip[c]) hpar[c] = 1.0;
+    }
+    DFH_HIP(hipMemcpyAsync(dpar, hpar.data(), (size_t)g * 24, hipMemcpyHostToDevice, ctx->stream));
+    {
+      SectionTimer t(ctx, DFH_T_KERNMAT);
+      if (uniform) {
+        const int64_t sBlob = (int64_t)kerndev_blob_bytes(kds[0]);
+        DFH_TRY(pack_scaled(ctx, kds[0], 0, 1, false, dX, n, d, Xpb, Npb, g, sBlob, sXp, sNp));
+        DFH_TRY(kernmat_sym_batch(ctx, kds[0], g, sBlob, Xpb, sXp, Npb, sNp, n, dpar + 2 * g, Kb, sK, NP));
+      } else {
+        for (int c = 0; c < g; ++c) {
+          double* Xp = Xpb + c * sXp; double* Np = Npb + c * sNp;
+          DFH_TRY(pack_scaled(ctx, kds[c], 0, kds[c].n_parts, false, dX, n, d, Xp, Np));
+          DFH_TRY(kernmat_packed(ctx, kds[c], 0, kds[c].n_parts, true, Xp, Np, n, Xp, Np, n, true, noise_vars[c0 + c],
+                                 Kb + c * sK, NP));
+        }
+      }
+    }
+    {
+      SectionTimer t(ctx, DFH_T_CHOL);
+      DFH_TRY(lml_wg_batch(ctx, Kb, sK, NP, n, g, dy, dpar, red, dinfo));
+    }
+    DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)g * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < g; ++c) {
+      if (skip[c] || hinfo[c] != 0 || !std::isfinite(hred[2 * c]) || !std::isfinite(hred[2 * c + 1])) { redo.push_back(c0 + c); continue; }
+      if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;
+      lml_out[c0 + c] = -0.5 * hred[2 * c + 1] - hred[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);     // gp_core.py:224-226
+    }
+  }
+  for (int c : redo)
+    DFH_TRY(lml_batch_lockstep(ctx, descs + c, 1, dX, n, d, y, mean_consts ? mean_consts + c : nullptr, noise_vars + c, flags,
+                               lml_out + c, jitter_powers ? jitter_powers + c : nullptr, c));
+  return DFH_OK;
+}
+
+extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* X,
+                                int64_t n, int64_t d, const double* y, const double* mean_consts,
+                                const double* noise_vars, int flags, double* lml_out,
+                                int32_t* jitter_powers) {
+  DFH_ARG(ctx && descs && nb >= 0 && X && y && noise_vars && lml_out && n >= 1 && d >= 1);
+  if (nb == 0) return DFH_OK;
+  for (int c = 0; c < nb; ++c) DFH_ARG(descs[c].dim == d);
+  DFH_HIP(hipSetDevice(ctx->device));
+  const double* dX = nullptr;
+  DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
+  static const bool tiny_enabled = []() { const char* e = getenv("DFH_LML_TINY"); return e ? atoi(e) != 0 : true; }();
+  if (tiny_enabled && n <= TINY_MAX_N) {
+    // small problems: pack, Gram matrix, stable_cholesky and the solve of every candidate in ONE
+    // launch (kernmat.hip: k_lml_tiny)
+    std::vector<KernDev> all((size_t)nb);
+    for (int c = 0; c < nb; ++c) DFH_TRY(kerndev_build_host(&descs[c], &all[c]));
+    if (lml_tiny_applies(all.data(), nb, n)) {
+      std::vector<double> y_host((size_t)n), ld_dot((size_t)nb * 2);
+      if (is_device_ptr(y)) {
+        DFH_HIP(hipMemcpyAsync(y_host.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        DFH_HIP(hipStreamSynchronize(ctx->stream));
+      } else {
+        std::memcpy(y_host.data(), y, (size_t)n * 8);
+      }
+      SectionTimer t(ctx, DFH_T_CHOL);
+      DFH_TRY(lml_tiny_batch(ctx, all.data(), nb, dX, n, d, y_host.data(), noise_vars, mean_consts,
+                             !(flags & DFH_FIT_NO_JITTER), ld_dot.data(), jitter_powers));
+      for (int c = 0; c < nb; ++c)     // gp_core.py:224-226
+        lml_out[c] = -0.5 * ld_dot[2 * c + 1] - ld_dot[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);
+      return DFH_OK;
+    }
+  }
+  // one workgroup per candidate up to n = 2047 (DFH_LML_WG=0: the lock-step schedule for every n)
+  static const int wg_min_batch = []() { const char* e = getenv("DFH_LML_WG_MIN_BATCH"); return e ? atoi(e) : 1; }();
+  static const bool wg_enabled = []() { const char* e = getenv("DFH_LML_WG"); return e ? atoi(e) != 0 : true; }();
+  if (wg_enabled && n <= LMLWG_MAX_N && nb >= wg_min_batch)
+    return lml_batch_wg(ctx, descs, nb, dX, n, d, y, mean_consts, noise_vars, flags, lml_out, jitter_powers);
+  return lml_batch_lockstep(ctx, descs, nb, dX, n, d, y, mean_consts, noise_vars, flags, lml_out, jitter_powers, 0);
 }
 
 extern "C" int dfh_gp_get(dfh_gp* gp, int what, double* out) {

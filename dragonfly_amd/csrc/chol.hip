@@ -528,6 +528,265 @@ static_assert(SPP == SPP_STAGE, "staging stride");
 constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17 + 8 * 16 * 17) * 8;   // image, panel rows, rdiag, ring, layout buffers, 16-blocks + inverses
 
 // ---------------------------------------------------------------------------------------------
+// The whole tuning objective of one hyper-parameter candidate in ONE workgroup (round 5): Cholesky
+// factor of the candidate's (n + 1) x (n + 1) AUGMENTED matrix
+//     [ K + s2 I   . ]        L_aug = [ L    0 ]      z = L^-1 (y - m)
+//     [ (y - m)^T  c ]                [ z^T  * ]
+// so that the forward solve of GP.build_posterior (gp_core.py:161-162) is finished when the factor is
+// -- the log marginal likelihood (gp_core.py:222-227) needs sum(log L_ii) and z.z only.  Replaces, for
+// 128 < n <= 2047 and lock-step groups of candidates (GPFitter._tuning_objective, gp_core.py:551-574),
+// the batched schedule of cholesky_device: at n = 1000 x 64 that was 44 launches, two one-launch panels
+// whose 1024 workgroups queue for 256 CUs, and 1.1 ms of 512-block inverses the likelihood never uses
+// (profiles/r05_lml_batch_before.txt).  Here a candidate never leaves its CU:
+//   left-looking over 64-column blocks j:  T_ij = A_ij - sum_{k<j} L_ik L_jk^T for the tile rows i >= j,
+//   two tile rows at a time, operands straight from L2 / HBM into MFMA fragments (no LDS, no barrier:
+//   each wave owns 16 rows of every tile and reads the 64 rows of block row j itself); then the diagonal
+//   tile through factor64_waves and the tiles below it through the 16-column MFMA substitution of
+//   diag_step64_kernel; every tile of A is read once and every tile of L written once.
+// The matrix is stored padded to NP = 64 ceil((n + 1) / 64) rows and columns; rows beyond n are not read
+// from memory but generated (row n: y - m and the diagonal entry c = 1 + |y - m|^2 / s2 > z.z, rows
+// beyond: identity), so the Gram kernel only has to fill the n x n part.
+// One workgroup per CU (the factor64_waves / substitution LDS images take 141 KB): the latency-bound
+// diagonal steps are NOT hidden behind another candidate's products -- the price of never waiting for
+// another workgroup.
+struct LmlWgArgs {
+  double* K; long sK; long ld;      // padded matrices, sK doubles apart, row stride ld
+  int n, nbt;                       // observations; tile rows = ceil((n + 1) / 64)
+  const double* y;                  // [n]
+  const double* par;                // [count] augmented diagonal entry c, then [count] prior mean m
+  int count;
+  double* out2;                     // [count][2]: sum(log L_ii), z.z
+  long long* info;                  // [count]: 1-based index of the first failing pivot (0: none)
+};
+
+// this wave's 16 x 64 slice of tile (i, j), as MFMA accumulators: acc[t][r] = element (64 i + 16 w + kq + 4 r, 64 j + 16 t + l15)
+__device__ __forceinline__ void lmlwg_load_tile(const LmlWgArgs& a, const double* __restrict__ Km, double mean, double cdiag,
+                                                int i, int j, int w, int kq, int l15, double4_t (&acc)[4]) {
+  const int n = a.n;
+  const long ld = a.ld;
+  if (64 * (i + 1) <= n) {                             // (uniform) every row of the tile is a row of K
+    const double* p = Km + (long)(64 * i + 16 * w + kq) * ld + 64 * j + l15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = p[(long)(4 * r) * ld + 16 * t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 64 * i + 16 * w + kq + 4 * r, gj = 64 * j + 16 * t + l15;
+        double v;
+        if (gi < n) v = (gj < n) ? Km[(long)gi * ld + gj] : 0.0;
+        else if (gi == n) v = (gj < n) ? a.y[gj] - mean : (gj == n ? cdiag : 0.0);
+        else v = (gi == gj) ? 1.0 : 0.0;
+        acc[t][r] = v;
+      }
+  }
+}
+
+// acc[q] += L[tile row i0 + q][0 : 64 j] L[tile row j][0 : 64 j]^T for q < RG, this wave's 16 rows.  Sixteen
+// columns per step: lane (kq, l15) holds columns 2 kq, 2 kq + 1 and 8 + 2 kq, 9 + 2 kq of its row (two 16-byte
+// loads, 64 contiguous bytes per row and instruction) and the four MFMAs of a step contract over the
+// columns {c, 2 + c, 4 + c, 6 + c} + {0, 8}: any assignment of columns to k-slots is a valid product as long
+// as both operands use the same one.  The next step's loads are in flight while this one multiplies.
+template <int RG>
+__device__ __forceinline__ void lmlwg_gemm(const double* __restrict__ Km, long ld, int j, int i0, int w, int kq, int l15,
+                                           double4_t (&acc)[2][4]) {
+  const int nch = 4 * j;                               // (even)
+  if (nch == 0) return;
+  const double* pa[RG];
+#pragma unroll
+  for (int q = 0; q < RG; ++q) pa[q] = Km + (long)(64 * (i0 + q) + 16 * w + l15) * ld + 2 * kq;
+  const double* pb = Km + (long)(64 * j + l15) * ld + 2 * kq;
+  double2_t a0[RG][2], b0[4][2], a1[RG][2], b1[4][2];
+  auto load = [&](int c, double2_t (&fa)[RG][2], double2_t (&fb)[4][2]) {
+    const int k0 = 16 * c;
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      fa[q][0] = *reinterpret_cast<const double2_t*>(pa[q] + k0);
+      fa[q][1] = *reinterpret_cast<const double2_t*>(pa[q] + k0 + 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fb[t][0] = *reinterpret_cast<const double2_t*>(pb + (long)(16 * t) * ld + k0);
+      fb[t][1] = *reinterpret_cast<const double2_t*>(pb + (long)(16 * t) * ld + k0 + 8);
+    }
+  };
+  auto mma = [&](const double2_t (&fa)[RG][2], const double2_t (&fb)[4][2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int q = 0; q < RG; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double av = (s & 1) ? fa[q][s >> 1].y : fa[q][s >> 1].x;
+          const double bv = (s & 1) ? fb[t][s >> 1].y : fb[t][s >> 1].x;
+          acc[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q][t], 0, 0, 0);
+        }
+  };
+  load(0, a0, b0);
+  for (int c = 0; c < nch; c += 2) {
+    load(c + 1, a1, b1);
+    mma(a0, b0);
+    if (c + 2 < nch) load(c + 2, a0, b0);
+    mma(a1, b1);
+  }
+}
+
+// X = T L_jj^-T for this wave's 16 x 64 slice T (in acc), by the 16-column substitution of diag_step64_kernel
+// (factor image Sp with perm16 columns, the inverses linv of its 16 x 16 diagonal blocks); X goes to the wave's
+// rows Rw of the LDS row buffer and from there to G (row stride ld), a 512-byte row segment per store.
+__device__ __forceinline__ void lmlwg_solve_store(const double4_t (&acc)[4], const double* Sp, const double* linv,
+                                                  double* Rw, double* Tt, double* __restrict__ G, long ld, int lane) {
+  const int kq = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    double4_t a1 = acc[b], a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const double av = Rw[l15 * PBP + 16 * bp + 4 * st + kq];                               // X_b'[i][k]
+        const double bv = -Sp[(16 * b + l15) * SPP_STAGE + perm16(16 * bp + 4 * st + kq)];     // -L[16b+j][16b'+k]
+        if (st & 1) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a2, 0, 0, 0);
+        else a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a1, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tt[(kq + 4 * r) * 17 + l15] = a1[r] + a2[r];
+    COMPILER_BARRIER();                              // same wave: LDS executes its operations in order
+    double4_t x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const double av = Tt[l15 * 17 + 4 * st + kq];                                            // T[i][k]
+      const double bv = linv[b * (16 * 17) + l15 * 17 + 4 * st + kq];                          // Linv_bb[j][k]
+      if (st & 1) x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x2, 0, 0, 0);
+      else x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+    }
+    COMPILER_BARRIER();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rw[(kq + 4 * r) * PBP + 16 * b + l15] = x[r] + x2[r];
+    COMPILER_BARRIER();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) G[(long)i * ld + lane] = Rw[i * PBP + lane];
+  COMPILER_BARRIER();                                // (the next tile's substitution overwrites Rw)
+}
+
+__global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* Sp = dsm;                                  // [64][SPP] staged diagonal tile, then the factor image (perm16 columns)
+  double* R = dsm + PB * SPP_STAGE;                  // [64][65] solved rows, 16 per wave
+  double* colbuf = R + PB * PBP;                     // [64] reciprocal diagonal
+  double* ring = colbuf + PB;                        // [64][64] published columns of factor64_waves
+  double* tbuf0 = ring + PB * PB;                    // 3 x [64][17] layout buffers, then 4 x [16][17] substitution tiles
+  double* lbb = tbuf0 + 3 * PB * 17;                 // 4 x [16][17]
+  double* linv = lbb + 4 * 16 * 17;                  // 4 x [16][17] inverses of the factor's 16 x 16 diagonal blocks
+  double* rdiag = colbuf;
+  __shared__ int s_badv[4];
+  __shared__ int s_ring_timeout;
+  __shared__ double s_red[8];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+  double* __restrict__ Km = a.K + (long)c * a.sK;
+  const long ld = a.ld;
+  const int n = a.n, nbt = a.nbt;
+  const double cdiag = a.par[c], mean = a.par[a.count + c];
+  double* Rw = R + 16 * w * PBP;
+  double* Tt = tbuf0 + w * (16 * 17);
+  for (int j = 0; j < nbt; ++j) {
+    double4_t acc[2][4];
+    // ---- tile rows j (the diagonal tile) and j + 1 ----
+    const bool two = j + 1 < nbt;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[1][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    lmlwg_load_tile(a, Km, mean, cdiag, j, j, w, kq, l15, acc[0]);
+    if (two) lmlwg_load_tile(a, Km, mean, cdiag, j + 1, j, w, kq, l15, acc[1]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[q][t] = -acc[q][t];       // the products ADD: -T = -A + sum L L^T
+    if (two) lmlwg_gemm<2>(Km, ld, j, j, w, kq, l15, acc);
+    else lmlwg_gemm<1>(Km, ld, j, j, w, kq, l15, acc);
+    // the diagonal tile -> staged block (lower triangle, zero above)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + kq + 4 * r, col = 16 * t + l15;
+        Sp[row * SPP_STAGE + col] = (col <= row) ? -acc[0][t][r] : 0.0;
+      }
+    if (tid < PB) ring[tid * PB] = 0.0;                // row-0 entries double as the "published" flags
+    if (tid == 0) s_ring_timeout = 0;
+    __syncthreads();
+    {
+      double av[16];
+      double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
+      const int bad = factor64_waves<false>(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout);
+      if (lane == 0) s_badv[w] = bad;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Sp[lane * SPP_STAGE + perm16(16 * w + q)] = av[q];
+    }
+    __syncthreads();
+    const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
+    if (s_bad >= 0 || s_ring_timeout) {                // (uniform) not positive definite as it stands: the host takes the ladder
+      if (tid == 0) a.info[c] = 64ll * j + (s_bad >= 0 ? s_bad : 0) + 1;
+      return;
+    }
+    {
+      // L_jj to its place (the likelihood reads its diagonal; later block columns never read a diagonal tile)
+      const int pk = perm16(lane);
+      double* Ljj = Km + (long)(64 * j) * ld + 64 * j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ljj[(long)(w + 4 * r) * ld + lane] = Sp[(w + 4 * r) * SPP_STAGE + pk];
+    }
+    if (two) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[1][t] = -acc[1][t];
+      lmlwg_solve_store(acc[1], Sp, linv, Rw, Tt, Km + (long)(64 * (j + 1) + 16 * w) * ld + 64 * j, ld, lane);
+    }
+    // ---- the tile rows below, two at a time ----
+    for (int i0 = j + 2; i0 < nbt; i0 += 2) {
+      const bool two2 = i0 + 1 < nbt;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[1][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      lmlwg_load_tile(a, Km, mean, cdiag, i0, j, w, kq, l15, acc[0]);
+      if (two2) lmlwg_load_tile(a, Km, mean, cdiag, i0 + 1, j, w, kq, l15, acc[1]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[q][t] = -acc[q][t];
+      if (two2) lmlwg_gemm<2>(Km, ld, j, i0, w, kq, l15, acc);
+      else lmlwg_gemm<1>(Km, ld, j, i0, w, kq, l15, acc);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[q][t] = -acc[q][t];
+      lmlwg_solve_store(acc[0], Sp, linv, Rw, Tt, Km + (long)(64 * i0 + 16 * w) * ld + 64 * j, ld, lane);
+      if (two2) lmlwg_solve_store(acc[1], Sp, linv, Rw, Tt, Km + (long)(64 * (i0 + 1) + 16 * w) * ld + 64 * j, ld, lane);
+    }
+    // block column j is out: every wave drains its stores, then all of them may read it as an operand
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // sum(log L_ii) over the rows of K, z.z over row n (fixed order: deterministic)
+  double ldv = 0.0, dt = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    ldv += log(Km[(long)i * ld + i]);
+    const double z = Km[(long)n * ld + i];
+    dt = fma(z, z, dt);
+  }
+  for (int off = 32; off > 0; off >>= 1) { ldv += __shfl_down(ldv, off, 64); dt += __shfl_down(dt, off, 64); }
+  if (lane == 0) { s_red[w] = ldv; s_red[4 + w] = dt; }
+  __syncthreads();
+  if (tid == 0) {
+    a.out2[2 * c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    a.out2[2 * c + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Panel strips.  Once the 512 x 512 diagonal block of a panel is factored, the rows below it are
 //     L21 = A21 L11^-T ,
 // and a strip of 64 of those rows needs nothing from any other strip: workgroup s keeps its
@@ -2185,6 +2444,30 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
       DFH_TRY(gemm_f64(ctx, GEMM_TRANSB, m, w, w, 1.0, R2, NB, inv + b * NB * NB, NB, 1.0, Bt + c0, ldb, Bt + c0, ldb));
     }
   }
+  return DFH_OK;
+}
+
+// Launch of lml_wg_kernel: `count` candidates, one workgroup each (K: padded matrices of order 64 * ceil((n + 1) / 64),
+// see the kernel).  d_par: [count] augmented diagonal entries, then [count] prior means; d_out2: [count][2];
+// d_info: [count] failing pivots (zeroed here).  Asynchronous on ctx->stream.
+int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int count, const double* d_y,
+                 const double* d_par, double* d_out2, long long* d_info) {
+  DFH_ARG(ctx && K && d_y && d_par && d_out2 && d_info && n >= 1 && n <= LMLWG_MAX_N && count >= 1);
+  const int64_t nbt = (n + 1 + PB - 1) / PB;
+  DFH_ARG(ld >= nbt * PB && (ld & 1) == 0 && sK >= nbt * PB * ld && (reinterpret_cast<uintptr_t>(K) & 15) == 0);
+  static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
+  bool& attr_set = attr_set_dev[ctx->device];
+  if (!attr_set) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lml_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DIAG_STEP_SMEM));
+    attr_set = true;
+  }
+  DFH_HIP(hipMemsetAsync(d_info, 0, (size_t)count * 8, ctx->stream));
+  LmlWgArgs a;
+  a.K = K; a.sK = (long)sK; a.ld = (long)ld; a.n = (int)n; a.nbt = (int)nbt;
+  a.y = d_y; a.par = d_par; a.count = count; a.out2 = d_out2; a.info = d_info;
+  hipLaunchKernelGGL(lml_wg_kernel, dim3((unsigned)count), dim3(256), DIAG_STEP_SMEM, ctx->stream, a);
+  DFH_LAUNCH_CHECK();
   return DFH_OK;
 }
 

@@ -321,6 +321,13 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
                     const std::function<int()>* rebuild = nullptr);
 constexpr int DFH_INTERNAL_RETRY = 1000;   // chol.hip internal: never crosses the C-ABI
 
+// The tuning objective of `count` candidates, one workgroup per candidate (chol.hip: lml_wg_kernel): Cholesky of the
+// augmented matrix [[K, .], [(y - m)^T, c]] of each, sum(log L_ii) and |L^-1 (y - m)|^2 out.  K: matrices padded to
+// order 64 * ceil((n + 1) / 64) (only the n x n part has to be filled), sK doubles apart, row stride ld.
+constexpr int64_t LMLWG_MAX_N = 2047;
+int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int count, const double* d_y,
+                 const double* d_par, double* d_out2, long long* d_info);
+
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x
 // refine (host, one entry per diagonal block, or null): refinement steps per block, see above
