@@ -49,6 +49,7 @@ def build(force=False, verbose=True, debug_hooks=False):
   LIB_PATH = os.path.join(HERE, 'libdfhip_dbg.so' if debug_hooks else 'libdfhip.so')   # pylint: disable=invalid-name
   os.makedirs(OBJ_DIR, exist_ok=True)
   flags = CXXFLAGS + (['-DDFH_DEBUG_HOOKS'] if debug_hooks else []) + os.environ.get('DFH_EXTRA_CXXFLAGS', '').split()
+  headers = HEADERS + ([os.path.join(HERE, '..', 'include', 'dfhip_debug.h')] if debug_hooks else [])
   stamp = os.path.join(OBJ_DIR, 'flags.txt')
   if not os.path.exists(stamp) or open(stamp).read() != ' '.join(flags):
     force = True                   # different flags than the objects on disk were built with
@@ -58,7 +59,7 @@ def build(force=False, verbose=True, debug_hooks=False):
   for src in SOURCES:
     src_path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
-    if force or _stale(obj, [src_path] + HEADERS):
+    if force or _stale(obj, [src_path] + headers):
       jobs.append((src_path, obj))
 
   def _compile(job):

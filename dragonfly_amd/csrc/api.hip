@@ -1317,6 +1317,10 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
   std::vector<double> hred((size_t)G * 2), hpar((size_t)G * 3);
   std::vector<long long> hinfo((size_t)G);
   std::vector<char> skip((size_t)G, 0);
+  unsigned long long hstatus = 0;
+  unsigned long long* d_status = reinterpret_cast<unsigned long long*>(ctx->d_info + CHOL_MAX_BATCH + 8);
+  // DFH_LML_TEAM: 0 = never a team, N = teams of up to N workgroups (default: up to 8)
+  static const int team_env = []() { const char* e = getenv("DFH_LML_TEAM"); return e ? atoi(e) : -1; }();
   std::vector<int> redo;                       // candidates for the lock-step schedule
   for (int c0 = 0; c0 < nb; c0 += G) {
     const int g = std::min(G, nb - c0);
@@ -1352,28 +1356,47 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
       if (skip[c]) hpar[c] = 1.0;
     }
     DFH_HIP(hipMemcpyAsync(dpar, hpar.data(), (size_t)g * 24, hipMemcpyHostToDevice, ctx->stream));
-    {
-      SectionTimer t(ctx, DFH_T_KERNMAT);
-      if (uniform) {
-        const int64_t sBlob = (int64_t)kerndev_blob_bytes(kds[0]);
-        DFH_TRY(pack_scaled(ctx, kds[0], 0, 1, false, dX, n, d, Xpb, Npb, g, sBlob, sXp, sNp));
-        DFH_TRY(kernmat_sym_batch(ctx, kds[0], g, sBlob, Xpb, sXp, Npb, sNp, n, dpar + 2 * g, Kb, sK, NP));
-      } else {
-        for (int c = 0; c < g; ++c) {
-          double* Xp = Xpb + c * sXp; double* Np = Npb + c * sNp;
-          DFH_TRY(pack_scaled(ctx, kds[c], 0, kds[c].n_parts, false, dX, n, d, Xp, Np));
-          DFH_TRY(kernmat_packed(ctx, kds[c], 0, kds[c].n_parts, true, Xp, Np, n, Xp, Np, n, true, noise_vars[c0 + c],
-                                 Kb + c * sK, NP));
+    // a group that leaves most of the device idle gets a TEAM of workgroups per candidate (chol.hip: lml_team_kernel)
+    int team = 1;
+    if (team_env != 0) {
+      const int cap = team_env > 0 ? team_env : 8;
+      while (team * 2 <= cap && (int64_t)team * 2 * g <= ctx->n_cu && team * 2 <= nbt) team *= 2;
+    }
+    auto run_group = [&](int tm) -> int {
+      {
+        SectionTimer t(ctx, DFH_T_KERNMAT);
+        if (uniform) {
+          const int64_t sBlob = (int64_t)kerndev_blob_bytes(kds[0]);
+          DFH_TRY(pack_scaled(ctx, kds[0], 0, 1, false, dX, n, d, Xpb, Npb, g, sBlob, sXp, sNp));
+          DFH_TRY(kernmat_sym_batch(ctx, kds[0], g, sBlob, Xpb, sXp, Npb, sNp, n, dpar + 2 * g, Kb, sK, NP));
+        } else {
+          for (int c = 0; c < g; ++c) {
+            double* Xp = Xpb + c * sXp; double* Np = Npb + c * sNp;
+            DFH_TRY(pack_scaled(ctx, kds[c], 0, kds[c].n_parts, false, dX, n, d, Xp, Np));
+            DFH_TRY(kernmat_packed(ctx, kds[c], 0, kds[c].n_parts, true, Xp, Np, n, Xp, Np, n, true, noise_vars[c0 + c],
+                                   Kb + c * sK, NP));
+          }
         }
       }
+      {
+        SectionTimer t(ctx, DFH_T_CHOL);
+        DFH_TRY(lml_wg_batch(ctx, Kb, sK, NP, n, g, dy, dpar, red, dinfo, tm, d_status));
+      }
+      DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)g * 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (tm > 1) DFH_HIP(hipMemcpyAsync(&hstatus, d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipStreamSynchronize(ctx->stream));
+      return DFH_OK;
+    };
+    hstatus = 0;
+    DFH_TRY(run_group(team));
+    if (team > 1 && hstatus != 0) {
+      // a hand-off between the members of a team timed out (the device is shared, or not all of them were
+      // resident): the matrices are rebuilt and every candidate gets ONE workgroup, which waits for nobody
+      ++ctx->chol_fallbacks;
+      hstatus = 0;
+      DFH_TRY(run_group(1));
     }
-    {
-      SectionTimer t(ctx, DFH_T_CHOL);
-      DFH_TRY(lml_wg_batch(ctx, Kb, sK, NP, n, g, dy, dpar, red, dinfo));
-    }
-    DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
-    DFH_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)g * 8, hipMemcpyDeviceToHost, ctx->stream));
-    DFH_HIP(hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < g; ++c) {
       if (skip[c] || hinfo[c] != 0 || !std::isfinite(hred[2 * c]) || !std::isfinite(hred[2 * c + 1])) { redo.push_back(c0 + c); continue; }
       if (jitter_powers) jitter_powers[c0 + c] = INT32_MIN;

@@ -557,7 +557,23 @@ struct LmlWgArgs {
   int count;
   double* out2;                     // [count][2]: sum(log L_ii), z.z
   long long* info;                  // [count]: 1-based index of the first failing pivot (0: none)
+  // lml_team_kernel only
+  int T;                            // workgroups per candidate
+  int* sync;                        // [count][LMLT_SYNC_INTS], zeroed per launch: diag[j], then brow[j] (see the kernel)
+  double* linvbuf;                  // [count][nbt][LMLT_LINV]: inverses of the diagonal tiles' 16 x 16 blocks, handed on
+  unsigned long long* status;       // hand-off status word (SYNC_ST_*)
+  int spin_limit;
+#ifdef DFH_DEBUG_HOOKS
+  long long* stamps = nullptr;      // dfh_debug_lmlt_stamps: [workgroup][32 columns][16] s_memrealtime (100 MHz) at the LSTAMP points
+#endif
 };
+constexpr int LMLT_SYNC_INTS = 64, LMLT_LINV = 4 * 16 * 17;
+#ifdef DFH_DEBUG_HOOKS
+#define LSTAMP(a, j, e) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[((long)blockIdx.x * 32 + (j)) * 16 + (e)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+long long* g_lmlt_stamps = nullptr;
+#else
+#define LSTAMP(a, j, e) do {} while (0)
+#endif
 
 // this wave's 16 x 64 slice of tile (i, j), as MFMA accumulators: acc[t][r] = element (64 i + 16 w + kq + 4 r, 64 j + 16 t + l15)
 __device__ __forceinline__ void lmlwg_load_tile(const LmlWgArgs& a, const double* __restrict__ Km, double mean, double cdiag,
@@ -571,72 +587,115 @@ __device__ __forceinline__ void lmlwg_load_tile(const LmlWgArgs& a, const double
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = p[(long)(4 * r) * ld + 16 * t];
   } else {
+    // (unconditional loads from clamped addresses, then selects: a load under a condition is waited for on the
+    //  spot, and sixteen memory latencies in a row per tile were a tenth of the kernel's time)
+    double kv[4][4], yv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int gj = min(64 * j + 16 * t + l15, n - 1);
+      yv[t] = a.y[gj];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kv[t][r] = Km[(long)min(64 * i + 16 * w + kq + 4 * r, n - 1) * ld + gj];
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = 64 * i + 16 * w + kq + 4 * r, gj = 64 * j + 16 * t + l15;
-        double v;
-        if (gi < n) v = (gj < n) ? Km[(long)gi * ld + gj] : 0.0;
-        else if (gi == n) v = (gj < n) ? a.y[gj] - mean : (gj == n ? cdiag : 0.0);
-        else v = (gi == gj) ? 1.0 : 0.0;
-        acc[t][r] = v;
+        const double on_row_n = (gj < n) ? yv[t] - mean : (gj == n ? cdiag : 0.0);
+        const double in_k = (gj < n) ? kv[t][r] : 0.0;
+        acc[t][r] = (gi < n) ? in_k : (gi == n ? on_row_n : (gi == gj ? 1.0 : 0.0));
       }
   }
 }
 
-// acc[q] += L[tile row i0 + q][0 : 64 j] L[tile row j][0 : 64 j]^T for q < RG, this wave's 16 rows.  Sixteen
-// columns per step: lane (kq, l15) holds columns 2 kq, 2 kq + 1 and 8 + 2 kq, 9 + 2 kq of its row (two 16-byte
-// loads, 64 contiguous bytes per row and instruction) and the four MFMAs of a step contract over the
-// columns {c, 2 + c, 4 + c, 6 + c} + {0, 8}: any assignment of columns to k-slots is a valid product as long
-// as both operands use the same one.  The next step's loads are in flight while this one multiplies.
+// acc[q] += L[tile row i0 + q * istep][K] L[tile row brow][K]^T for q < RG, this wave's 16 rows of each tile, K = the
+// tile columns [kt0, kt1) (default: all j of them; brow default j).  Sixteen columns per step.
+//   A operand (this wave's own rows): straight from L2 / HBM into MFMA fragments -- lane (kq, l15) holds columns
+//     2 kq, 2 kq + 1 and 8 + 2 kq, 9 + 2 kq of its row (two 16-byte loads, 64 contiguous bytes per row and
+//     instruction) and the four MFMAs of a step contract over the columns {c, 2 + c, 4 + c, 6 + c} + {0, 8}: any
+//     assignment of columns to k-slots is a valid product as long as both operands use the same one.
+//   B operand (the 64 rows of tile row brow, the same for all four waves): through a double-buffered LDS image
+//     Bs[2][64][LG_BKP], 32 bytes per thread and step, one barrier per step.  (Round 5's first version had every
+//     wave load all of B itself: ten loads per sixteen MFMAs at one tile row per wave, and the products ran at a
+//     third of the matrix pipe's rate -- tools/dbg_lmlt.py.)
+// Loads are issued NS steps ahead and unconditionally (a load under a condition makes the compiler drain the whole
+// queue -- s_waitcnt vmcnt(0) -- before every step; the last steps therefore re-load the final step's operands).
+// Called by all four waves together (barriers inside); ends behind a barrier: Bs is free again.
+constexpr int LG_BKP = 18;                             // row stride of the B image (doubles): 16-byte aligned rows
 template <int RG>
 __device__ __forceinline__ void lmlwg_gemm(const double* __restrict__ Km, long ld, int j, int i0, int w, int kq, int l15,
-                                           double4_t (&acc)[2][4]) {
-  const int nch = 4 * j;                               // (even)
-  if (nch == 0) return;
+                                           double4_t (&acc)[2][4], double* Bs, int istep = 1, int brow = -1, int kt0 = 0,
+                                           int kt1 = -1) {
+  if (kt1 < 0) kt1 = j;
+  const int nch = 4 * (kt1 - kt0);                     // (a multiple of NS)
+  if (nch <= 0) return;
+  if (brow < 0) brow = j;
+  const int tid = threadIdx.x;
   const double* pa[RG];
 #pragma unroll
-  for (int q = 0; q < RG; ++q) pa[q] = Km + (long)(64 * (i0 + q) + 16 * w + l15) * ld + 2 * kq;
-  const double* pb = Km + (long)(64 * j + l15) * ld + 2 * kq;
-  double2_t a0[RG][2], b0[4][2], a1[RG][2], b1[4][2];
-  auto load = [&](int c, double2_t (&fa)[RG][2], double2_t (&fb)[4][2]) {
-    const int k0 = 16 * c;
+  for (int q = 0; q < RG; ++q) pa[q] = Km + (long)(64 * (i0 + q * istep) + 16 * w + l15) * ld + 64 * kt0 + 2 * kq;
+  const double* pbg = Km + (long)(64 * brow + (tid >> 2)) * ld + 64 * kt0 + 4 * (tid & 3);   // staging: row tid / 4, four columns
+  double* bst = Bs + (tid >> 2) * LG_BKP + 4 * (tid & 3);
+  const double* bfr = Bs + l15 * LG_BKP + 2 * kq;      // fragments: row 16 t + l15, columns 2 kq (+ 8)
+  constexpr int NS = 4;
+  double2_t fa[NS][RG][2], gb[NS][2];
+  auto load_a = [&](int c, double2_t (&xa)[RG][2]) {
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
-      fa[q][0] = *reinterpret_cast<const double2_t*>(pa[q] + k0);
-      fa[q][1] = *reinterpret_cast<const double2_t*>(pa[q] + k0 + 8);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      fb[t][0] = *reinterpret_cast<const double2_t*>(pb + (long)(16 * t) * ld + k0);
-      fb[t][1] = *reinterpret_cast<const double2_t*>(pb + (long)(16 * t) * ld + k0 + 8);
+      xa[q][0] = *reinterpret_cast<const double2_t*>(pa[q] + 16 * c);
+      xa[q][1] = *reinterpret_cast<const double2_t*>(pa[q] + 16 * c + 8);
     }
   };
-  auto mma = [&](const double2_t (&fa)[RG][2], const double2_t (&fb)[4][2]) {
+  auto load_b = [&](int c, double2_t (&xb)[2]) {
+    xb[0] = *reinterpret_cast<const double2_t*>(pbg + 16 * c);
+    xb[1] = *reinterpret_cast<const double2_t*>(pbg + 16 * c + 2);
+  };
+  auto stage_b = [&](const double2_t (&xb)[2], int buf) {
+    *reinterpret_cast<double2_t*>(bst + buf * (64 * LG_BKP)) = xb[0];
+    *reinterpret_cast<double2_t*>(bst + buf * (64 * LG_BKP) + 2) = xb[1];
+  };
+  auto mma = [&](const double2_t (&xa)[RG][2], int buf) {
+    double2_t xb[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      xb[t][0] = *reinterpret_cast<const double2_t*>(bfr + buf * (64 * LG_BKP) + 16 * t * LG_BKP);
+      xb[t][1] = *reinterpret_cast<const double2_t*>(bfr + buf * (64 * LG_BKP) + 16 * t * LG_BKP + 8);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int q = 0; q < RG; ++q)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const double av = (s & 1) ? fa[q][s >> 1].y : fa[q][s >> 1].x;
-          const double bv = (s & 1) ? fb[t][s >> 1].y : fb[t][s >> 1].x;
+          const double av = (s & 1) ? xa[q][s >> 1].y : xa[q][s >> 1].x;
+          const double bv = (s & 1) ? xb[t][s >> 1].y : xb[t][s >> 1].x;
           acc[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q][t], 0, 0, 0);
         }
   };
-  load(0, a0, b0);
-  for (int c = 0; c < nch; c += 2) {
-    load(c + 1, a1, b1);
-    mma(a0, b0);
-    if (c + 2 < nch) load(c + 2, a0, b0);
-    mma(a1, b1);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) { load_a(min(u, nch - 1), fa[u]); load_b(min(u, nch - 1), gb[u]); }
+  stage_b(gb[0], 0);
+  load_b(min(NS, nch - 1), gb[0]);
+  __syncthreads();
+  for (int c = 0; c < nch; c += NS) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      // step c + u: its B image is in buffer u & 1 (NS is even), its A fragments in fa[u]
+      stage_b(gb[(u + 1) % NS], (u + 1) & 1);          // the next step's image (read last in the step before this one)
+      load_b(min(c + u + 1 + NS, nch - 1), gb[(u + 1) % NS]);
+      mma(fa[u], u & 1);
+      load_a(min(c + u + NS, nch - 1), fa[u]);
+      __syncthreads();
+    }
   }
 }
 
 // X = T L_jj^-T for this wave's 16 x 64 slice T (in acc), by the 16-column substitution of diag_step64_kernel
 // (factor image Sp with perm16 columns, the inverses linv of its 16 x 16 diagonal blocks); X goes to the wave's
 // rows Rw of the LDS row buffer and from there to G (row stride ld), a 512-byte row segment per store.
+// SC1: the rows go out with write-through stores (another workgroup reads them: lml_team_kernel).
+template <bool SC1 = false>
 __device__ __forceinline__ void lmlwg_solve_store(const double4_t (&acc)[4], const double* Sp, const double* linv,
                                                   double* Rw, double* Tt, double* __restrict__ G, long ld, int lane) {
   const int kq = lane >> 4, l15 = lane & 15;
@@ -669,7 +728,10 @@ __device__ __forceinline__ void lmlwg_solve_store(const double4_t (&acc)[4], con
     COMPILER_BARRIER();
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) G[(long)i * ld + lane] = Rw[i * PBP + lane];
+  for (int i = 0; i < 16; ++i) {
+    if (SC1) __hip_atomic_store(G + (long)i * ld + lane, Rw[i * PBP + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else G[(long)i * ld + lane] = Rw[i * PBP + lane];
+  }
   COMPILER_BARRIER();                                // (the next tile's substitution overwrites Rw)
 }
 
@@ -707,8 +769,8 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[q][t] = -acc[q][t];       // the products ADD: -T = -A + sum L L^T
-    if (two) lmlwg_gemm<2>(Km, ld, j, j, w, kq, l15, acc);
-    else lmlwg_gemm<1>(Km, ld, j, j, w, kq, l15, acc);
+    if (two) lmlwg_gemm<2>(Km, ld, j, j, w, kq, l15, acc, ring);
+    else lmlwg_gemm<1>(Km, ld, j, j, w, kq, l15, acc, ring);
     // the diagonal tile -> staged block (lower triangle, zero above)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -757,8 +819,8 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[q][t] = -acc[q][t];
-      if (two2) lmlwg_gemm<2>(Km, ld, j, i0, w, kq, l15, acc);
-      else lmlwg_gemm<1>(Km, ld, j, i0, w, kq, l15, acc);
+      if (two2) lmlwg_gemm<2>(Km, ld, j, i0, w, kq, l15, acc, ring);
+      else lmlwg_gemm<1>(Km, ld, j, i0, w, kq, l15, acc, ring);
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -771,6 +833,279 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
     __syncthreads();
   }
   // sum(log L_ii) over the rows of K, z.z over row n (fixed order: deterministic)
+  double ldv = 0.0, dt = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    ldv += log(Km[(long)i * ld + i]);
+    const double z = Km[(long)n * ld + i];
+    dt = fma(z, z, dt);
+  }
+  for (int off = 32; off > 0; off >>= 1) { ldv += __shfl_down(ldv, off, 64); dt += __shfl_down(dt, off, 64); }
+  if (lane == 0) { s_red[w] = ldv; s_red[4 + w] = dt; }
+  __syncthreads();
+  if (tid == 0) {
+    a.out2[2 * c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    a.out2[2 * c + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+  }
+}
+
+// The same objective with a TEAM of T workgroups per candidate (few candidates: one workgroup each would leave
+// most of the device idle and take 3 ms at n = 1000).  Tile row i belongs to member i mod T; in block column j
+//   every member with rows >= j:  waits for brow[j] (tile row j -- the B operand -- is complete up to column
+//                                 j - 1), accumulates its tiles of the column two at a time;
+//   the owner of row j:           takes the diagonal tile first, factors it, hands L_jj (in its place) and the
+//                                 inverses of its 16 x 16 blocks on under diag[j];
+//   the others:                   wait for diag[j] after their first products, fetch that image, substitute;
+//   the owner of row j + 1:       announces brow[j + 1] as soon as its tile (j + 1, j) is out.
+// Hand-offs as in the one-launch panel: write-through (sc1) stores of whatever another member reads, every
+// wave drains its stores, barrier, relaxed flag; the reader polls, takes ONE agent-scope acquire (its CU's L1)
+// and reads with plain loads -- no line is ever read by a member before its final contents are written, so no
+// stale copy can sit in another XCD's L2.  Every wait is bounded (status word -> the host repeats the group with
+// one workgroup per candidate).  A failed pivot is handed on as diag[j] = 2: every member that still has rows
+// waits for exactly that flag and leaves.  Nothing here assumes where a workgroup runs; co-residency of the
+// T * count <= CUs workgroups is what makes it fast, the bounded waits are what makes it safe.
+__device__ __forceinline__ int lmlt_wait(const int* p, const LmlWgArgs& a, int* s_val, int target = 1) {
+  if (threadIdx.x == 0) {
+    int spins = 0, v;
+    while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+      if (++spins > a.spin_limit) { atomicOr(a.status, (unsigned long long)SYNC_ST_FUSED); v = -1; break; }
+      if ((spins & 63) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { v = -1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    *s_val = v;
+  }
+  __syncthreads();
+  const int v = *s_val;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 holds nothing older than the flag
+  __syncthreads();                                     // (s_val may be rewritten by the next wait)
+  return v;
+}
+__device__ __forceinline__ void lmlt_publish(int* p, int v) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its write-through stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS images of the one-workgroup objective (dynamic LDS, the layout of diag_step64_kernel, two words behind it)
+struct LmltLds { double *Sp, *R, *ring, *tbuf0, *lbb, *linv, *rdiag; int *badv, *ring_timeout; };
+constexpr int LMLT_SMEM = DIAG_STEP_SMEM + 64;
+__device__ __forceinline__ LmltLds lmlt_lds() {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  LmltLds L;
+  L.Sp = dsm;                                        // [64][SPP] staged diagonal tile, then the factor image (perm16 columns)
+  L.R = dsm + PB * SPP_STAGE;                        // [64][65] solved rows, 16 per wave
+  double* colbuf = L.R + PB * PBP;                   // [64] reciprocal diagonal
+  L.ring = colbuf + PB;                              // [64][64] published columns of factor64_waves
+  L.tbuf0 = L.ring + PB * PB;                        // 3 x [64][17] layout buffers, then 4 x [16][17] substitution tiles
+  L.lbb = L.tbuf0 + 3 * PB * 17;                     // 4 x [16][17]
+  L.linv = L.lbb + 4 * 16 * 17;                      // 4 x [16][17] inverses of the factor's 16 x 16 diagonal blocks
+  L.rdiag = colbuf;
+  L.badv = reinterpret_cast<int*>(dsm + DIAG_STEP_SMEM / 8);
+  L.ring_timeout = L.badv + 4;
+  return L;
+}
+
+// Stage a diagonal tile (this wave's 16 x 64 slice in d0 .. d3), factor it (factor64_waves) and leave the factor image
+// (perm16 columns) in Sp and the inverses of its 16 x 16 blocks in linv.  Returns -1, or the first bad column (64: an
+// LDS ring flag never came up).
+// NOT inlined: inside the team kernel's loop nest the register allocator spilled two dwords of every pivot step of
+// factor64_waves to scratch -- a memory round trip per column on the one chain that is pure latency: 53 us per tile
+// instead of ~10 (tools/dbg_lmlt.py).  As a function of its own the step has the register file to itself; its LDS
+// pointers are formed here, from the dynamic LDS base, so that they stay LDS pointers (passed as arguments they
+// would be generic ones: flat_load instead of ds_read).
+__device__ __attribute__((noinline)) int lmlt_factor_tile(double4_t d0, double4_t d1, double4_t d2, double4_t d3) {
+  const LmltLds L = lmlt_lds();
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * w + kq + 4 * r;
+    L.Sp[row * SPP_STAGE + l15] = (l15 <= row) ? d0[r] : 0.0;
+    L.Sp[row * SPP_STAGE + 16 + l15] = (16 + l15 <= row) ? d1[r] : 0.0;
+    L.Sp[row * SPP_STAGE + 32 + l15] = (32 + l15 <= row) ? d2[r] : 0.0;
+    L.Sp[row * SPP_STAGE + 48 + l15] = (48 + l15 <= row) ? d3[r] : 0.0;
+  }
+  if (tid < PB) L.ring[tid * PB] = 0.0;                // row-0 entries double as the "published" flags
+  if (tid == 0) *L.ring_timeout = 0;
+  __syncthreads();
+  {
+    double av[16];
+    double* tbuf = L.tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
+    const int bad = factor64_waves<false>(av, lane, w, L.Sp, tbuf, L.ring, L.lbb, L.linv, L.rdiag, L.ring_timeout);
+    if (lane == 0) L.badv[w] = bad;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) L.Sp[lane * SPP_STAGE + perm16(16 * w + q)] = av[q];
+  }
+  __syncthreads();
+  const int s_bad = (L.badv[0] >= 0) ? L.badv[0] : (L.badv[1] >= 0) ? L.badv[1] : (L.badv[2] >= 0) ? L.badv[2] : L.badv[3];
+  return *L.ring_timeout ? 64 : s_bad;
+}
+
+// ... and hand it on: factor image and inverses to global memory with write-through stores, *flag = 1 -- or 2 after a
+// failed pivot (then info is set and the caller leaves).  Returns false on failure.
+__device__ __forceinline__ bool lmlt_factor_publish(const LmlWgArgs& a, const LmltLds& L, const double4_t (&dacc)[4],
+                                                    double* __restrict__ Km, long ld, int jj, int c, double* linvg,
+                                                    int* flag) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  LSTAMP(a, jj, 10);
+  const int s_bad = lmlt_factor_tile(dacc[0], dacc[1], dacc[2], dacc[3]);
+  LSTAMP(a, jj, 13);
+  if (s_bad >= 0) {
+    if (tid == 0) a.info[c] = 64ll * jj + (s_bad & 63) + 1;
+    lmlt_publish(flag, 2);                             // nobody may hang: the waiters leave on 2
+    return false;
+  }
+  const int pk = perm16(lane);
+  double* Ljj = Km + (long)(64 * jj) * ld + 64 * jj;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __hip_atomic_store(Ljj + (long)(w + 4 * r) * ld + lane, L.Sp[(w + 4 * r) * SPP_STAGE + pk], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = tid; i < LMLT_LINV; i += 256)
+    __hip_atomic_store(linvg + (long)jj * LMLT_LINV + i, L.linv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  LSTAMP(a, jj, 14);
+  lmlt_publish(flag, 1);
+  LSTAMP(a, jj, 15);
+  return true;
+}
+
+// factor image of block column jj (announced and waited for before) from global memory into Sp / linv
+__device__ __forceinline__ void lmlt_fetch_image(const LmltLds& L, const double* __restrict__ Km, long ld, int jj,
+                                                 const double* linvg) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const double* Ljj = Km + (long)(64 * jj) * ld + 64 * jj;
+  const int pk = perm16(lane);
+  double pre[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pre[r] = Ljj[(long)(w + 4 * r) * ld + lane];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) L.Sp[(w + 4 * r) * SPP_STAGE + pk] = pre[r];
+  for (int i = tid; i < LMLT_LINV; i += 256) L.linv[i] = linvg[(long)jj * LMLT_LINV + i];
+  __syncthreads();
+}
+
+// Look-ahead (the member that owns tile row j + 1, while block column j is being finished): the NEXT diagonal tile
+// is accumulated over the columns before j while the member waits for L_jj anyway, takes the product with the
+// just-solved tile (j + 1, j) straight from the LDS row buffer, and is factored and announced before the member
+// turns to the rest of its rows of column j -- so that a block column's critical path is
+//     L_jj announced -> fetch -> substitution of ONE tile -> K = 64 product -> 64 x 64 factorisation -> announce
+// whatever j (the left-looking products over 64 j columns had been on it: 1.7 j us per column).
+__global__ __launch_bounds__(256, 1) void lml_team_kernel(LmlWgArgs a) {
+  const LmltLds L = lmlt_lds();
+  __shared__ int s_wait;
+  __shared__ double s_red[8];
+  const int T = a.T;
+  const int c = blockIdx.x / T, t = blockIdx.x - c * T;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, l15 = lane & 15;
+  double* __restrict__ Km = a.K + (long)c * a.sK;
+  const long ld = a.ld;
+  const int n = a.n, nbt = a.nbt;
+  const double cdiag = a.par[c], mean = a.par[a.count + c];
+  int* dflag = a.sync + (long)c * LMLT_SYNC_INTS;
+  int* bflag = dflag + 32;
+  double* linvg = a.linvbuf + (long)c * nbt * LMLT_LINV;
+  double* Rw = L.R + 16 * w * PBP;
+  double* Tt = L.tbuf0 + w * (16 * 17);
+  int lds_image = -1;                                  // block column whose factor image Sp / linv hold
+  int factored = -1;                                   // last diagonal tile this member has factored and announced
+  double4_t dacc[2][4];                                // [0]: the look-ahead diagonal tile ([1] unused: lmlwg_gemm's signature)
+  for (int j = 0; j < nbt; ++j) {
+    const int own_j = j % T;
+    const bool owner = own_j == t;
+    const bool next_owner = (j + 1 < nbt) && ((j + 1) % T == t);
+    const int i_first = j + ((t - own_j + T) % T);     // this member's first tile row >= j
+    if (i_first >= nbt) break;                         // no rows left in this or any later column
+    LSTAMP(a, j, 0);
+    if (next_owner) {
+      // look-ahead, part 1: the next diagonal tile over the columns before j (tile row j + 1 on both sides: this member's
+      // own tiles) -- BEFORE the wait for tile row j, whose owner is busy with this column's diagonal tile right now
+      lmlwg_load_tile(a, Km, mean, cdiag, j + 1, j + 1, w, kq, l15, dacc[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dacc[0][q] = -dacc[0][q];
+      lmlwg_gemm<1>(Km, ld, j, j + 1, w, kq, l15, dacc, L.ring, T, j + 1);
+      LSTAMP(a, j, 3);
+    }
+    if (j > 0 && !owner) {
+      // tile row j (the B operand of this column) was completed by its owner in column j - 1
+      if (lmlt_wait(bflag + j, a, &s_wait) != 1) return;
+    }
+    LSTAMP(a, j, 1);
+    if (owner && factored < j) {
+      // (j = 0, or a team of one: no look-ahead has prepared this tile)
+      lmlwg_load_tile(a, Km, mean, cdiag, j, j, w, kq, l15, dacc[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dacc[0][q] = -dacc[0][q];
+      lmlwg_gemm<1>(Km, ld, j, j, w, kq, l15, dacc, L.ring, T);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dacc[0][q] = -dacc[0][q];
+      __syncthreads();
+      if (!lmlt_factor_publish(a, L, dacc[0], Km, ld, j, c, linvg, dflag + j)) return;
+      factored = j; lds_image = j;
+    }
+    bool waited = owner;                               // diag[j] seen (the owner wrote it)
+    for (int i0 = owner ? j + T : i_first, inext; i0 < nbt; i0 = inext) {
+      const int i1 = i0 + T;
+      const bool two = i1 < nbt;
+      inext = i1 + T;
+      const bool la = next_owner && i0 == j + 1;       // this group starts with tile (j + 1, j)
+      double4_t acc[2][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[1][q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      lmlwg_load_tile(a, Km, mean, cdiag, i0, j, w, kq, l15, acc[0]);
+      if (two) lmlwg_load_tile(a, Km, mean, cdiag, i1, j, w, kq, l15, acc[1]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) acc[q][q2] = -acc[q][q2];
+      if (two) lmlwg_gemm<2>(Km, ld, j, i0, w, kq, l15, acc, L.ring, T);
+      else lmlwg_gemm<1>(Km, ld, j, i0, w, kq, l15, acc, L.ring, T);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) acc[q][q2] = -acc[q][q2];
+      if (i0 == (owner ? j + T : i_first)) LSTAMP(a, j, 2);
+      if (!waited) {
+        const int v = lmlt_wait(dflag + j, a, &s_wait);
+        if (v != 1) return;                            // 2: not positive definite (reported by the owner); -1: gave up
+        waited = true;
+        LSTAMP(a, j, 4);
+      }
+      if (lds_image != j) { lmlt_fetch_image(L, Km, ld, j, linvg); lds_image = j; }
+      if (i0 == (owner ? j + T : i_first)) LSTAMP(a, j, 5);
+      lmlwg_solve_store<true>(acc[0], L.Sp, L.linv, Rw, Tt, Km + (long)(64 * i0 + 16 * w) * ld + 64 * j, ld, lane);
+      if (i0 == (owner ? j + T : i_first)) LSTAMP(a, j, 6);
+      if (la) {
+        // -dacc += X X^T, X = tile (j + 1, j): this wave's rows and all 64 rows from the LDS row buffer
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const double av = Rw[l15 * PBP + 4 * ks + kq];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            dacc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, L.R[(16 * q + l15) * PBP + 4 * ks + kq], dacc[0][q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dacc[0][q] = -dacc[0][q];
+        // tile row j + 1 is complete up to column j: the next column's B operand (the barrier inside also frees the row buffer)
+        lmlt_publish(bflag + j + 1, 1);
+        LSTAMP(a, j, 7);
+      }
+      if (two) lmlwg_solve_store<true>(acc[1], L.Sp, L.linv, Rw, Tt, Km + (long)(64 * i1 + 16 * w) * ld + 64 * j, ld, lane);
+      if (la) {
+        // the next diagonal tile now, ahead of this member's other rows of column j
+        __syncthreads();                               // every wave is done with the image of column j
+        if (!lmlt_factor_publish(a, L, dacc[0], Km, ld, j + 1, c, linvg, dflag + j + 1)) return;
+        factored = j + 1; lds_image = j + 1;
+        LSTAMP(a, j, 8);
+      }
+    }
+    // this member's tiles of column j are out: its own waves may read them as operands
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    LSTAMP(a, j, 9);
+  }
+  // the owner of the last tile row holds row n (z) and has waited for every diagonal tile
+  if (t != (nbt - 1) % T) return;
   double ldv = 0.0, dt = 0.0;
   for (int i = tid; i < n; i += 256) {
     ldv += log(Km[(long)i * ld + i]);
@@ -2450,9 +2785,13 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
 // Launch of lml_wg_kernel: `count` candidates, one workgroup each (K: padded matrices of order 64 * ceil((n + 1) / 64),
 // see the kernel).  d_par: [count] augmented diagonal entries, then [count] prior means; d_out2: [count][2];
 // d_info: [count] failing pivots (zeroed here).  Asynchronous on ctx->stream.
+// team > 1: `team` workgroups per candidate (lml_team_kernel; team * count should not exceed the CUs).  d_status
+// (device, 8 bytes, or null when team == 1) is zeroed here and non-zero afterwards iff a hand-off wait expired:
+// the results of the launch are then void.
 int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int count, const double* d_y,
-                 const double* d_par, double* d_out2, long long* d_info) {
-  DFH_ARG(ctx && K && d_y && d_par && d_out2 && d_info && n >= 1 && n <= LMLWG_MAX_N && count >= 1);
+                 const double* d_par, double* d_out2, long long* d_info, int team, unsigned long long* d_status) {
+  DFH_ARG(ctx && K && d_y && d_par && d_out2 && d_info && n >= 1 && n <= LMLWG_MAX_N && count >= 1 && team >= 1 &&
+          team <= 32 && (team == 1 || d_status));
   const int64_t nbt = (n + 1 + PB - 1) / PB;
   DFH_ARG(ld >= nbt * PB && (ld & 1) == 0 && sK >= nbt * PB * ld && (reinterpret_cast<uintptr_t>(K) & 15) == 0);
   static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
@@ -2460,17 +2799,40 @@ int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int
   if (!attr_set) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lml_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 DIAG_STEP_SMEM));
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lml_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LMLT_SMEM));
     attr_set = true;
   }
   DFH_HIP(hipMemsetAsync(d_info, 0, (size_t)count * 8, ctx->stream));
   LmlWgArgs a;
   a.K = K; a.sK = (long)sK; a.ld = (long)ld; a.n = (int)n; a.nbt = (int)nbt;
   a.y = d_y; a.par = d_par; a.count = count; a.out2 = d_out2; a.info = d_info;
-  hipLaunchKernelGGL(lml_wg_kernel, dim3((unsigned)count), dim3(256), DIAG_STEP_SMEM, ctx->stream, a);
+  a.T = team; a.sync = nullptr; a.linvbuf = nullptr; a.status = d_status; a.spin_limit = 0;
+  if (team == 1) {
+    hipLaunchKernelGGL(lml_wg_kernel, dim3((unsigned)count), dim3(256), DIAG_STEP_SMEM, ctx->stream, a);
+    DFH_LAUNCH_CHECK();
+    return DFH_OK;
+  }
+  DFH_TRY(scratch_get(ctx, SCR_CHOLSYNC, (size_t)count * LMLT_SYNC_INTS * sizeof(int), (void**)&a.sync));
+  DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)count * nbt * LMLT_LINV * 8, (void**)&a.linvbuf));
+  DFH_HIP(hipMemsetAsync(a.sync, 0, (size_t)count * LMLT_SYNC_INTS * sizeof(int), ctx->stream));
+  DFH_HIP(hipMemsetAsync(d_status, 0, 8, ctx->stream));
+  // a legitimate wait lasts well under a millisecond; a poll is ~1 us: give up after ~0.1 s (DFH_TEST_SPIN_LIMIT=0: at once, the fallback's test)
+  static const int spin_limit = env_int("DFH_TEST_SPIN_LIMIT", 1 << 17);
+  a.spin_limit = spin_limit;
+#ifdef DFH_DEBUG_HOOKS
+  a.stamps = g_lmlt_stamps;
+#endif
+  hipLaunchKernelGGL(lml_team_kernel, dim3((unsigned)(count * team)), dim3(256), LMLT_SMEM, ctx->stream, a);
   DFH_LAUNCH_CHECK();
   return DFH_OK;
 }
 
+#ifdef DFH_DEBUG_HOOKS
+// Diagnostics: the team kernel's next launches stamp their progress into `dev_buf` (device, [workgroups][32][16] int64,
+// zeroed by the caller); null switches it off.  tools/dbg_lmlt.py decodes the stamps.
+extern "C" int dfh_debug_lmlt_stamps(void* dev_buf) { g_lmlt_stamps = reinterpret_cast<long long*>(dev_buf); return DFH_OK; }
+#endif
 #ifdef DFH_DEBUG_HOOKS      // diagnostics: built only with `python -m dragonfly_amd.build --debug-hooks` (include/dfhip_debug.h)
 // Diagnostics hook (not part of the product path): times `reps` back-to-back launches of the
 // 64-wide diagonal step on a synthetic SPD block and returns in-kernel cycle stamps.

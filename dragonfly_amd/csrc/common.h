@@ -325,8 +325,11 @@ constexpr int DFH_INTERNAL_RETRY = 1000;   // chol.hip internal: never crosses t
 // augmented matrix [[K, .], [(y - m)^T, c]] of each, sum(log L_ii) and |L^-1 (y - m)|^2 out.  K: matrices padded to
 // order 64 * ceil((n + 1) / 64) (only the n x n part has to be filled), sK doubles apart, row stride ld.
 constexpr int64_t LMLWG_MAX_N = 2047;
+// team > 1: that many workgroups per candidate (for groups far smaller than the device); *d_status != 0 afterwards
+// means a hand-off between them timed out and the launch's results are void (repeat with team = 1).
 int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int count, const double* d_y,
-                 const double* d_par, double* d_out2, long long* d_info);
+                 const double* d_par, double* d_out2, long long* d_info, int team = 1,
+                 unsigned long long* d_status = nullptr);
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x

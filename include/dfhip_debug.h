@@ -26,6 +26,10 @@ int dfh_debug_panel_stamps(dfh_ctx* ctx, int reps, int rows_below, double* ms_ou
 /* input block and published 64 x 64 factor blocks of the last dfh_debug_panel_stamps call (either may be NULL);
  * returns the number of doubles of the input block.                                                        */
 int dfh_debug_panel_data(double* A_out, double* Lfac_out);
+/* The team form of the one-workgroup tuning objective (lml_team_kernel) stamps its progress into dev_buf
+ * ([workgroups][32 block columns][16] int64 of s_memrealtime, zeroed by the caller) from the next launch on;
+ * NULL switches the stamps off (tools/dbg_lmlt.py).                                                        */
+int dfh_debug_lmlt_stamps(void* dev_buf);
 #ifdef __cplusplus
 }
 #endif

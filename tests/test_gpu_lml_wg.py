@@ -3,10 +3,17 @@ GPFitter._tuning_objective, dragonfly/gp/gp_core.py:551-574 -> build_posterior :
 the 64-row tile edges (the augmented row n falls into a tile of its own when n is a multiple of 64), more
 candidates than one launch holds, candidates that need the stable_cholesky ladder inside a large group, kernels
 that are not structurally uniform, and the no-jitter failure."""
+import os
+import re
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 from oracle import ref_numpy as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -122,3 +129,29 @@ def test_failures_surface_like_the_single_fit(engine):
     engine.gp_lml_batch(specs[:1], Xnan, Y, None, noises[:1])
   lml = engine.gp_lml_batch(specs, X, Y, None, [1e-3, 1e-3, 1e-2])      # (the context is fine afterwards)
   assert np.all(np.isfinite(lml))
+
+
+# the schedule switches are read once per process: each variant runs tests/lml_wg_check.py in a subprocess
+VARIANTS = {
+  'defaults': ({}, 0),
+  'one-workgroup-per-candidate-only': ({'DFH_LML_TEAM': '0'}, 0),
+  'teams-of-two': ({'DFH_LML_TEAM': '2'}, 0),
+  'teams-of-four': ({'DFH_LML_TEAM': '4'}, 0),
+  'teams-of-sixteen': ({'DFH_LML_TEAM': '16'}, 0),
+  'small-groups': ({'DFH_LML_WG_GROUP': '7'}, 0),
+  # every hand-off between the members of a team expires at once: the status word sends the group back through
+  # one workgroup per candidate (counted in dfh_ctx_counters)
+  'forced-handoff-timeout': ({'DFH_TEST_SPIN_LIMIT': '0'}, 1),
+  'lock-step-schedule': ({'DFH_LML_WG': '0'}, 0),
+}
+
+
+@pytest.mark.parametrize('name', sorted(VARIANTS))
+def test_schedule_variant(engine, name):
+  env = dict(os.environ)
+  env.update(VARIANTS[name][0])
+  res = subprocess.run([sys.executable, os.path.join(HERE, 'lml_wg_check.py')], env=env, capture_output=True, text=True,
+                       timeout=600)
+  assert res.returncode == 0 and res.stdout.strip().endswith('OK'), (res.stdout[-2000:], res.stderr[-4000:])
+  fallbacks = int(re.search(r'fallbacks (\d+)', res.stdout).group(1))
+  assert (fallbacks > 0) == bool(VARIANTS[name][1]), res.stdout

@@ -46,7 +46,7 @@ print('ladder case: got', list(got), 'ref', ref, 'powers', powers)
 Xd.free()
 if len(sys.argv) > 1 and sys.argv[1] == 'quick':
   sys.exit(0)
-for (n, d, nbs) in ((200, 6, (64, 256, 1024, 4096)), (500, 6, (64, 256, 1024)), (1000, 6, (64, 256, 512, 2048)), (2000, 6, (64, 256, 512))):
+for (n, d, nbs) in ((200, 6, (8, 64, 256, 1024, 4096)), (500, 6, (8, 32, 64, 256, 1024)), (1000, 6, (4, 8, 16, 32, 64, 128, 256, 512, 2048)), (2000, 6, (8, 32, 64, 256, 512))):
   rs = np.random.RandomState(n)
   X = rs.rand(n, d); Y = np.sin(4 * X.sum(axis=1)) + 0.1 * rs.randn(n)
   Xd = eng.to_device(X)
