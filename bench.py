@@ -58,7 +58,7 @@ def fp64_pipe_frac(kind, packed_width, elements, parts_per_element, ms):
   return {'bound': 'fp64 pipe (valu_f64 epilogue + MFMA share it)', 'min_ms_mfma': round(t_mfma * 1e3, 4),
           'min_ms_valu': round(t_valu * 1e3, 4), 'frac_of_fp64_pipe_peak': round((t_mfma + t_valu) / (ms * 1e-3), 4),
           'frac_of_valu_peak': round(t_valu / (ms * 1e-3), 4)}
-PMC_TRAFFIC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+PMC_TRAFFIC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def rel(a, b):
@@ -125,6 +125,9 @@ class InProcess(object):
   def max_over_ranks(self, x):
     return x
 
+  def comm_info(self):
+    return self.mg.comm_info(0)
+
   def close(self):
     self.mg.free_fit()
     self.mg.close()
@@ -172,6 +175,9 @@ class PerProcess(object):
 
   def max_over_ranks(self, x):
     return float(self.comm.allreduce_max([x])[0])
+
+  def comm_info(self):
+    return self.comm.info()
 
   def close(self):
     self.comm.barrier()
@@ -514,15 +520,18 @@ def c4_shards_on_one_gpu(runner, eng, spec, prob, result):
           'equals_timed_step_over_all_candidates': bool(int(i_red) == int(result['idx']) and v_red == result['best'])}
 
 
-def pmc_traffic():
+def pmc_traffic(scaling):
   """ HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over
       this same command (profiles/rNN_pmc_traffic.json, written by tools/rocpd_pmc_traffic.py).
-      Counters cannot be collected inside the timed run itself; the source file is named. """
+      Counters cannot be collected inside the timed run itself; the source file is named.  Only a record taken
+      under the same --scaling mode counts: the launches of a weak-scaling step are an eighth as long. """
   for name in PMC_TRAFFIC_FILES:
     path = os.path.join(ROOT, 'profiles', name)
     try:
       with open(path) as f:
         rec = json.load(f)
+        if rec.get('scaling', 'weak') != scaling:
+          continue
         note = (' (%d launches per step in the counter passes: %s)' % (rec['launches'], rec['schedule_note'])) \
                if 'schedule_note' in rec else ''
         return rec['hbm_bytes_per_launch'], 'profiles/' + name + note
@@ -591,7 +600,7 @@ def main():
     # wall-clock is the union of its launch intervals (busy_ms), not the sum of their durations
     achieved = g0['flop'] / (g0['busy_ms'] * 1e-3) / 1e12 if g0['busy_ms'] > 0 else 0.0
     achieved_sum = g0['flop'] / (g0['ms'] * 1e-3) / 1e12 if g0['ms'] > 0 else 0.0
-    traffic, traffic_src = pmc_traffic()
+    traffic, traffic_src = pmc_traffic(args.scaling)
     out = {
       'metric': 'GP-fit+acq-batch ms at n=16384,d=32',
       'value': round(ms_per_step, 3), 'unit': 'ms', 'n_gpus': world, 'steps': args.steps,
@@ -633,7 +642,18 @@ def main():
       'device': eng.name(),
       # factorisations that had to be repeated on the hand-off-free schedule so far in this process (expected: 0)
       'chol_fallbacks': eng.counters()['chol_fallbacks'],
+      # the communicator as RCCL itself reports it (ncclCommCount / ncclCommUserRank / ncclGetVersion on rank 0):
+      # a scaling record is checked for "RCCL formed N ranks" against ranks_formed, not against --gpus
+      'comm': runner.comm_info(),
     }
+    # north_star's two side targets and the fit's sections as flat top-level scalars (a driver that keeps only
+    # scalars keeps these): from the extra, untimed step whose section timers synchronise the host
+    st = out['roofline']['side_targets']
+    out['cholesky_frac_of_fp64_mfma_peak'] = st['cholesky_frac_of_fp64_mfma_peak']
+    out['kernel_matrix_frac_of_hbm_peak'] = st['kernel_matrix_frac_of_hbm_peak']
+    for key in ('kernmat', 'chol', 'solve', 'cross', 'trsm', 'ts'):
+      out[key + '_ms'] = round(sections[key], 4) if sections.get(key, 0) > 0 else None
+    out['kernel_matrix_bytes_algorithmic'] = 8 * (N_TRAIN ** 2 + 2 * N_TRAIN * DIM)
     if not args.no_extras and world == 1:       # (ranks of a multi-process run stay in step: no rank-0-only extras)
       # conditioning of the matrix that was factored (quoted next to the parity numbers):
       # lambda_max(K) by power iteration on the host, lambda_min(K + noise I) >= noise

@@ -15,6 +15,7 @@ besides the headline step, each with the CPU oracle timed beside it and an equal
 Nothing here is inside bench.py's timed region; the oracle (oracle/ref_numpy.py) is the checker and
 the CPU leg only.
 """
+import os
 import time
 from argparse import Namespace
 
@@ -129,6 +130,11 @@ def hp_tuning(eng):
       lml = eng.gp_lml_batch(specs[:budget], Xd, Y, means[:budget], noises[:budget])
       eng.sync()
       row['ms_%d' % budget] = round((time.perf_counter() - t0) * 1e3, 2)
+    # a small group on its own (a tree-search frontier, a slice sampler's loop): 64 and 8 candidates per call
+    for small in (64, 8):
+      _median_ms(lambda: eng.gp_lml_batch(specs[:small], Xd, Y, means[:small], noises[:small]), eng.sync, reps=2, warm=1)
+      row['ms_batch_of_%d' % small] = round(_median_ms(lambda: eng.gp_lml_batch(specs[:small], Xd, Y, means[:small], noises[:small]),
+                                                       eng.sync, reps=5, warm=0), 4)
     kc = 24 if n <= 1000 else 6
     t0 = time.perf_counter()
     ref = [O.GPOracle(X, Y, O.KernelSpec('se', d, scales[c], bws[c]), means[c], noises[c]).lml() for c in range(kc)]
@@ -139,7 +145,8 @@ def hp_tuning(eng):
     out['n%d' % n] = row
     Xd.free()
   out['what'] = ('log marginal likelihood of 500 / 10000 hyper-parameter candidates per call sequence (SE-ARD d = 3 / 6), '
-                 'dfh_gp_lml_batch; oracle = one NumPy fit per candidate (sample of 24 / 6)')
+                 'dfh_gp_lml_batch; ms_batch_of_64 / _8: one call with that many candidates (wall, host side included); '
+                 'oracle = one NumPy fit per candidate (sample of 24 / 6)')
   return out
 
 
@@ -330,10 +337,33 @@ def hallucinated_batch(eng, workers=8, m_parity=4096):
           'picks_equal_vs_oracle_over_%d' % m_parity: bool(picks_d == picks_o), 'ei_rel_per_q': rels}
 
 
+def bo_wallclock():
+  """ Only where a Dragonfly checkout is beside the GPU (DRAGONFLY_REFERENCE): dragonfly.maximise_function on Hartmann6
+      with default options, 60 evaluations, the reference as it is and with dragonfly_amd.install(), each in a process of
+      its own (tools/bo_wallclock.py; install() rebinds module globals).  profiles/r05_bo_wallclock.json holds the
+      builder's runs at 60 / 200 / 1000 evaluations. """
+  import json
+  import subprocess
+  import sys
+  ref = os.environ.get('DRAGONFLY_REFERENCE', '')
+  if not ref or not os.path.isdir(os.path.join(ref, 'dragonfly')):
+    return {'skipped': 'no Dragonfly checkout on this box (DRAGONFLY_REFERENCE); see profiles/r05_bo_wallclock.json'}
+  tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'bo_wallclock.py')
+  out = {}
+  for mode in ('install', 'ref'):
+    res = subprocess.run([sys.executable, tool, '60', mode], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    out[mode] = json.loads(lines[-1]) if lines else {'error': res.stderr[-400:]}
+  if 'wall_s' in out['ref'] and 'wall_s' in out['install']:
+    out['speedup_wall'] = round(out['ref']['wall_s'] / out['install']['wall_s'], 2)
+  return out
+
+
 def run_all(eng, prob, spec, include_c4_full=True):
   out = {}
   for name, fn in (('C1', lambda: config1(eng)), ('hp_tuning', lambda: hp_tuning(eng)), ('append', lambda: append(eng)),
-                   ('pdoo', lambda: pdoo(eng)), ('hallucinated_batch', lambda: hallucinated_batch(eng))):
+                   ('pdoo', lambda: pdoo(eng)), ('hallucinated_batch', lambda: hallucinated_batch(eng)),
+                   ('bo_wallclock', bo_wallclock)):
     try:
       out[name] = fn()
     except Exception as e:      # pylint: disable=broad-except

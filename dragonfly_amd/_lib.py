@@ -5,6 +5,7 @@ library (or a gfx950 device) is missing, loading / creating an engine raises lou
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -107,6 +108,7 @@ SIGNATURES = {
   'dfh_comm_destroy': (None, [C.c_void_p]),
   'dfh_comm_rank': (C.c_int, [C.c_void_p]),
   'dfh_comm_size': (C.c_int, [C.c_void_p]),
+  'dfh_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
   'dfh_comm_allgather_argmax': (C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_double_p, c_int64_p]),
   'dfh_comm_allgather_f64': (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
   'dfh_comm_allreduce_max': (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
@@ -145,6 +147,8 @@ def load():
     return _lib
   # DFH_LIB: another build of the same sources (the diagnostics build libdfhip_dbg.so of kernel work)
   path = os.environ.get('DFH_LIB') or LIB_PATH
+  if path != LIB_PATH:
+    sys.stderr.write('dragonfly_amd: DFH_LIB is set -- loading %s instead of the packaged %s\n' % (path, LIB_PATH))
   if not os.path.exists(path):
     raise ImportError('%s not found. Build it with `python -m dragonfly_amd.build` '
                       '(hipcc, gfx950). dragonfly_amd has no CPU fallback.' % path)

@@ -1307,6 +1307,8 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
   } else {
     std::memcpy(y_host.data(), y, (size_t)n * 8);
   }
+  double sum_y = 0.0, sum_y2 = 0.0;
+  for (int64_t i = 0; i < n; ++i) { sum_y += y_host[(size_t)i]; sum_y2 = fma(y_host[(size_t)i], y_host[(size_t)i], sum_y2); }
   double *Kb = nullptr, *red = nullptr, *dpar = nullptr;
   long long* dinfo = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * sK * 8, (void**)&Kb));
@@ -1345,9 +1347,9 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
     const int64_t sXp = n * Pmax, sNp = n * parts_max;
     for (int c = 0; c < g; ++c) {
       // the augmented row's diagonal entry: c = 1 + |y - m|^2 / s2 > z.z (the eigenvalues of K + s2 I are >= s2)
+      // (|y - m|^2 = sum y^2 - 2 m sum y + n m^2: a bound needs no more than that, with a hair of slack for its rounding)
       const double m = mean_consts ? mean_consts[c0 + c] : 0.0, s2 = noise_vars[c0 + c];
-      double r2 = 0.0;
-      for (int64_t i = 0; i < n; ++i) { const double r = y_host[(size_t)i] - m; r2 = fma(r, r, r2); }
+      const double r2 = std::max(0.0, (sum_y2 - 2.0 * m * sum_y + (double)n * m * m)) * (1.0 + 1e-6) + 1e-6 * sum_y2;
       hpar[c] = 1.0 + r2 / s2;
       hpar[g + c] = m;
       hpar[2 * g + c] = s2;

@@ -64,6 +64,7 @@ struct dfh_ctx {
   // the next calls go straight to that schedule (chol_cooldown of them), so that a crowded device does not pay
   // the time-out of ~1 s on every fit
   int64_t chol_fallbacks = 0;
+  int64_t chol_notpd_rechecks = 0;   // "not positive definite" verdicts of a hand-off schedule that were re-examined on the safe one
   int chol_fallback_streak = 0, chol_cooldown = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
@@ -319,7 +320,8 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
                     int64_t* info_pivot, int nbatch = 1, int64_t strideA = 0, int64_t strideKeep = 0,
                     int* refine_out = nullptr, bool inv64_only = false,
                     const std::function<int()>* rebuild = nullptr);
-constexpr int DFH_INTERNAL_RETRY = 1000;   // chol.hip internal: never crosses the C-ABI
+constexpr int DFH_INTERNAL_RETRY = 1000;   // chol.hip internal: never crosses the C-ABI (a hand-off wait expired)
+constexpr int DFH_INTERNAL_RETRY_COND = 1001;   // ... a block inverse too poor for the inverse-based panel solve (deterministic)
 
 // The tuning objective of `count` candidates, one workgroup per candidate (chol.hip: lml_wg_kernel): Cholesky of the
 // augmented matrix [[K, .], [(y - m)^T, c]] of each, sum(log L_ii) and |L^-1 (y - m)|^2 out.  K: matrices padded to

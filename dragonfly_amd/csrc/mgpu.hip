@@ -41,6 +41,8 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   int (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 
 std::mutex g_rccl_mu;
@@ -77,6 +79,8 @@ int rccl_load(const RcclApi** out) {
       g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
       g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
       g_rccl.GetVersion = (decltype(g_rccl.GetVersion))sym("ncclGetVersion");
+      g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+      g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
       if (!ok) { dlclose(g_rccl.handle); g_rccl.handle = nullptr; }
     }
   }
@@ -226,6 +230,21 @@ extern "C" int dfh_comm_create(dfh_ctx* ctx, int nranks, int rank, const void* i
 
 extern "C" int dfh_comm_rank(dfh_comm* c) { return c ? c->rank : -1; }
 extern "C" int dfh_comm_size(dfh_comm* c) { return c ? c->nranks : -1; }
+
+// What the communicator ITSELF says (ncclCommCount / ncclCommUserRank / ncclGetVersion), as opposed to what it was
+// asked to be: a scaling record can be checked for "RCCL formed N ranks" from these.  A test-mode communicator
+// (duplicate devices: the exchange runs on the host) reports 0 ranks formed.
+extern "C" int dfh_comm_info(dfh_comm* c, int32_t* ranks_formed, int32_t* rank, int32_t* rccl_version) {
+  DFH_ARG(c && ranks_formed && rank && rccl_version);
+  *ranks_formed = 0; *rank = c->rank; *rccl_version = 0;
+  if (!c->comm || !c->api) return DFH_OK;
+  int cnt = 0, ur = -1, ver = 0;
+  DFH_NCCL(c->api, c->api->CommCount(c->comm, &cnt));
+  DFH_NCCL(c->api, c->api->CommUserRank(c->comm, &ur));
+  if (c->api->GetVersion) c->api->GetVersion(&ver);
+  *ranks_formed = cnt; *rank = ur; *rccl_version = ver;
+  return DFH_OK;
+}
 
 // enqueue the all-gather of this rank's pair on its context's stream
 static int comm_gather_enqueue(dfh_comm* c, double val, int64_t idx) {

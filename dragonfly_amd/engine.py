@@ -100,6 +100,38 @@ class DeviceArray(object):
 _SINGLE_KINDS = {'se': KERNEL_SE, 'matern': KERNEL_MATERN, 'poly': KERNEL_POLY, 'expdecay': KERNEL_EXPDECAY}
 
 
+_DESC_DTYPE = np.dtype({'names': [f[0] for f in KernelDesc._fields_],
+                        'formats': ['<i4' if f[1] is C.c_int32 else ('<f8' if f[1] is C.c_double else '<u8') for f in KernelDesc._fields_],
+                        'offsets': [getattr(KernelDesc, f[0]).offset for f in KernelDesc._fields_],
+                        'itemsize': C.sizeof(KernelDesc)})
+
+
+def _single_kind_descs(specs, d, backing):
+  """ struct dfh_kernel_desc[len(specs)] for a list of SE / Matern / polynomial / exponential-decay candidates of
+      dimension d, filled column-wise (a tuning batch holds thousands: 6 us of ctypes per candidate otherwise);
+      None if some candidate has groups or a bandwidth vector of another length (to_desc reports those). """
+  nb = len(specs)
+  if nb == 0:
+    return None
+  try:
+    kinds = np.fromiter((_SINGLE_KINDS[sp.kind] for sp in specs), dtype=np.int32, count=nb)
+  except KeyError:
+    return None
+  if any(sp.bandwidths is None or sp.bandwidths.size != d or sp.dim != d for sp in specs):
+    return None
+  bw = np.empty((nb, d), dtype=np.float64)
+  for i, sp in enumerate(specs):
+    bw[i] = sp.bandwidths
+  arr = np.zeros(nb, dtype=_DESC_DTYPE)
+  arr['kind'] = kinds
+  arr['dim'] = d
+  arr['scale'] = np.fromiter((sp.scale for sp in specs), dtype=np.float64, count=nb)
+  arr['nu'] = np.fromiter((sp.nu for sp in specs), dtype=np.float64, count=nb)
+  arr['bw'] = bw.ctypes.data + np.arange(nb, dtype=np.uint64) * np.uint64(8 * d)
+  backing += [bw, arr]
+  return arr.ctypes.data_as(C.POINTER(KernelDesc))
+
+
 class KernelSpec(object):
   """ Host-side description of a Euclidean kernel, convertible to struct dfh_kernel_desc.
       kind: 'se' | 'matern' | 'poly' (nu = order, bandwidths = dim_scalings) | 'expdecay' (nu =
@@ -349,10 +381,11 @@ class Engine(object):
 
   def counters(self):
     """ {'chol_fallbacks': factorisations repeated on the hand-off-free schedule, 'chol_cooldown': how many
-        of the next ones skip the hand-off schedules} (dfh_ctx_counters) """
+        of the next ones skip the hand-off schedules, 'chol_notpd_rechecks': "not positive definite" verdicts that
+        were re-examined on the schedule without hand-offs before they stood} (dfh_ctx_counters) """
     arr = (C.c_int64 * 4)()
     check(self.lib.dfh_ctx_counters(self.ctx, arr))
-    return {'chol_fallbacks': int(arr[0]), 'chol_cooldown': int(arr[1])}
+    return {'chol_fallbacks': int(arr[0]), 'chol_cooldown': int(arr[1]), 'chol_notpd_rechecks': int(arr[2])}
 
   def gemm_profile(self, enable=True, fetch=True):
     """ Per-variant {launches, ms (sum of launch durations), flop, busy_ms (union of the launch
@@ -455,12 +488,14 @@ class Engine(object):
     Xh = X if isinstance(X, DeviceArray) else _f64(X)
     yh = y if isinstance(y, DeviceArray) else _f64(y)
     n, d = Xh.shape
-    descs = (_lib.KernelDesc * max(nb, 1))()
     backing = []
-    for i, sp in enumerate(specs):
-      one = sp.to_desc()
-      backing.append(one.backing)       # the arrays the copied struct points at
-      descs[i] = one
+    descs = _single_kind_descs(specs, d, backing)      # one vectorised fill when every candidate is a plain kernel
+    if descs is None:
+      descs = (_lib.KernelDesc * max(nb, 1))()
+      for i, sp in enumerate(specs):
+        one = sp.to_desc()
+        backing.append(one.backing)       # the arrays the copied struct points at
+        descs[i] = one
     mc = _f64(np.zeros(nb) if mean_consts is None else mean_consts).reshape(-1)
     nv = _f64(noise_vars).reshape(-1)
     if len(mc) != nb or len(nv) != nb:

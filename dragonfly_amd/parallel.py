@@ -173,6 +173,13 @@ class RcclComm(object):
   def barrier(self):
     check(self.lib.dfh_comm_barrier(self.handle))
 
+  def info(self):
+    """ {'backend', 'ranks_formed', 'rank', 'rccl_version'} as the communicator itself reports them
+        (ncclCommCount / ncclCommUserRank / ncclGetVersion). """
+    nr, rk, ver = C.c_int32(0), C.c_int32(-1), C.c_int32(0)
+    check(self.lib.dfh_comm_info(self.handle, C.byref(nr), C.byref(rk), C.byref(ver)))
+    return {'backend': 'rccl', 'ranks_formed': int(nr.value), 'rank': int(rk.value), 'rccl_version': int(ver.value)}
+
   def close(self):
     if self.handle is not None:
       self.lib.dfh_comm_destroy(self.handle)
@@ -261,6 +268,9 @@ class HostExchangeComm(object):
   def barrier(self):
     self._allgather([0.0])
 
+  def info(self):
+    return {'backend': 'host files (test mode)', 'ranks_formed': 0, 'rank': self.rank, 'rccl_version': 0}
+
   def close(self):
     """ A rank that closes has finished every read; rank 0 waits until all have and clears the files. """
     if self._seq < 0:
@@ -320,6 +330,16 @@ class MultiEngine(object):
     self.lml = None
     self.jitter_power = None
     self._keep = None
+
+  def comm_info(self, rank=0):
+    """ Rank `rank`'s communicator as RCCL reports it (dfh_comm_info); ranks_formed == 0: the host-exchange test mode. """
+    nr, rk, ver = C.c_int32(0), C.c_int32(-1), C.c_int32(0)
+    comm = C.c_void_p(self.lib.dfh_mgpu_comm(self.handle, int(rank)))
+    if not comm:
+      return {'backend': 'none (one device)' if self.size == 1 else 'host exchange (test mode)', 'ranks_formed': 0, 'rank': int(rank), 'rccl_version': 0}
+    check(self.lib.dfh_comm_info(comm, C.byref(nr), C.byref(rk), C.byref(ver)))
+    return {'backend': 'rccl' if nr.value > 0 else 'host exchange (test mode)', 'ranks_formed': int(nr.value),
+            'rank': int(rk.value), 'rccl_version': int(ver.value)}
 
   def _per_rank(self, a):
     """ One entry per rank: a list is taken as is, anything else is shared by all ranks. """

@@ -366,6 +366,10 @@ int  dfh_comm_create(dfh_ctx* ctx, int nranks, int rank, const void* id, dfh_com
 void dfh_comm_destroy(dfh_comm* comm);
 int  dfh_comm_rank(dfh_comm* comm);
 int  dfh_comm_size(dfh_comm* comm);
+/* The communicator as RCCL reports it: ranks it formed (ncclCommCount; 0 for the host-exchange test mode), this
+ * rank (ncclCommUserRank), library version (ncclGetVersion, e.g. 22707).  No reference counterpart: the reference
+ * is one process (dragonfly/utils/oper_utils.py:59-80 finds its arg-max in one array).                          */
+int  dfh_comm_info(dfh_comm* comm, int32_t* ranks_formed, int32_t* rank, int32_t* rccl_version);
 /* all-gather of (local_val, local_idx) on the context's stream + the reduce; identical result on
  * every rank.  local_idx is the GLOBAL row index (or < 0 for an empty shard).                   */
 int  dfh_comm_allgather_argmax(dfh_comm* comm, double local_val, int64_t local_idx,

@@ -738,6 +738,78 @@ def gen_nonpsd_cases():
   print('wrote nonpsd_gp (min eig K: plain %.3f, cp %.3f)' % (res['min_eig_K'], res['cp_min_eig_K']))
 
 
+def gen_engine_traces():
+  """ For each of the 25 configurations of tests/test_gpu_install_end_to_end.py: the UNMODIFIED reference optimiser with
+      dragonfly_amd.install(), on the NumPy stand-in engine behind a recorder (tests/engine_trace.py) -- every call that
+      reaches the engine object, in order, with arguments and results -> tests/golden/engine_trace_<name>.npz.  Before
+      anything is written the run is checked against the same run WITHOUT install(): the same points, bit for bit
+      (dragonfly/opt/gp_bandit.py:405-421, 490, 647-673; apis/opt.py:138). """
+  tests_dir = os.path.join(os.path.dirname(HERE), 'tests')
+  if tests_dir not in sys.path:
+    sys.path.insert(0, tests_dir)
+  import_reference()
+  import engine_trace as ET
+  import test_install_end_to_end as E
+  from dragonfly_amd import install
+  from dragonfly_amd import euclidean_gp, general_utils, gp_core, gpb_acquisitions, kernel
+  from dragonfly_amd import engine as engine_mod
+
+  def maximise_function_run():
+    from dragonfly import maximise_function
+    f = lambda x: -float((x[0] - 0.3) ** 2 + (x[1] + 0.2) ** 2) + 0.05 * float(np.cos(7 * x[0]))
+    np.random.seed(77)
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      val, pt, history = maximise_function(f, [[-1, 1], [-1, 1]], 7)
+    return [np.array([val]), np.array(pt), np.array(history.query_points)]
+
+  scenarios = []
+  for i, cfg in enumerate(E.CONFIGS):
+    scenarios.append(('ask_%02d_%s_%s_%s' % (i, cfg['kernel_type'], cfg['acq'], cfg['acq_opt_method']),
+                      (lambda c=cfg: [np.array(p) for p in E._ask(c)[0]]), {}, dict(kind='ask', options=cfg)))       # pylint: disable=protected-access
+  for i, (mode, workers, extra) in enumerate(E.FULL_RUNS):
+    scenarios.append(('full_%02d_%s%d_%s' % (i, mode, workers, extra['acq'].replace('-', '_')),
+                      (lambda m=mode, w=workers, e=extra: [E._full_run(m, w, e)]), {},                              # pylint: disable=protected-access
+                      dict(kind='full run', mode=mode, workers=workers, options=extra)))
+  for acq, method in (('ts', 'rand'), ('ucb', 'rand'), ('ucb', 'pdoo')):
+    scenarios.append(('moo_%s_%s' % (acq, method), (lambda a=acq, m=method: [E._moo_run(a, m)]), {},              # pylint: disable=protected-access
+                      dict(kind='multi-objective', acq=acq, method=method)))
+  for workers, acq in ((1, None), (3, 'ucb-ts')):
+    scenarios.append(('mf_%d_%s' % (workers, (acq or 'default').replace('-', '_')),
+                      (lambda w=workers, a=acq: [np.array(v) for v in E._mf_run(w, a)[:2]]), dict(multi_fidelity=True),   # pylint: disable=protected-access
+                      dict(kind='multi-fidelity', workers=workers, acq=acq)))
+  scenarios.append(('maximise_function_defaults', maximise_function_run, {}, dict(kind='dragonfly.maximise_function, default options')))
+
+  mods = (engine_mod, euclidean_gp, general_utils, gp_core, kernel)
+  total = 0
+  for name, run, install_kwargs, meta in scenarios:
+    want = run()                                   # the reference as it is
+    eng, log = ET.recording_engine()
+    saved = [(m, m.get_engine) for m in mods]
+    saved_dc = gpb_acquisitions.DEVICE_CANDIDATES
+    for m in mods:
+      m.get_engine = (lambda _e=eng: _e)
+    gpb_acquisitions.DEVICE_CANDIDATES = False
+    install.install(**install_kwargs)
+    try:
+      got = run()
+    finally:
+      install.uninstall()
+      for m, fn in saved:
+        m.get_engine = fn
+      gpb_acquisitions.DEVICE_CANDIDATES = saved_dc
+    assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want)), name
+    meta = dict(meta, name=name, events=len(log.events), reference_points_equal=True,
+                result_shapes=[list(np.shape(w)) for w in want])
+    ET.save(os.path.join(OUT, 'engine_trace_%s.npz' % name), log, meta)
+    kinds = {}
+    for ev in log.events:
+      kinds[ev['m']] = kinds.get(ev['m'], 0) + 1
+    total += len(log.events)
+    print('wrote engine_trace_%s: %d calls %s' % (name, len(log.events), kinds))
+  print('engine traces: %d scenarios, %d calls' % (len(scenarios), total))
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   import_reference()
@@ -769,6 +841,9 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':
     gen_trajectory_case()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'engine_traces':
+    gen_engine_traces()
+    sys.exit(0)
   gen_gp_cases()
   gen_fitter_case()
   gen_c1_case()
@@ -781,3 +856,4 @@ if __name__ == '__main__':
   gen_post_sampling_cases()
   gen_trajectory_case()
   gen_nonpsd_cases()
+  gen_engine_traces()

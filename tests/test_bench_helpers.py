@@ -28,15 +28,18 @@ def test_fp64_pipe_bound():
   assert r['frac_of_fp64_pipe_peak'] == pytest.approx((r['min_ms_mfma'] + r['min_ms_valu']) / 1.0, rel=1e-3)
 
 
-def test_cpu_legs_agree_stage_by_stage(monkeypatch):
+# (n = 2048 with 1100 candidates: OpenBLAS / LAPACK take their blocked, multi-threaded code paths there -- dpotrf's
+#  recursive panels, dtrsm / dgemm blocking -- which n = 384 does not reach: `kind: port` is pinned to the reference's
+#  own functions at a size where the library's blocking matters)
+@pytest.mark.parametrize('n,m', [(384, 128), (2048, 1100)])
+def test_cpu_legs_agree_stage_by_stage(monkeypatch, n, m):
   ref = os.environ.get('DRAGONFLY_REFERENCE', '/root/reference')
   if not os.path.isdir(os.path.join(ref, 'dragonfly')):
     pytest.skip('needs the reference tree (build container only)')
   prob = BC.config3()
-  n = 384
   X, Y = prob['X'][:n], prob['Y'][:n]
-  cands = np.random.RandomState(0).rand(128, BC.DIM)
-  U = np.random.RandomState(1).randn(128)
+  cands = np.random.RandomState(0).rand(m, BC.DIM)
+  U = np.random.RandomState(1).randn(m)
   monkeypatch.setenv('DRAGONFLY_REFERENCE', ref)
   fr, kr, kind_r, _ = bench.cpu_functions(prob)
   monkeypatch.setenv('DRAGONFLY_REFERENCE', '')

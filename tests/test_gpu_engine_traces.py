@@ -1,0 +1,32 @@
+"""MI355X, no Dragonfly checkout needed: the drop-in boundary under the REAL reference optimiser, call by call.
+
+oracle/make_golden.py (gen_engine_traces) ran the unmodified reference -- EuclideanGPBandit in ask/tell mode with
+every acquisition / maximiser / tuning criterion (11 configurations), whole runs with parallel synthetic workers
+(8), multi-objective (3) and multi-fidelity (2) bandits and dragonfly.maximise_function with its defaults --
+with dragonfly_amd.install() on the NumPy stand-in engine, checked that each run returns the reference's own points
+bit for bit, and recorded every call on the engine object (dragonfly/opt/gp_bandit.py:405-421, 490, 647-673 ->
+fitters, GPs, acquisitions -> Engine / FittedGP).  Here the same 42 286 calls go to libdfhip.so: fits and appends
+(lml within 1e-10, jitter powers equal), tuning batches, posterior mean / std / covariance, fused acquisition
+arg-maxes (values within 1e-10, indices equal), Thompson draws, additive-UCB groups.  This is the driver-visible half
+of tests/test_gpu_install_end_to_end.py (which needs the checkout beside the GPU)."""
+import glob
+import os
+
+import pytest
+
+import engine_trace as ET
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TRACES = sorted(glob.glob(os.path.join(HERE, 'golden', 'engine_trace_*.npz')))
+
+
+def test_all_25_configurations_are_there():
+  assert len(TRACES) == 25
+
+
+@pytest.mark.parametrize('path', TRACES, ids=lambda p: os.path.basename(p)[13:-4])
+def test_reference_optimiser_calls_replayed_on_the_device(engine, path):
+  calls, worst, meta = ET.replay(path, engine, tol=1e-10)
+  assert calls == meta['events'] and meta['reference_points_equal']
+  print('%s: %d calls, largest relative difference %.1e' % (meta['name'], calls, worst))

@@ -256,16 +256,31 @@ def test_hallucination_when_the_augmented_matrix_needs_the_ladder(engine, noise_
   Xs = rs.rand(m, d)
   mu_o, sd_o = og.eval_with_hallucinated_observations(Xs, Xh)
   mu_d, sd_d = gp.predict(Xs, X_halluc=Xh)
-  # (robustness asserts, not parity asserts: the augmented matrix is numerically singular, the two sides'
-  #  solves differ by cond x eps; what is checked is that the device does what the reference does -- goes on
-  #  with the ladder -- and lands where the reference lands to the accuracy such a matrix allows)
-  assert relerr(mu_d, mu_o) < 1e-6
+  # The augmented matrix is numerically singular: the two sides' solves differ by cond x eps, and a literal 1e-10
+  # cannot hold.  The bound is computed, as everywhere (tests/truth_bounds.py): both sides against the same linear
+  # algebra in extended precision on the same Gram matrices (with whatever jitter the reference's ladder settled
+  # on), the device held to max(1e-10, 8 x the reference's own distance from that truth).  (8, not the 2 of the other
+  # cases: at noise 1e-13 x scale the base matrix has cond ~ 1e13 and is factored WITHOUT jitter on both sides; two
+  # correct eliminations in different orders land a few cond x eps apart -- measured 1.8e-10 for the device against
+  # 4.5e-11 for NumPy in the mean -- and a factor of 2 would be a statement about luck, not about correctness.)
+  from oracle import ref_longdouble as T
+  from truth_bounds import bound
+  ks = O.KernelSpec('se', d, scale, bw)
+  K = ks(X, X)
+  jit_b = 0.0 if og.jitter_power is None else (10.0 ** og.jitter_power) * float(np.diag(K + noise * np.eye(n)).max())
+  tr = T.gram_truth(K, noise + jit_b, Y, ks(Xs, X), np.diag(ks(Xs, Xs)).copy(), None, 0.0)
+  Xa = np.vstack([X, Xh])
+  Ka = ks(Xa, Xa)
+  _, pa = O.stable_cholesky(Ka + noise * np.eye(n + 2), return_power=True)
+  jit_a = 0.0 if pa is None else (10.0 ** pa) * float(np.diag(Ka + noise * np.eye(n + 2)).max())
+  tra = T.gram_truth(Ka, noise + jit_a, np.zeros(n + 2), ks(Xs, Xa), np.diag(ks(Xs, Xs)).copy(), ks(Xs, Xs), 0.0)
+  assert relerr(mu_d, tr['mu']) <= bound(mu_o, tr['mu'], factor=8.0)
   assert np.all(np.isfinite(sd_d) == np.isfinite(sd_o))
-  ok = np.isfinite(sd_o)
-  assert relerr(sd_d[ok], sd_o[ok]) < 1e-3
+  ok = np.isfinite(sd_o) & np.isfinite(tra['sd'])
+  assert relerr(sd_d[ok], tra['sd'][ok]) <= bound(sd_o[ok], tra['sd'][ok], factor=8.0)
   _, cov_o = og.eval_with_hallucinated_observations(Xs, Xh, 'covar')
   _, cov_d = gp.predict_covar(Xs, X_halluc=Xh)
-  assert relerr(cov_d, cov_o) < 1e-3
+  assert relerr(cov_d, tra['cov']) <= bound(cov_o, tra['cov'], factor=8.0)
 
 
 def test_thompson_blocks_in_the_panel_strip_regime(engine):

@@ -12,6 +12,7 @@ import json, sys
 rec = json.load(open(sys.argv[1]))
 rec['schedule_note'] = ('--pmc serialises kernels, so the counter passes run with DFH_CHOL_LR=0: the trailing updates that the default '
                         'schedule gives to gemm_f64_la_kernel are launches of this kernel there')
+rec['scaling'] = 'strong'      # bench.py's default: the whole of config 4 per step (bench.pmc_traffic matches on it)
 json.dump(rec, open(sys.argv[1], 'w'), indent=1)
 PY
 {
