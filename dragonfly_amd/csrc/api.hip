@@ -666,9 +666,16 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
     const double *dX = nullptr, *dy = nullptr;
     DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
     DFH_TRY(to_device(ctx, y_centred, (size_t)n * 8, SCR_STAGE_B, &dy));
+    // From n = 2048 on only the lower triangle of the Gram matrix is written (the factorisation, in place in this buffer,
+    // reads nothing else; whoever asks for GP.L gets a zeroed upper part, dfh_gp_get): half the bytes of the
+    // HBM-write-bound build.  DFH_KM_LOWER_ONLY=0: the full symmetric matrix as before.
+    static const bool lower_env = []() { const char* e = getenv("DFH_KM_LOWER_ONLY"); return e ? atoi(e) != 0 : true; }();
     auto build_M = [&]() -> int {     // K + noise_var * I     (gp_core.py:843)
       SectionTimer t(ctx, DFH_T_KERNMAT);
-      return kernmat_packed(ctx, kd, 0, kd.n_parts, true, gp->Xp, gp->Np, n, gp->Xp, gp->Np, n, true, noise_var, gp->L, n);
+      ctx->km_lower_only = lower_env && n >= 2048;
+      const int rc = kernmat_packed(ctx, kd, 0, kd.n_parts, true, gp->Xp, gp->Np, n, gp->Xp, gp->Np, n, true, noise_var, gp->L, n);
+      ctx->km_lower_only = false;
+      return rc;
     };
     {
       SectionTimer t(ctx, DFH_T_KERNMAT);

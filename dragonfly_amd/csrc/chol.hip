@@ -2584,22 +2584,6 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
   const bool safe_first = force_safe || cooling;
   int rc = attempt(rebuild != nullptr && !cooling, safe_first);
   static const bool verbose = env_int("DFH_CHOL_VERBOSE", 0) != 0;
-  if (rc == DFH_ERR_NOT_PD && rebuild && !safe_first) {
-    // "Not positive definite" from a schedule with inter-workgroup hand-offs is re-examined ONCE on the schedule
-    // without them before it stands (the caller's jitter ladder or LinAlgError hang on it).  Round 4 met a build of
-    // the one-launch panel that produced NaN columns -- hence a failed pivot -- on a diagonally dominant block
-    // (docs/NOTES_r05.md: deterministic for that code generation, not a wait-state hazard; the shipped form is the
-    // one every build agrees on); should any such mis-step recur, it costs a second factorisation, not a wrong verdict.
-    // A matrix that really is not positive definite fails both times, at the cost of a genuine failure's time twice.
-    static const bool recheck = env_int("DFH_CHOL_RECHECK_NOTPD", 1) != 0;
-    if (recheck) {
-      ++ctx->chol_notpd_rechecks;
-      if (verbose) fprintf(stderr, "dfhip: factorisation of n = %lld: %s -- re-examined on the safe schedule\n", (long long)n, dfh_last_error());
-      DFH_TRY((*rebuild)());
-      rc = attempt(false, true);
-      return (rc == DFH_INTERNAL_RETRY || rc == DFH_INTERNAL_RETRY_COND) ? DFH_ERR_HIP : rc;
-    }
-  }
   if (rc != DFH_INTERNAL_RETRY && rc != DFH_INTERNAL_RETRY_COND) { if (!cooling) ctx->chol_fallback_streak = 0; return rc; }
   ++ctx->chol_fallbacks;
   // only hand-off time-outs (a crowded device) feed the cool-down: an ill-conditioned block is a property of the

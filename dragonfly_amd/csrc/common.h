@@ -64,7 +64,6 @@ struct dfh_ctx {
   // the next calls go straight to that schedule (chol_cooldown of them), so that a crowded device does not pay
   // the time-out of ~1 s on every fit
   int64_t chol_fallbacks = 0;
-  int64_t chol_notpd_rechecks = 0;   // "not positive definite" verdicts of a hand-off schedule that were re-examined on the safe one
   int chol_fallback_streak = 0, chol_cooldown = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
@@ -83,6 +82,9 @@ struct dfh_ctx {
   // When set, 128x128 GEMM launches request > 80 KB of LDS so that only ONE workgroup fits per
   // CU: the other half of every CU stays available to latency-critical kernels of another stream.
   bool gemm_half_occupancy = false;
+  // The next symmetric single-part Gram matrix is wanted as its lower triangle only (tiles on and below the diagonal;
+  // the rest of the buffer is left as it is): the fit path, whose factorisation reads nothing above the diagonal.
+  bool km_lower_only = false;
   // Extended GEMM launches of the factorisation (gemm_f64.hip, chol.hip), consumed by the next
   // gemm_f64 call(s) while set: a device-side skip condition (the launch exits unless *gemm_cond >
   // gemm_cond_thr) and the look-ahead tile order with its completion counters.

@@ -51,6 +51,7 @@ struct KmArgs {
   int apply_outer, symmetric;
   int product;                 // MULTI: parts are multiplied (CoordinateProductKernel) instead of summed
   int nt_stores;               // kernmat_sym_kernel: write the matrix with streaming stores
+  int lower_only;              // kernmat_sym_kernel: tiles of the lower triangle only, no mirror images (the fit path: the factorisation reads nothing else)
   double diag_add;
   double* K; long ldk;
   // lock-step batch over blockIdx.z (symmetric single-part kernel only): element strides of the
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256, OCC) void kernmat_sym_kernel(KmArgs p) {
 
   // staged stores: passes [0, NH) = the tile itself, SR rows at a time; passes [NH, 2 NH) = the
   // mirror image (rows = original columns)
-  const int npass = (!SYM || ti == tj) ? NH : 2 * NH;
+  const int npass = (!SYM || ti == tj || p.lower_only) ? NH : 2 * NH;
   for (int pass = 0; pass < npass; ++pass) {
     const bool mirror = pass >= NH;
     const int h = mirror ? pass - NH : pass;
@@ -1662,6 +1663,7 @@ int kernmat_sym_batch(dfh_ctx* ctx, const KernDev& kd, int count, int64_t sBlob,
   DFH_ARG(!kd.multi && kd.n_parts == 1 && (ldk & 1) == 0 && (sK & 1) == 0 &&
           (reinterpret_cast<uintptr_t>(K) & 15) == 0 && count <= 65535);
   KmArgs a;
+  a.lower_only = 0;
   a.ec = kExpConsts;
   a.Xp1 = Xp; a.Np1 = Np; a.Xp2 = Xp; a.Np2 = Np;
   a.n1 = (int)n; a.n2 = (int)n; a.P = kd.P; a.n_parts_total = kd.n_parts;
@@ -1686,6 +1688,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   if (n1 <= 0 || n2 <= 0) return DFH_OK;
   DFH_ARG(n1 < (1LL << 31) && n2 < (1LL << 31));
   KmArgs a;
+  a.lower_only = 0;
   a.mu_alpha = nullptr; a.mu_part = nullptr; a.mu_out = nullptr; a.mu_nblk = 0;
   a.ec = kExpConsts;
   a.sXp = a.sNp = a.sK = a.sBlob = 0; a.diag_adds = nullptr;
@@ -1694,6 +1697,7 @@ int kernmat_packed(dfh_ctx* ctx, const KernDev& kd, int part_lo, int part_hi, bo
   a.parts = kd.d_parts; a.part_lo = part_lo; a.part_hi = part_hi;
   a.outer = kd.outer_scale; a.apply_outer = apply_outer ? 1 : 0; a.product = kd.product ? 1 : 0;
   a.symmetric = symmetric ? 1 : 0; a.diag_add = diag_add;
+  a.lower_only = (symmetric && ctx->km_lower_only) ? 1 : 0;
   a.K = K; a.ldk = ldk;
   {
     static const int nt_env = []() { const char* e = getenv("DFH_KM_NT"); return e ? atoi(e) : -1; }();

@@ -273,8 +273,7 @@ extern "C" int dfh_ctx_counters(dfh_ctx* ctx, int64_t* out) {
   DFH_ARG(ctx && out);
   out[0] = ctx->chol_fallbacks;
   out[1] = ctx->chol_cooldown;
-  out[2] = ctx->chol_notpd_rechecks;
-  out[3] = 0;
+  out[2] = 0; out[3] = 0;
   return DFH_OK;
 }
 

@@ -381,11 +381,10 @@ class Engine(object):
 
   def counters(self):
     """ {'chol_fallbacks': factorisations repeated on the hand-off-free schedule, 'chol_cooldown': how many
-        of the next ones skip the hand-off schedules, 'chol_notpd_rechecks': "not positive definite" verdicts that
-        were re-examined on the schedule without hand-offs before they stood} (dfh_ctx_counters) """
+        of the next ones skip the hand-off schedules} (dfh_ctx_counters) """
     arr = (C.c_int64 * 4)()
     check(self.lib.dfh_ctx_counters(self.ctx, arr))
-    return {'chol_fallbacks': int(arr[0]), 'chol_cooldown': int(arr[1]), 'chol_notpd_rechecks': int(arr[2])}
+    return {'chol_fallbacks': int(arr[0]), 'chol_cooldown': int(arr[1])}
 
   def gemm_profile(self, enable=True, fetch=True):
     """ Per-variant {launches, ms (sum of launch durations), flop, busy_ms (union of the launch
