@@ -122,6 +122,20 @@ def _euclidean_dispatch(ours, theirs):
   return acquisition
 
 
+class _KernelMeanNoise(object):
+  """ What BatchedEuclideanGPFitter._lml_batch needs of the GP the reference's build_gp constructs -- kernel, mean
+      function, noise variance -- with EuclideanGP's constructor signature (gp/euclidean_gp.py:151-152). """
+  __slots__ = ('kernel', 'mean_func', 'noise_var', 'host_kernel')
+
+  def __init__(self, X, Y, kernel, mean_func, noise_var, kernel_hyperparams=None, build_posterior=True, reporter=None):
+    # pylint: disable=unused-argument
+    if isinstance(kernel, str) or build_posterior:
+      raise RuntimeError('dragonfly_amd.install: the candidate stand-in was asked for a real GP')
+    self.kernel, self.mean_func, self.noise_var = kernel, mean_func, noise_var
+    # (gp_core.GP._generic for a plain EuclideanGP: a kernel without a device description is evaluated by the host)
+    self.host_kernel = not (hasattr(kernel, 'to_spec') and getattr(kernel, 'has_device_spec', lambda: True)())
+
+
 def make_batched_fitter(ref_fitter_cls):
   """ A subclass of the reference's EuclideanGPFitter whose maximum-likelihood tuners evaluate the
       tuning objective (gp_core.py:551-564) in batches on the device. """
@@ -174,17 +188,30 @@ def make_batched_fitter(ref_fitter_cls):
       user_mean = getattr(self.options, 'mean_func', None) is not None
       specs, means, noises = [], [], []
       probe = [np.zeros(self.dim)]
-      for i, cts in enumerate(cts_hps_list):
-        dscr = list(dscr_hps[i]) if per_cand else list(dscr_hps)
-        gp = self.build_gp(cts, dscr, other_gp_params=other_gp_params, build_posterior=False)
-        if user_mean or getattr(gp, '_generic', True):
-          # an arbitrary mean function, or a kernel the host evaluates: one fit per candidate
-          return np.array([self._tuning_objective(c, list(dscr_hps[j]) if per_cand else list(dscr_hps),
-                                                  other_gp_params=other_gp_params)
-                           for j, c in enumerate(cts_hps_list)])
-        specs.append(gp.kernel.to_spec(self.dim))
-        means.append(float(gp.mean_func(probe)[0]))
-        noises.append(float(gp.noise_var))
+      # build_gp ends in `EuclideanGP(self.X, self.Y, kernel, mean_func, noise_var, build_posterior=False)`, a module
+      # global of the reference looked up at call time (gp/euclidean_gp.py:338).  All that is wanted of that object here
+      # are its three arguments: for the length of this loop the name is bound to a stand-in that keeps them and does
+      # nothing else (a GP object per candidate -- data lists copied and checked -- was a fifth of a small run's time).
+      import dragonfly.gp.euclidean_gp as _ref_egp
+      saved_cls = _ref_egp.EuclideanGP
+      _ref_egp.EuclideanGP = _KernelMeanNoise
+      try:
+        for i, cts in enumerate(cts_hps_list):
+          dscr = list(dscr_hps[i]) if per_cand else list(dscr_hps)
+          gp = self.build_gp(cts, dscr, other_gp_params=other_gp_params, build_posterior=False)
+          if user_mean or gp.host_kernel:
+            specs = None
+            break
+          specs.append(gp.kernel.to_spec(self.dim))
+          means.append(float(gp.mean_func(probe)[0]))
+          noises.append(float(gp.noise_var))
+      finally:
+        _ref_egp.EuclideanGP = saved_cls
+      if specs is None:
+        # an arbitrary mean function, or a kernel the host evaluates: one fit per candidate
+        return np.array([self._tuning_objective(c, list(dscr_hps[j]) if per_cand else list(dscr_hps),
+                                                other_gp_params=other_gp_params)
+                         for j, c in enumerate(cts_hps_list)])
       if getattr(self, '_X_dev', None) is None:
         self._X_dev = get_engine().to_device(_as_2d_array(self.X))
       return get_engine().gp_lml_batch(specs, self._X_dev, np.asarray(self.Y, dtype=np.float64), means, noises)
@@ -210,15 +237,23 @@ def make_batched_fitter(ref_fitter_cls):
       num_cts = len(self.cts_hp_bounds)
       out = np.empty(len(xs))
       pending = []
+      base = np.array(self.hps, dtype=np.float64)
+
+      def prior_term(i, value):
+        prior = self.hp_priors[i]
+        if type(prior).__name__ == 'Categorical':
+          return prior.logp(prior.get_id(value))
+        return prior.logp(value)
+      # only the coordinate being sampled changes between the xs: the other priors' terms are evaluated once, and
+      # added in index order per x exactly as the reference's loop adds them (same partial sums, same bits)
+      cur = self.curr_hp
+      terms = [None if i == cur else prior_term(i, base[i]) for i in range(len(self.hp_priors))]
       for k, x in enumerate(xs):
-        hps = np.array(self.hps, dtype=np.float64)
-        hps[self.curr_hp] = x
+        hps = base.copy()
+        hps[cur] = x
         lp = 0
-        for i, prior in enumerate(self.hp_priors):
-          if type(prior).__name__ == 'Categorical':
-            lp += prior.logp(prior.get_id(hps[i]))
-          else:
-            lp += prior.logp(hps[i])
+        for i, t in enumerate(terms):
+          lp += prior_term(i, hps[i]) if t is None else t
         if not np.isfinite(lp):
           out[k] = lp
         else:
