@@ -609,8 +609,8 @@ __device__ __forceinline__ void lmlwg_load_tile(const LmlWgArgs& a, const double
   }
 }
 
-// acc[q] += L[tile row i0 + q * istep][K] L[tile row brow][K]^T for q < RG, this wave's 16 rows of each tile, K = the
-// tile columns [kt0, kt1) (default: all j of them; brow default j).  Sixteen columns per step.
+// acc[q] += L[tile row i0 + q * istep][0 : 64 j] L[tile row brow][0 : 64 j]^T for q < RG, this wave's 16 rows of each
+// tile (brow: j, or j + 1 for the look-ahead product of the next diagonal tile).  Sixteen columns per step.
 //   A operand (this wave's own rows): straight from L2 / HBM into MFMA fragments -- lane (kq, l15) holds columns
 //     2 kq, 2 kq + 1 and 8 + 2 kq, 9 + 2 kq of its row (two 16-byte loads, 64 contiguous bytes per row and
 //     instruction) and the four MFMAs of a step contract over the columns {c, 2 + c, 4 + c, 6 + c} + {0, 8}: any
@@ -625,17 +625,15 @@ __device__ __forceinline__ void lmlwg_load_tile(const LmlWgArgs& a, const double
 constexpr int LG_BKP = 18;                             // row stride of the B image (doubles): 16-byte aligned rows
 template <int RG>
 __device__ __forceinline__ void lmlwg_gemm(const double* __restrict__ Km, long ld, int j, int i0, int w, int kq, int l15,
-                                           double4_t (&acc)[2][4], double* Bs, int istep = 1, int brow = -1, int kt0 = 0,
-                                           int kt1 = -1) {
-  if (kt1 < 0) kt1 = j;
-  const int nch = 4 * (kt1 - kt0);                     // (a multiple of NS)
+                                           double4_t (&acc)[2][4], double* Bs, int istep = 1, int brow = -1) {
+  const int nch = 4 * j;                               // (a multiple of NS)
   if (nch <= 0) return;
   if (brow < 0) brow = j;
   const int tid = threadIdx.x;
   const double* pa[RG];
 #pragma unroll
-  for (int q = 0; q < RG; ++q) pa[q] = Km + (long)(64 * (i0 + q * istep) + 16 * w + l15) * ld + 64 * kt0 + 2 * kq;
-  const double* pbg = Km + (long)(64 * brow + (tid >> 2)) * ld + 64 * kt0 + 4 * (tid & 3);   // staging: row tid / 4, four columns
+  for (int q = 0; q < RG; ++q) pa[q] = Km + (long)(64 * (i0 + q * istep) + 16 * w + l15) * ld + 2 * kq;
+  const double* pbg = Km + (long)(64 * brow + (tid >> 2)) * ld + 4 * (tid & 3);   // staging: row tid / 4, four columns
   double* bst = Bs + (tid >> 2) * LG_BKP + 4 * (tid & 3);
   const double* bfr = Bs + l15 * LG_BKP + 2 * kq;      // fragments: row 16 t + l15, columns 2 kq (+ 8)
   constexpr int NS = 4;
@@ -863,10 +861,10 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
 // one workgroup per candidate).  A failed pivot is handed on as diag[j] = 2: every member that still has rows
 // waits for exactly that flag and leaves.  Nothing here assumes where a workgroup runs; co-residency of the
 // T * count <= CUs workgroups is what makes it fast, the bounded waits are what makes it safe.
-__device__ __forceinline__ int lmlt_wait(const int* p, const LmlWgArgs& a, int* s_val, int target = 1) {
+__device__ __forceinline__ int lmlt_wait(const int* p, const LmlWgArgs& a, int* s_val) {
   if (threadIdx.x == 0) {
     int spins = 0, v;
-    while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+    while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
       if (++spins > a.spin_limit) { atomicOr(a.status, (unsigned long long)SYNC_ST_FUSED); v = -1; break; }
       if ((spins & 63) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { v = -1; break; }
       __builtin_amdgcn_s_sleep(2);

@@ -139,6 +139,8 @@ VARIANTS = {
   'teams-of-four': ({'DFH_LML_TEAM': '4'}, 0),
   'teams-of-sixteen': ({'DFH_LML_TEAM': '16'}, 0),
   'small-groups': ({'DFH_LML_WG_GROUP': '7'}, 0),
+  'small-problems-too': ({'DFH_LML_TINY': '0'}, 0),
+  'small-problems-too-no-teams': ({'DFH_LML_TINY': '0', 'DFH_LML_TEAM': '0'}, 0),
   # every hand-off between the members of a team expires at once: the status word sends the group back through
   # one workgroup per candidate (counted in dfh_ctx_counters)
   'forced-handoff-timeout': ({'DFH_TEST_SPIN_LIMIT': '0'}, 1),
