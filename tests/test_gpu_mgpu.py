@@ -37,6 +37,9 @@ def test_mgpu_one_device_equals_single_device_calls(engine):
     cd, ud = mg.engines[0].to_device(cands), mg.engines[0].to_device(U)
     assert mg.thompson([cd], [ud], block=512, mean_const=mean_c) == want_ts
     assert mg.acq_argmax('ei', [cd], params=(float(yc.max() + mean_c), 0.0), mean_const=mean_c) == want_ei
+    # the communicator as RCCL itself reports it (dfh_comm_info: ncclCommCount / ncclCommUserRank / ncclGetVersion)
+    info = mg.comm_info(0)
+    assert info['backend'] == 'rccl' and info['ranks_formed'] == 1 and info['rank'] == 0 and info['rccl_version'] > 20000
     # the exchange alone: NaN-first / lowest-index rule comes back through RCCL unchanged
     assert mg.allgather_argmax([2.5], [17]) == (2.5, 17)
     v, i = mg.allgather_argmax([float('nan')], [4])
@@ -96,6 +99,8 @@ def test_process_per_gpu_communicator_single_rank(engine, monkeypatch, tmp_path)
   comm = parallel.RcclComm.from_env(engine, key='gpu_test')
   try:
     assert (comm.rank, comm.size) == (0, 1)
+    info = comm.info()
+    assert (info['ranks_formed'], info['rank']) == (1, 0) and info['rccl_version'] > 20000
     assert comm.allgather_argmax(1.25, 7) == (1.25, 7)
     v, i = comm.allgather_argmax(float('nan'), -1)       # every shard empty
     assert i == -1

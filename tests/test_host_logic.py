@@ -58,6 +58,32 @@ def test_kernel_desc_marshalling():
     KernelSpec('spline', 2, 1.0, [1, 1]).to_desc()
 
 
+def test_batch_descriptors_equal_the_per_candidate_ones():
+  """ engine._single_kind_descs (a tuning batch's struct array filled column-wise) == one to_desc per candidate, field by field """
+  from dragonfly_amd import engine as E
+  rs = np.random.RandomState(3)
+  d = 4
+  specs = []
+  for i in range(37):
+    kind = ['se', 'matern', 'poly', 'expdecay'][i % 4]
+    nu = {'se': 0.0, 'matern': [0.5, 1.5, 2.5][i % 3], 'poly': 2.0, 'expdecay': 0.3}[kind]
+    specs.append(KernelSpec(kind, d, 0.5 + rs.rand(), 0.2 + rs.rand(d), nu=nu))
+  keep = []
+  arr = E._single_kind_descs(specs, d, keep)      # pylint: disable=protected-access
+  assert arr is not None and len(keep) == 2
+  for i, sp in enumerate(specs):
+    one = sp.to_desc()
+    got = arr[i]
+    assert (got.kind, got.dim, got.scale, got.nu, got.n_groups) == (one.kind, one.dim, one.scale, one.nu, 0)
+    assert [got.bw[k] for k in range(d)] == [one.bw[k] for k in range(d)]
+    assert not got.group_off and not got.sub_bw and not got.factor_scale
+  # anything with groups, or a bandwidth vector of another length, takes the per-candidate path (which reports it)
+  add = K.AdditiveKernel(3.0, [K.SEKernel(2, 1.0, [0.5, 0.6]), K.MaternKernel(2, 2.5, 1.0, [0.7, 0.8])], [[2, 0], [1, 3]]).to_spec()
+  assert E._single_kind_descs(specs[:3] + [add], d, []) is None      # pylint: disable=protected-access
+  assert E._single_kind_descs([KernelSpec('se', d, 1.0, [0.1, 0.2])], d, []) is None      # pylint: disable=protected-access
+  assert E._single_kind_descs([], d, []) is None      # pylint: disable=protected-access
+
+
 def test_option_handler():
   specs = [get_option_specs('a', False, 1, ''), get_option_specs('b', False, 'x', '')]
   o = load_options(specs)
