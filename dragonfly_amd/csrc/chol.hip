@@ -539,10 +539,10 @@ constexpr int DIAG_STEP_SMEM = (PB * SPP + PB * PBP + PB + PB * PB + 3 * PB * 17
 // whose 1024 workgroups queue for 256 CUs, and 1.1 ms of 512-block inverses the likelihood never uses
 // (profiles/r05_lml_batch_before.txt).  Here a candidate never leaves its CU:
 //   left-looking over 64-column blocks j:  T_ij = A_ij - sum_{k<j} L_ik L_jk^T for the tile rows i >= j,
-//   two tile rows at a time, operands straight from L2 / HBM into MFMA fragments (no LDS, no barrier:
-//   each wave owns 16 rows of every tile and reads the 64 rows of block row j itself); then the diagonal
-//   tile through factor64_waves and the tiles below it through the 16-column MFMA substitution of
-//   diag_step64_kernel; every tile of A is read once and every tile of L written once.
+//   two tile rows at a time (each wave owns 16 rows of every tile: its A operand goes straight from L2 / HBM
+//   into MFMA fragments, the B operand -- block row j, shared by the four waves -- through a double-buffered
+//   LDS image; lmlwg_gemm); then the diagonal tile through factor64_waves and the tiles below it through the
+//   16-column MFMA substitution of diag_step64_kernel; every tile of A is read once, every tile of L written once.
 // The matrix is stored padded to NP = 64 ceil((n + 1) / 64) rows and columns; rows beyond n are not read
 // from memory but generated (row n: y - m and the diagonal entry c = 1 + |y - m|^2 / s2 > z.z, rows
 // beyond: identity), so the Gram kernel only has to fill the n x n part.
