@@ -564,6 +564,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
+  ap.add_argument('--no-accuracy', action='store_true', help='skip the device / oracle vs extended-precision truth comparison (~5 s)')
   ap.add_argument('--no-c4-full', action='store_true', help='skip the untimed 2 097 152-candidate single-GPU extra (~35 s)')
   ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong',
                   help='strong (default): the 2 097 152 candidates of BASELINE config 4 split over the GPUs, the same problem '
@@ -747,7 +748,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'], out['parity_vs_oracle'], c3 = cpu_baseline_and_parity(prob, runner.cands0, runner.U0, eng, spec, cpg)
       out.setdefault('configs', {})['C3_posterior'] = c3
-      out['accuracy_vs_truth'] = accuracy_vs_truth(eng, prob, spec)
+      if not args.no_accuracy:
+        out['accuracy_vs_truth'] = accuracy_vs_truth(eng, prob, spec)
     elif not args.no_cpu_baseline:
       out['cpu_baseline'] = None
   runner.close()
