@@ -15,8 +15,51 @@ dfh_gp_lml_batch on the device), the first candidate that ends the loop is found
 random numbers the reference would have consumed are consumed.  The chain is the reference's, draw
 for draw; what changes is two device calls per step instead of six to eight.
 """
+import ctypes
+
 import numpy as np
 import numpy.random as nr
+
+
+class _GlobalStreamPosition(object):
+  """ Un-reading the last few draws of the GLOBAL legacy stream without copying its 2.5 KB state.
+
+      nr.get_state() + nr.set_state() cost 80 us together; the shrinking loop below did both on every turn, a fifth of
+      a short optimisation run.  The MT19937 state is 624 words and a position; nr.rand() takes two words per double; as
+      long as the draws to be un-read came out of the block of words that is current, un-reading them is `pos -= 2 k`.
+      The position is reached through the bit generator's documented ctypes interface (state_address: struct
+      { uint32_t key[624]; int pos; }).  Whenever that does not apply -- another bit generator behind np.random, a
+      block boundary inside the draws -- the caller takes the state-copy route. """
+
+  def __init__(self):
+    self.pos = None
+    try:
+      bitgen = nr.mtrand._rand._bit_generator      # pylint: disable=protected-access
+      if type(bitgen).__name__ != 'MT19937':
+        return
+      addr = bitgen.ctypes.state_address
+      addr = addr.value if hasattr(addr, 'value') else int(addr)
+      self.pos = ctypes.c_int.from_address(addr + 624 * 4)
+      self._bitgen = bitgen                          # (keeps the state's memory alive)
+    except Exception:      # pylint: disable=broad-except
+      self.pos = None
+
+  def room_for(self, doubles):
+    """ True if the next `doubles` calls' worth of words all come from the current block (so they can be un-read) """
+    return self.pos is not None and 0 <= self.pos.value and self.pos.value + 2 * doubles <= 624
+
+  def unread(self, doubles):
+    self.pos.value -= 2 * doubles
+
+
+_STREAM = None
+
+
+def _stream():
+  global _STREAM      # pylint: disable=global-statement
+  if _STREAM is None:
+    _STREAM = _GlobalStreamPosition()
+  return _STREAM
 
 
 class SpeculativeSlice(object):
@@ -76,8 +119,10 @@ class SpeculativeSlice(object):
   def _shrink(self, y, q0, ql, qr):
     """ slice.py:65-76: draw uniformly from [ql, qr]; a rejected draw becomes the new edge on its
         side of q0.  Returns the accepted point, its log density and the final edges. """
+    stream = _stream()
     while True:
-      state = nr.get_state()
+      fast = stream.room_for(self.ahead_shrink)
+      state = None if fast else nr.get_state()
       draws = nr.rand(self.ahead_shrink)
       cands, edges = [], []
       l, r = ql, qr
@@ -92,8 +137,12 @@ class SpeculativeSlice(object):
       vals = self._logp(cands)
       hit = next((j for j, v in enumerate(vals) if not v < y), None)
       if hit is not None:
-        nr.set_state(state)
-        nr.rand(hit + 1)              # exactly the draws the reference's loop consumes
+        # exactly the draws the reference's loop consumes: the others go back into the stream
+        if fast:
+          stream.unread(self.ahead_shrink - (hit + 1))
+        else:
+          nr.set_state(state)
+          nr.rand(hit + 1)
         self.consumed += hit + 1
         l, r = edges[hit]
         return cands[hit], vals[hit], l, r

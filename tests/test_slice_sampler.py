@@ -24,3 +24,38 @@ def test_chain_is_the_reference_chain(name, logp, start, num, burn, seed):
     if (ahead_step, ahead_shrink) == (3, 4):
       assert sampler.batches * 2.5 < sampler.consumed                 # ... fetched in far fewer calls
       assert sampler.evaluated < 3 * sampler.consumed
+
+
+def test_unreading_draws_lands_where_the_state_copy_lands():
+  """ slice_sampler._GlobalStreamPosition: `pos -= 2 k` on the global MT19937 state == set_state(saved) + re-draw, at
+      every position of the 624-word block (the block boundary takes the state-copy route) """
+  import numpy.random as nr
+  from dragonfly_amd import slice_sampler as S
+  stream = S._stream()        # pylint: disable=protected-access
+  assert stream.pos is not None, 'np.random is not backed by the legacy MT19937 state'
+  saved = nr.get_state()
+  try:
+    fast_seen = slow_seen = 0
+    for seed in (0, 1):
+      nr.seed(seed)
+      for trial in range(1500):
+        ahead, hit = 4, trial % 4
+        s0 = nr.get_state()
+        fast = stream.room_for(ahead)
+        d = nr.rand(ahead)
+        if fast:
+          stream.unread(ahead - (hit + 1))
+          fast_seen += 1
+        else:
+          nr.set_state(s0)
+          nr.rand(hit + 1)
+          slow_seen += 1
+        a = nr.get_state()
+        nr.set_state(s0)
+        d2 = nr.rand(hit + 1)
+        b = nr.get_state()
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3:] == b[3:] and np.array_equal(d[:hit + 1], d2)
+        nr.rand(trial % 7)
+    assert fast_seen > 0 and slow_seen > 0
+  finally:
+    nr.set_state(saved)
