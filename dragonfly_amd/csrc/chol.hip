@@ -1670,11 +1670,15 @@ __global__ __launch_bounds__(256, 1) void panel_fused_kernel(FusedArgs a) {
   a.sync += (long)blockIdx.y * FUSED_SYNC_INTS;
   a.info += blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
-  // (NOT through readfirstlane here, unlike in fused_step_t: with a scalar w the diagnostics build of this kernel
-  //  flagged pivot 5 of a diagonally dominant block -- columns 0..3 of strip 0's 64 x 64 block right, NaN from
-  //  column 4 on (tools/dbg_panel.py compares the published blocks with LAPACK) -- while the product build of the
-  //  same source passed the GPU suite; tools/r4_run10.sh.  Not understood (the owner steps' ISA reads right);
-  //  the vector form is the one both builds agree on, and both builds run the whole GPU suite.)
+  // (NOT through readfirstlane here, unlike in fused_step_t.  With a scalar w the diagnostics build of this kernel
+  //  came out with columns 0..3 of strip 0's block right and NaN from column 4 on.  Root cause, read off the ISA
+  //  (docs/NOTES_r05.md section 2): a register-allocation fault of the compiler under this kernel's pressure (512 of
+  //  512 registers, 288 spilled dwords).  The spill of acc[0] was split into scratch_store_dwordx3 (dwords 0-2), an
+  //  AGPR copy a191 of dword 3 and four AGPR copies of dwords 4-7; the reload in the strip-0 leaf of the block select
+  //  below restores seven of the eight -- a191 is written once and read nowhere -- so the high half of acc[0][1],
+  //  i.e. columns 4..7 of the staged block, is whatever a195 last held.  Nothing in the source or the hardware; it
+  //  comes and goes with the allocation, so tools/isa_audit.py looks for its signature (a register written and never
+  //  read) in every function of the built library and tests/test_isa_audit.py runs that on each build.)
   const int w = tid >> 6;
   const int kq = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.x + a.g0;   // (g0: the launch may hold only the rows-below strips, see cholesky_device_impl)

@@ -1,0 +1,73 @@
+"""The built library's machine code holds no register that is written and never read.
+
+That is the signature of the compiler fault behind the "scalar wave index" build of panel_fused_kernel<true>
+(docs/NOTES_r05.md section 2, profiles/r05_scalar_w_root_cause.txt): one dword of a spilled accumulator tuple
+parked in an AGPR and never put back.  It depends on the register allocation, not on the source, so it is checked
+on what was actually built -- here on CPU, with the ROCm LLVM tools.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import isa_audit  # noqa: E402  pylint: disable=wrong-import-position
+
+LIB = os.path.join(ROOT, 'dragonfly_amd', 'libdfhip.so')
+
+# the fault as it stood in the faulty build, cut to the registers involved: the spill site, and the reload of the strip-0 leaf
+_FAULTY = '''
+v_mov_b64_e32 v[10:11], v[82:83]
+v_mov_b64_e32 v[12:13], v[84:85]
+v_mov_b64_e32 v[14:15], v[86:87]
+v_mov_b64_e32 v[16:17], v[88:89]
+v_accvgpr_write_b32 a191, v13           ;  Reload Reuse
+scratch_store_dwordx3 off, v[10:12], off offset:384 ; 12-byte Folded Spill
+v_accvgpr_write_b32 a187, v17           ;  Reload Reuse
+v_accvgpr_write_b32 a188, v16           ;  Reload Reuse
+v_accvgpr_write_b32 a189, v15           ;  Reload Reuse
+v_accvgpr_write_b32 a190, v14           ;  Reload Reuse
+scratch_load_dwordx3 a[192:194], off, off offset:384 ; 12-byte Folded Reload
+s_waitcnt vmcnt(0)
+v_accvgpr_mov_b32 a199, a187
+v_accvgpr_mov_b32 a198, a188
+v_accvgpr_mov_b32 a197, a189
+v_accvgpr_mov_b32 a196, a190
+v_accvgpr_read_b32 v0, a192
+v_accvgpr_read_b32 v1, a193
+v_accvgpr_read_b32 v2, a194
+v_accvgpr_read_b32 v3, a195
+v_accvgpr_read_b32 v4, a196
+v_accvgpr_read_b32 v5, a197
+v_accvgpr_read_b32 v6, a198
+v_accvgpr_read_b32 v7, a199
+ds_write2_b64 v20, v[0:1], v[2:3] offset1:4
+ds_write2_b64 v20, v[4:5], v[6:7] offset0:8 offset1:12
+s_endpgm
+'''.strip().splitlines()
+
+
+def test_the_fault_is_what_the_audit_finds():
+  assert isa_audit.audit_function(_FAULTY) == [(('a', 191), 1)]
+  repaired = list(_FAULTY)
+  repaired.insert(repaired.index('v_accvgpr_mov_b32 a196, a190') + 1, 'v_accvgpr_mov_b32 a195, a191')
+  assert isa_audit.audit_function(repaired) == []
+
+
+def test_operands_are_sorted_into_reads_and_writes():
+  # stores and LDS writes have no destination; a call makes written-only vector registers legitimate (arguments)
+  assert isa_audit.audit_function(['v_mov_b32_e32 v1, 0', 'global_store_dword v2, v1, s[0:1]']) == []
+  assert isa_audit.audit_function(['v_mov_b32_e32 v1, 0', 's_endpgm']) == [(('v', 1), 1)]
+  assert isa_audit.audit_function(['v_mov_b32_e32 v1, 0', 's_swappc_b64 s[30:31], s[4:5]']) == []
+  assert isa_audit.audit_function(['v_accvgpr_write_b32 a7, v1', 's_swappc_b64 s[30:31], s[4:5]']) == [(('a', 7), 1)]
+  assert isa_audit.audit_function(['v_mfma_f64_16x16x4_f64 a[0:7], v[0:1], v[2:3], a[0:7]',
+                                   'v_accvgpr_read_b32 v4, a3', 'ds_write_b32 v5, v4']) == []   # read as the addend
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(isa_audit.LLVM, 'llvm-objdump')), reason='ROCm LLVM tools not found')
+def test_built_library_has_no_written_never_read_register():
+  assert os.path.exists(LIB), 'libdfhip.so is not built (python -m dragonfly_amd.build)'
+  n, bad = isa_audit.audit(LIB)
+  assert n >= 100, 'only %d functions disassembled' % n
+  assert not bad, 'written-never-read registers (tools/isa_audit.py): %r' % (bad,)

@@ -1,0 +1,151 @@
+"""Static audit of the gfx950 machine code of libdfhip.so: registers that are written and never read.
+
+    python tools/isa_audit.py [path/to/libdfhip.so | file.s ...]      (exit status 1 if anything is flagged)
+
+Why this exists (docs/NOTES_r05.md section 2): the "scalar wave index" build of panel_fused_kernel<true> that
+produced NaN from column 4 on was a register-allocation fault of the compiler, not of the source or the
+hardware.  Under the kernel's register pressure (512 of 512) the allocator split the spill of one 8-dword
+accumulator tuple into  scratch_store_dwordx3 (dwords 0-2) + v_accvgpr_write a191 (dword 3, "Reload Reuse")
++ four more AGPR copies (dwords 4-7), and the reload put back seven of the eight pieces:  a191 is written
+once and read nowhere, dword 3 -- the high half of the second element of the block's double4, i.e. columns
+4..7 of strip 0 -- came back as whatever a195 last held.  The signature is a register with a write and no
+read anywhere in the function; a correct compilation has none (such a write would have been deleted as dead
+code), so that is what this looks for, kernel by kernel:
+  * accumulator registers (aN) in every function -- the unified register file's AGPRs are the allocator's
+    spill space on gfx90a+, they never carry call arguments;
+  * vector registers (vN) in functions that make no call (arguments of a call are written and not read).
+The check is flow-insensitive (a read anywhere counts), so it cannot prove a build right; it finds this fault.
+
+Inputs: the shipped library (the .hip_fatbin section is unbundled and disassembled with the ROCm LLVM tools)
+or assembly files from `hipcc -save-temps` (the *-hip-amdgcn-*.s ones).
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
+TARGET = 'hipv4-amdgcn-amd-amdhsa--gfx950'
+
+_REG = re.compile(r'\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]')
+# no destination register in the first operand: stores, LDS writes, scalar / control instructions, VOPC to vcc
+_NO_DEST = re.compile(r'^(global_store|scratch_store|flat_store|buffer_store|ds_write|ds_store|ds_gws|s_|v_cmpx?_\w+_e32|'
+                      r'v_nop|exp|buffer_wbl2|buffer_inv|global_atomic_(?!.*\bsc0\b))')
+_CALL = re.compile(r'^s_(swappc|setpc)_b64')
+
+
+def _regs(text):
+  out = set()
+  for m in _REG.finditer(text):
+    if m.group(1):
+      out.add((m.group(1), int(m.group(2))))
+    else:
+      out.update((m.group(3), i) for i in range(int(m.group(4)), int(m.group(5)) + 1))
+  return out
+
+
+def audit_function(lines):
+  """lines: instruction texts ('mnemonic operands') of one function. Returns sorted [(reg, n_writes)]."""
+  written, read = {}, set()
+  calls = False
+  for ins in lines:
+    ins = ins.split(';')[0].strip()
+    if not ins:
+      continue
+    mnem, _, ops = ins.partition(' ')
+    if _CALL.match(mnem):
+      calls = True
+    operands = [o.strip() for o in ops.split(',')] if ops else []
+    if not operands:
+      continue
+    if _NO_DEST.match(mnem):
+      for o in operands:
+        read |= _regs(o)
+      continue
+    for r in _regs(operands[0]):
+      written[r] = written.get(r, 0) + 1
+    for o in operands[1:]:
+      read |= _regs(o)
+  flagged = [(r, n) for r, n in written.items() if r not in read and (r[0] == 'a' or not calls)]
+  return sorted(flagged)
+
+
+def functions_of_asm(path):
+  """-save-temps assembly: yield (name, [instruction text]) per function."""
+  name, body = None, []
+  for line in open(path, errors='replace'):
+    s = line.rstrip('\n')
+    m = re.match(r'^([A-Za-z_][\w$.]*):\s*(;.*)?$', s)
+    if m and not s.startswith('.L'):
+      if name and body:
+        yield name, body
+      name, body = m.group(1), []
+      continue
+    if s.startswith('.Lfunc_end'):
+      if name and body:
+        yield name, body
+      name, body = None, []
+      continue
+    if name and s.startswith('\t') and not s.lstrip().startswith(('.', ';')):
+      body.append(s.strip())
+  if name and body:
+    yield name, body
+
+
+def functions_of_library(path):
+  """Shared library built by hipcc: yield (name, [instruction text]) for every gfx950 function in it."""
+  with tempfile.TemporaryDirectory() as tmp:
+    fat = os.path.join(tmp, 'fat.bin')
+    subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', path, fat], check=True)
+    blob = open(fat, 'rb').read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    for i, st in enumerate(starts):
+      piece = os.path.join(tmp, 'bundle%d.bin' % i)
+      with open(piece, 'wb') as f:
+        f.write(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+      co = os.path.join(tmp, 'co%d.o' % i)
+      subprocess.run([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--targets=' + TARGET,
+                      '--input=' + piece, '--output=' + co], check=True, capture_output=True)
+      dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', '--no-leading-addr', co],
+                           check=True, capture_output=True, text=True).stdout
+      name, body = None, []
+      for line in dis.splitlines():
+        m = re.match(r'^(?:[0-9a-f]+ )?<([^>]+)>:$', line.strip())
+        if m:
+          if name and body:
+            yield name, body
+          name, body = m.group(1), []
+        elif name and line.startswith(('\t', ' ')) and line.strip():
+          body.append(re.sub(r'\s*//.*$', '', line.strip()))
+      if name and body:
+        yield name, body
+
+
+def audit(path):
+  funcs = functions_of_asm(path) if path.endswith('.s') else functions_of_library(path)
+  n, bad = 0, []
+  for name, body in funcs:
+    if name.startswith('.L') or '$local' in name:
+      continue
+    n += 1
+    for reg, writes in audit_function(body):
+      bad.append((name, '%s%d' % reg, writes))
+  return n, bad
+
+
+def main(argv):
+  paths = argv or [os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'dragonfly_amd', 'libdfhip.so')]
+  rc = 0
+  for p in paths:
+    n, bad = audit(p)
+    print('%s: %d functions, %d written-never-read registers' % (os.path.relpath(p), n, len(bad)))
+    for name, reg, writes in bad:
+      print('  %s  in  %s  (%d write%s, no read)' % (reg, name, writes, '' if writes == 1 else 's'))
+      rc = 1
+  return rc
+
+
+if __name__ == '__main__':
+  sys.exit(main(sys.argv[1:]))
