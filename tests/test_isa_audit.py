@@ -71,3 +71,28 @@ def test_built_library_has_no_written_never_read_register():
   n, bad = isa_audit.audit(LIB)
   assert n >= 100, 'only %d functions disassembled' % n
   assert not bad, 'written-never-read registers (tools/isa_audit.py): %r' % (bad,)
+
+
+# scratch bytes per lane as recorded in profiles/r05_kernel_resource_usage.txt: the throughput kernels have none, the
+# latency-chain kernels of the factorisation must not get worse than what the round's timings were measured with
+_NO_SCRATCH = ('gemm_f64_kernel', 'lml_wg_kernel', 'kernmat_sym', 'kernmat_strip', 'trtri64_kernel', 'k_lml_tiny', 'k_pack_fused')
+_SCRATCH_CEILING = {'panel_fused_kernelILb1E': 388, 'panel_fused_kernelILb0E': 188, 'panel_strip_kernel': 228,
+                    'lml_team_kernel': 52, 'diag_step64_kernel': 48, 'gemm_f64_cond_kernel': 44, 'gemm_f64_la_kernel': 12}
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(isa_audit.LLVM, 'llvm-readelf')), reason='ROCm LLVM tools not found')
+def test_scratch_of_the_built_kernels_is_what_was_recorded():
+  usage = isa_audit.resource_usage(LIB)
+  assert len(usage) >= 80, 'only %d kernels found in the metadata' % len(usage)
+  seen = set()
+  for name, r in usage.items():
+    for key in _NO_SCRATCH:
+      if key in name:
+        seen.add(key)
+        assert r['scratch'] == 0, '%s: %d B/lane of scratch (was 0)' % (name, r['scratch'])
+    for key, ceiling in _SCRATCH_CEILING.items():
+      if key in name:
+        seen.add(key)
+        assert r['scratch'] <= ceiling, '%s: %d B/lane of scratch (recorded: %d)' % (name, r['scratch'], ceiling)
+  missing = (set(_NO_SCRATCH) | set(_SCRATCH_CEILING)) - seen
+  assert not missing, 'kernels not found in the library: %r' % sorted(missing)

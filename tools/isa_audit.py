@@ -16,6 +16,9 @@ code), so that is what this looks for, kernel by kernel:
   * vector registers (vN) in functions that make no call (arguments of a call are written and not read).
 The check is flow-insensitive (a read anywhere counts), so it cannot prove a build right; it finds this fault.
 
+`python tools/isa_audit.py --resources [lib]` prints every kernel's registers, scratch bytes per lane, LDS and spill counts
+from the code objects' metadata (tests/test_isa_audit.py holds the latency-chain kernels to their recorded scratch).
+
 Inputs: the shipped library (the .hip_fatbin section is unbundled and disassembled with the ROCm LLVM tools)
 or assembly files from `hipcc -save-temps` (the *-hip-amdgcn-*.s ones).
 """
@@ -94,20 +97,26 @@ def functions_of_asm(path):
     yield name, body
 
 
+def _code_objects(path, tmp):
+  """Unbundle every gfx950 code object of a hipcc-built shared library into tmp; yields their paths."""
+  fat = os.path.join(tmp, 'fat.bin')
+  subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', path, fat], check=True)
+  blob = open(fat, 'rb').read()
+  starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+  for i, st in enumerate(starts):
+    piece = os.path.join(tmp, 'bundle%d.bin' % i)
+    with open(piece, 'wb') as f:
+      f.write(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+    co = os.path.join(tmp, 'co%d.o' % i)
+    subprocess.run([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--targets=' + TARGET,
+                    '--input=' + piece, '--output=' + co], check=True, capture_output=True)
+    yield co
+
+
 def functions_of_library(path):
   """Shared library built by hipcc: yield (name, [instruction text]) for every gfx950 function in it."""
   with tempfile.TemporaryDirectory() as tmp:
-    fat = os.path.join(tmp, 'fat.bin')
-    subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', path, fat], check=True)
-    blob = open(fat, 'rb').read()
-    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
-    for i, st in enumerate(starts):
-      piece = os.path.join(tmp, 'bundle%d.bin' % i)
-      with open(piece, 'wb') as f:
-        f.write(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
-      co = os.path.join(tmp, 'co%d.o' % i)
-      subprocess.run([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--targets=' + TARGET,
-                      '--input=' + piece, '--output=' + co], check=True, capture_output=True)
+    for co in _code_objects(path, tmp):
       dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', '--no-leading-addr', co],
                            check=True, capture_output=True, text=True).stdout
       name, body = None, []
@@ -123,6 +132,50 @@ def functions_of_library(path):
         yield name, body
 
 
+_META = ('.agpr_count', '.vgpr_count', '.sgpr_count', '.private_segment_fixed_size', '.group_segment_fixed_size',
+         '.vgpr_spill_count', '.sgpr_spill_count')
+
+
+def resource_usage(path):
+  """Kernel -> {vgpr, agpr, sgpr, scratch (bytes per lane), lds, vgpr_spill, sgpr_spill}, from the code objects' metadata
+  notes (what -Rpass-analysis=kernel-resource-usage prints at compile time, read back from what was built)."""
+  out = {}
+  with tempfile.TemporaryDirectory() as tmp:
+    for co in _code_objects(path, tmp):
+      notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', co], check=True, capture_output=True, text=True).stdout
+      cur = None
+      for line in notes.splitlines():
+        m = re.match(r'^(  - |    )(\.[a-z_]+):\s+(\S+)\s*$', line)        # kernel-level keys only (arguments sit deeper)
+        if not m:
+          continue
+        if m.group(1) == '  - ':
+          cur = {}
+          out[len(out)] = cur
+        if cur is None:
+          continue
+        key, val = m.group(2), m.group(3)
+        if key in _META:
+          cur[key] = int(val)
+        elif key == '.name':
+          cur['.name'] = val
+  res = {}
+  for k in out.values():
+    if '.name' in k:
+      res[k['.name']] = {'vgpr': k.get('.vgpr_count', 0), 'agpr': k.get('.agpr_count', 0), 'sgpr': k.get('.sgpr_count', 0),
+                         'scratch': k.get('.private_segment_fixed_size', 0), 'lds': k.get('.group_segment_fixed_size', 0),
+                         'vgpr_spill': k.get('.vgpr_spill_count', 0), 'sgpr_spill': k.get('.sgpr_spill_count', 0)}
+  return res
+
+
+def demangle(names):
+  import shutil
+  filt = shutil.which('llvm-cxxfilt') or shutil.which('c++filt')
+  if not filt:
+    return list(names)
+  p = subprocess.run([filt], input='\n'.join(names), capture_output=True, text=True, check=True)
+  return p.stdout.split('\n')[:len(names)]
+
+
 def audit(path):
   funcs = functions_of_asm(path) if path.endswith('.s') else functions_of_library(path)
   n, bad = 0, []
@@ -136,6 +189,16 @@ def audit(path):
 
 
 def main(argv):
+  if argv and argv[0] == '--resources':
+    lib = argv[1] if len(argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'dragonfly_amd', 'libdfhip.so')
+    ru = resource_usage(lib)
+    names = sorted(ru, key=lambda k: (-ru[k]['scratch'], k))
+    print('%-6s %-5s %-5s %-8s %-7s %-7s %-7s  kernel' % ('vgpr', 'agpr', 'sgpr', 'scratch', 'lds', 'vspill', 'sspill'))
+    for k, d in zip(names, demangle(names)):
+      r = ru[k]
+      print('%-6d %-5d %-5d %-8d %-7d %-7d %-7d  %s' % (r['vgpr'], r['agpr'], r['sgpr'], r['scratch'], r['lds'], r['vgpr_spill'],
+                                                      r['sgpr_spill'], d.replace('(anonymous namespace)::', '')))
+    return 0
   paths = argv or [os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'dragonfly_amd', 'libdfhip.so')]
   rc = 0
   for p in paths:
