@@ -140,7 +140,7 @@ def make_batched_fitter(ref_fitter_cls):
   """ A subclass of the reference's EuclideanGPFitter whose maximum-likelihood tuners evaluate the
       tuning objective (gp_core.py:551-564) in batches on the device. """
   from .doo import pdoo_maximise_batched
-  from .engine import get_engine
+  from .engine import get_engine, KernelSpec
   from .gpb_acquisitions import _fortran_direct_available
   from .kernel import _as_2d_array
   from .oper_utils import random_maximise, random_sample_cts_dscr
@@ -177,6 +177,133 @@ def make_batched_fitter(ref_fitter_cls):
       else:
         self._batched_ml = False          # a compiled DIRECT drives the search one point at a time
 
+    def _decode_candidates(self, cts_hps_list, dscr_hps, per_cand, other_gp_params):
+      """ (specs, means, noises) of the candidates WITHOUT a call of the reference's build_gp per candidate, for the
+          usual cases -- an SE or Matern kernel over all dimensions or an additive model of such kernels, no user mean
+          function, the fitter's own build_gp / _child_build_gp -- or None (then _lml_batch takes the general route below).
+          The arithmetic is the reference's, operation for operation and on operands of the same shape (gp_core.py:
+          501-543: the tuned mean is the first entry, exp of the next is the noise variance; gp/euclidean_gp.py:796-866:
+          exp of the next is the scale, np.exp of the next `dim` entries -- one call on the slice -- the bandwidths, or
+          exp of one entry repeated; a tuned Matern nu is the first discrete entry), so the numbers are the same bits.
+          What it skips are the objects: per candidate a kernel, a mean closure, a stand-in GP and a second
+          description of the kernel, ~50 us of Python that a real run pays some 300 000 times per 60 evaluations.
+          The first calls of every fitter check candidate 0 against the general route and switch this one off for
+          good on any difference. """
+      state = getattr(self, '_amd_decode', None)
+      if state is None:
+        state = self._amd_decode = {'ok': self._decode_applies(), 'checks': 0}
+      if not state['ok']:
+        return None
+      try:
+        o = self.options
+        dim = self.dim
+        kh = self._prep_init_kernel_hyperparams(self.kernel_type)
+        if kh['dim'] != dim:
+          return None
+        mean_type, noise_type = o.mean_func_type, o.noise_var_type
+        if mean_type == 'mean':
+          mean_c = np.mean(self.Y)
+        elif mean_type == 'median':
+          mean_c = np.median(self.Y)
+        elif mean_type == 'upper_bound':
+          mean_c = np.mean(self.Y) + 3 * np.std(self.Y)
+        elif mean_type == 'const':
+          mean_c = o.mean_func_const
+        else:
+          mean_c = 0
+        if noise_type == 'label':
+          noise_c = o.noise_var_label * (self.Y.std() ** 2)
+        elif noise_type != 'tune':
+          noise_c = o.noise_var_value
+        matern = self.kernel_type == 'matern'
+        nu_fixed = kh['nu'] if matern and 'nu' in kh and not kh['nu'] < 0 else None
+        same_bw = o.use_same_bandwidth
+        additive = bool(o.use_additive_gp)
+        if additive:
+          # an additive model (gp/euclidean_gp.py:329-337, 820-826, 893-897): the groups come with the call, every
+          # group's kernel has scale 1 and its columns' bandwidths, the sum carries the scale
+          groupings = other_gp_params.add_gp_groupings
+          groups = [[int(c) for c in grp] for grp in groupings]
+          n_groups = len(groups)
+        specs, means, noises = [], [], []
+        for i, cts in enumerate(cts_hps_list):
+          dscr = list(dscr_hps[i]) if per_cand else list(dscr_hps)
+          if self.num_hps != len(cts) + len(dscr):
+            return None                                 # (the general route raises the reference's error)
+          if additive:
+            dscr = dscr[:-1]                            # the group size's index
+          if mean_type == 'tune':
+            mean = cts[0].item()
+            cts = cts[1:]
+          else:
+            mean = mean_c
+          if noise_type == 'tune':
+            noise = np.exp(cts[0])
+            cts = cts[1:]
+          else:
+            noise = noise_c
+          scale = np.exp(cts[0])
+          cts = cts[1:]
+          if same_bw:
+            bws = [np.exp(cts[0])] * dim
+            cts = cts[1:]
+          else:
+            bws = np.exp(cts[0:dim])
+            cts = cts[dim:]
+          if len(cts) != 0:
+            return None
+          if matern:
+            if nu_fixed is None:
+              nu = dscr[0]
+              dscr = dscr[1:]
+            else:
+              nu = nu_fixed
+            if nu % 1 != 0.5:
+              return None
+          if len(dscr) != 0 or len(bws) != dim:
+            return None
+          if additive:
+            specs.append(KernelSpec('additive', dim, scale, groups=groups, sub_kinds=['matern' if matern else 'se'] * n_groups,
+                                    sub_scales=[1.0] * n_groups, sub_nus=[nu if matern else 0.0] * n_groups,
+                                    sub_bandwidths=[np.ravel(np.asarray([bws[idx] for idx in grp], dtype=float))
+                                                    for grp in groupings]))
+          else:
+            specs.append(KernelSpec('matern', dim, scale, bws, nu=nu) if matern else KernelSpec('se', dim, scale, bws))
+          means.append(float(mean))
+          noises.append(float(noise))
+      except Exception:             # pylint: disable=broad-except
+        return None                 # whatever it was, the general route meets it the way the reference does
+      if state['checks'] < 3:
+        state['checks'] += 1
+        want = self._build_one(cts_hps_list[0], list(dscr_hps[0]) if per_cand else list(dscr_hps), other_gp_params)
+        got = (specs[0].signature(), means[0], noises[0])
+        if want is None or want != got:
+          state['ok'] = False
+          return None
+      return specs, means, noises
+
+    def _decode_applies(self):
+      import dragonfly.gp.kernel as _ref_kernel
+      from . import kernel as _kernel
+      o = self.options
+      return (type(self)._child_build_gp is ref_fitter_cls._child_build_gp and type(self).build_gp is ref_fitter_cls.build_gp
+              and self.kernel_type in ('se', 'matern') and getattr(o, 'mean_func', None) is None
+              and _ref_kernel.SEKernel is _kernel.SEKernel and _ref_kernel.MaternKernel is _kernel.MaternKernel
+              and _ref_kernel.AdditiveKernel is _kernel.AdditiveKernel)
+
+    def _build_one(self, cts, dscr, other_gp_params=None):
+      """ (kernel signature, mean, noise) of one candidate by the general route: the reference's build_gp. """
+      import dragonfly.gp.euclidean_gp as _ref_egp
+      saved_cls = _ref_egp.EuclideanGP
+      _ref_egp.EuclideanGP = _KernelMeanNoise
+      try:
+        gp = self.build_gp(cts, dscr, other_gp_params=other_gp_params, build_posterior=False)
+      finally:
+        _ref_egp.EuclideanGP = saved_cls
+      if gp.host_kernel:
+        return None
+      return (gp.kernel.to_spec(self.dim).signature(), float(gp.mean_func([np.zeros(self.dim)])[0]), float(gp.noise_var))
+
     def _lml_batch(self, cts_hps_list, dscr_hps, other_gp_params=None):
       """ Log marginal likelihoods of a list of candidates.  Each candidate goes through the
           reference's own build_gp (gp_core.py:501-543) without building a posterior -- that gives
@@ -186,6 +313,12 @@ def make_batched_fitter(ref_fitter_cls):
       if len(cts_hps_list) == 0:
         return np.zeros((0,))
       user_mean = getattr(self.options, 'mean_func', None) is not None
+      decoded = self._decode_candidates(cts_hps_list, dscr_hps, per_cand, other_gp_params)
+      if decoded is not None:
+        specs, means, noises = decoded
+        if getattr(self, '_X_dev', None) is None:
+          self._X_dev = get_engine().to_device(_as_2d_array(self.X))
+        return get_engine().gp_lml_batch(specs, self._X_dev, np.asarray(self.Y, dtype=np.float64), means, noises)
       specs, means, noises = [], [], []
       probe = [np.zeros(self.dim)]
       # build_gp ends in `EuclideanGP(self.X, self.Y, kernel, mean_func, noise_var, build_posterior=False)`, a module
