@@ -195,30 +195,36 @@ def make_batched_fitter(ref_fitter_cls):
       if not state['ok']:
         return None
       try:
-        o = self.options
         dim = self.dim
-        kh = self._prep_init_kernel_hyperparams(self.kernel_type)
-        if kh['dim'] != dim:
-          return None
-        mean_type, noise_type = o.mean_func_type, o.noise_var_type
-        if mean_type == 'mean':
-          mean_c = np.mean(self.Y)
-        elif mean_type == 'median':
-          mean_c = np.median(self.Y)
-        elif mean_type == 'upper_bound':
-          mean_c = np.mean(self.Y) + 3 * np.std(self.Y)
-        elif mean_type == 'const':
-          mean_c = o.mean_func_const
-        else:
-          mean_c = 0
-        if noise_type == 'label':
-          noise_c = o.noise_var_label * (self.Y.std() ** 2)
-        elif noise_type != 'tune':
-          noise_c = o.noise_var_value
-        matern = self.kernel_type == 'matern'
-        nu_fixed = kh['nu'] if matern and 'nu' in kh and not kh['nu'] < 0 else None
-        same_bw = o.use_same_bandwidth
-        additive = bool(o.use_additive_gp)
+        # what does not depend on the candidate is worked out once per fitter (and set of labels): the option fields,
+        # the kernel's fixed hyper-parameters, the constant means gp_core.py:516-523 computes from the labels
+        plan = state.get('plan')
+        if plan is None or plan[0] is not self.Y or plan[1] != len(self.Y):
+          o = self.options
+          kh = self._prep_init_kernel_hyperparams(self.kernel_type)
+          if kh['dim'] != dim:
+            return None
+          mean_type, noise_type = o.mean_func_type, o.noise_var_type
+          if mean_type == 'mean':
+            mean_c = np.mean(self.Y)
+          elif mean_type == 'median':
+            mean_c = np.median(self.Y)
+          elif mean_type == 'upper_bound':
+            mean_c = np.mean(self.Y) + 3 * np.std(self.Y)
+          elif mean_type == 'const':
+            mean_c = o.mean_func_const
+          else:
+            mean_c = 0
+          noise_c = None
+          if noise_type == 'label':
+            noise_c = o.noise_var_label * (self.Y.std() ** 2)
+          elif noise_type != 'tune':
+            noise_c = o.noise_var_value
+          matern = self.kernel_type == 'matern'
+          nu_fixed = kh['nu'] if matern and 'nu' in kh and not kh['nu'] < 0 else None
+          plan = state['plan'] = (self.Y, len(self.Y), mean_type, noise_type, mean_c, noise_c, matern, nu_fixed,
+                                  o.use_same_bandwidth, bool(o.use_additive_gp))
+        _, _, mean_type, noise_type, mean_c, noise_c, matern, nu_fixed, same_bw, additive = plan
         if additive:
           # an additive model (gp/euclidean_gp.py:329-337, 820-826, 893-897): the groups come with the call, every
           # group's kernel has scale 1 and its columns' bandwidths, the sum carries the scale
@@ -318,7 +324,7 @@ def make_batched_fitter(ref_fitter_cls):
         specs, means, noises = decoded
         if getattr(self, '_X_dev', None) is None:
           self._X_dev = get_engine().to_device(_as_2d_array(self.X))
-        return get_engine().gp_lml_batch(specs, self._X_dev, np.asarray(self.Y, dtype=np.float64), means, noises)
+        return get_engine().gp_lml_batch(specs, self._X_dev, self._labels_array(), means, noises)
       specs, means, noises = [], [], []
       probe = [np.zeros(self.dim)]
       # build_gp ends in `EuclideanGP(self.X, self.Y, kernel, mean_func, noise_var, build_posterior=False)`, a module
@@ -347,7 +353,14 @@ def make_batched_fitter(ref_fitter_cls):
                          for j, c in enumerate(cts_hps_list)])
       if getattr(self, '_X_dev', None) is None:
         self._X_dev = get_engine().to_device(_as_2d_array(self.X))
-      return get_engine().gp_lml_batch(specs, self._X_dev, np.asarray(self.Y, dtype=np.float64), means, noises)
+      return get_engine().gp_lml_batch(specs, self._X_dev, self._labels_array(), means, noises)
+
+    def _labels_array(self):
+      """ self.Y as the float64 array every batch call hands to the engine (converted once per list of labels) """
+      cached = getattr(self, '_amd_labels', None)
+      if cached is None or cached[0] is not self.Y or cached[1] != len(self.Y):
+        cached = self._amd_labels = (self.Y, len(self.Y), np.asarray(self.Y, dtype=np.float64))
+      return cached[2]
 
     # -- posterior sampling (gp_core.py:476-487, 592-726) -------------------------------------------
     def _set_up_post_sampling_hp_tune(self):
@@ -379,8 +392,15 @@ def make_batched_fitter(ref_fitter_cls):
         return prior.logp(value)
       # only the coordinate being sampled changes between the xs: the other priors' terms are evaluated once, and
       # added in index order per x exactly as the reference's loop adds them (same partial sums, same bits)
+      # (and the sampler asks several times per step of a coordinate -- stepping out, shrinking -- with the others unchanged)
       cur = self.curr_hp
-      terms = [None if i == cur else prior_term(i, base[i]) for i in range(len(self.hp_priors))]
+      key = (cur, base.tobytes())
+      cached = getattr(self, '_amd_prior_terms', None)
+      if cached is not None and cached[0] == key and cached[1] is self.hp_priors:
+        terms = cached[2]
+      else:
+        terms = [None if i == cur else prior_term(i, base[i]) for i in range(len(self.hp_priors))]
+        self._amd_prior_terms = (key, self.hp_priors, terms)
       for k, x in enumerate(xs):
         hps = base.copy()
         hps[cur] = x
