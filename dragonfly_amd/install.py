@@ -50,6 +50,8 @@ edited):
 A compiled Fortran DIRECT, when present, keeps working: it calls gp.eval per point, which now
 runs on the device, through `external_maximise_with_method`.
 """
+import os
+
 import numpy as np
 
 
@@ -120,6 +122,10 @@ def _euclidean_dispatch(ours, theirs):
   acquisition.__wrapped__ = ours
   acquisition.reference_callable = theirs
   return acquisition
+
+
+# DFH_SLICE_MERGE=0: the speculative slice sampler's stepping-out and shrinking candidates in separate density calls again
+_SLICE_MERGE_FIRST = os.environ.get('DFH_SLICE_MERGE', '1') != '0'
 
 
 class _KernelMeanNoise(object):
@@ -374,7 +380,7 @@ def make_batched_fitter(ref_fitter_cls):
     def _speculative_slice(self, model, init_sample, num_samples, burn):
       # pylint: disable=unused-argument
       from .slice_sampler import SpeculativeSlice
-      return SpeculativeSlice(self._post_logp_batch).sample(init_sample, num_samples, burn)
+      return SpeculativeSlice(self._post_logp_batch, merge_first=_SLICE_MERGE_FIRST).sample(init_sample, num_samples, burn)
 
     def _post_logp_batch(self, xs):
       """ The log density `_logp` of gp_core.py:597-622 -- log priors of all hyper-parameters, summed

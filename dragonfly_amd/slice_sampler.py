@@ -14,6 +14,12 @@ rewound.  So each loop's next few candidates are evaluated in ONE batched densit
 dfh_gp_lml_batch on the device), the first candidate that ends the loop is found, and exactly the
 random numbers the reference would have consumed are consumed.  The chain is the reference's, draw
 for draw; what changes is two device calls per step instead of six to eight.
+
+And often ONE: the shrinking loop's first candidates depend on the stepping-out only through the edges it ends with,
+and with the width tuned to the slices (slice.py:84-87) the edges mostly stay where they start.  The first batch of an
+update therefore carries both loops' candidates -- the shrinking ones drawn under the guess that neither edge moves.
+If the guess holds, the update may be over with that one call; if not, their draws go back into the stream, their
+densities are dropped, and the update goes on as before (the stepping-out values of that batch are used either way).
 """
 import ctypes
 
@@ -65,10 +71,13 @@ def _stream():
 class SpeculativeSlice(object):
   """ slice.py:15-36 for a univariate target given as a batch log-density:
       logp_batch([x_0, ..., x_k]) -> [log p(x_0), ..., log p(x_k)].  w, tune as in the reference;
-      `ahead_step` / `ahead_shrink`: how many candidates of each loop go into one batch. """
+      `ahead_step` / `ahead_shrink`: how many candidates of each loop go into one batch; `merge_first`: the first batch
+      of an update holds both loops' candidates (see the module text). """
 
-  def __init__(self, logp_batch, w=1., tune=True, ahead_step=3, ahead_shrink=4):
+  def __init__(self, logp_batch, w=1., tune=True, ahead_step=3, ahead_shrink=4, merge_first=True):
     self.logp_batch = logp_batch
+    self.merge_first = bool(merge_first)
+    self.merged_done = 0      # updates whose stepping-out AND shrinking were settled by their first batch
     self.w = w
     self.tune = tune
     self.n_tunes = 0.
@@ -83,9 +92,8 @@ class SpeculativeSlice(object):
     self.evaluated += len(xs)
     return np.asarray(self.logp_batch(list(xs)), dtype=np.float64).ravel()
 
-  def _step_out(self, y, ql, qr, w):
+  def _step_out(self, y, ql, qr, w, need_l=True, need_r=True):
     """ slice.py:52-63: move each edge outwards by w until the density there is below the level. """
-    need_l, need_r = True, True
     while need_l or need_r:
       lefts, rights = [], []
       edge = ql
@@ -116,38 +124,84 @@ class SpeculativeSlice(object):
           qr = rights[-1] + w
     return ql, qr
 
+  def _shrink_candidates(self, q0, ql, qr):
+    """ The next ahead_shrink candidates of the shrinking loop, each drawn from the interval its predecessors'
+        rejection would leave: (fast, saved state, candidates, the edges each was drawn from, the edges after all). """
+    stream = _stream()
+    fast = stream.room_for(self.ahead_shrink)
+    state = None if fast else nr.get_state()
+    draws = nr.rand(self.ahead_shrink)
+    cands, edges = [], []
+    l, r = ql, qr
+    for u in draws:
+      q = (r - l) * u + l
+      cands.append(q)
+      edges.append((l, r))
+      if q > q0:
+        r = q
+      elif q < q0:
+        l = q
+    return fast, state, cands, edges, (l, r)
+
+  def _give_back(self, fast, state, keep):
+    """ Exactly `keep` of the ahead_shrink draws just read are the reference's: the others go back into the stream. """
+    if fast:
+      _stream().unread(self.ahead_shrink - keep)
+    else:
+      nr.set_state(state)
+      if keep:
+        nr.rand(keep)
+
   def _shrink(self, y, q0, ql, qr):
     """ slice.py:65-76: draw uniformly from [ql, qr]; a rejected draw becomes the new edge on its
         side of q0.  Returns the accepted point, its log density and the final edges. """
-    stream = _stream()
     while True:
-      fast = stream.room_for(self.ahead_shrink)
-      state = None if fast else nr.get_state()
-      draws = nr.rand(self.ahead_shrink)
-      cands, edges = [], []
-      l, r = ql, qr
-      for u in draws:
-        q = (r - l) * u + l
-        cands.append(q)
-        edges.append((l, r))
-        if q > q0:
-          r = q
-        elif q < q0:
-          l = q
+      fast, state, cands, edges, after = self._shrink_candidates(q0, ql, qr)
       vals = self._logp(cands)
       hit = next((j for j, v in enumerate(vals) if not v < y), None)
       if hit is not None:
-        # exactly the draws the reference's loop consumes: the others go back into the stream
-        if fast:
-          stream.unread(self.ahead_shrink - (hit + 1))
-        else:
-          nr.set_state(state)
-          nr.rand(hit + 1)
+        self._give_back(fast, state, hit + 1)
         self.consumed += hit + 1
         l, r = edges[hit]
         return cands[hit], vals[hit], l, r
       self.consumed += len(cands)
-      ql, qr = l, r                   # all rejected: the stream has advanced by ahead_shrink draws
+      ql, qr = after                  # all rejected: the stream has advanced by ahead_shrink draws
+
+  def _first_batch(self, y, q0, ql, qr, w):
+    """ Both loops' first candidates in one density call (see the module text).  Returns what _shrink returns. """
+    lefts, rights = [], []
+    edge = ql
+    for _ in range(self.ahead_step):
+      lefts.append(edge)
+      edge = edge - w
+    edge = qr
+    for _ in range(self.ahead_step):
+      rights.append(edge)
+      edge = edge + w
+    fast, state, cands, edges, after = self._shrink_candidates(q0, ql, qr)      # guess: the edges stay
+    vals = self._logp(lefts + rights + cands)
+    lv, rv, sv = vals[:len(lefts)], vals[len(lefts):len(lefts) + len(rights)], vals[len(lefts) + len(rights):]
+    stop_l = next((k for k, v in enumerate(lv) if not y < v), None)
+    stop_r = next((k for k, v in enumerate(rv) if not y < v), None)
+    self.consumed += (stop_l + 1) if stop_l is not None else len(lefts)
+    self.consumed += (stop_r + 1) if stop_r is not None else len(rights)
+    if stop_l == 0 and stop_r == 0:
+      hit = next((j for j, v in enumerate(sv) if not v < y), None)
+      if hit is not None:
+        self._give_back(fast, state, hit + 1)
+        self.consumed += hit + 1
+        self.merged_done += 1
+        l, r = edges[hit]
+        return cands[hit], sv[hit], l, r
+      self.consumed += len(cands)
+      return self._shrink(y, q0, after[0], after[1])
+    # an edge moves: the shrinking candidates were drawn from the wrong interval -- their draws go back, all of them
+    self._give_back(fast, state, 0)
+    need_l, need_r = stop_l is None, stop_r is None
+    ql = lefts[stop_l] if stop_l is not None else lefts[-1] - w
+    qr = rights[stop_r] if stop_r is not None else rights[-1] + w
+    ql, qr = self._step_out(y, ql, qr, w, need_l, need_r)
+    return self._shrink(y, q0, ql, qr)
 
   def _sample(self, q0):
     """ One slice-sampling update of the scalar q0 (slice.py:38-89 with len(q0) == 1). """
@@ -162,8 +216,11 @@ class SpeculativeSlice(object):
     y = lp0 - nr.standard_exponential()
     ql = q0 - nr.uniform(0, w)
     qr = q0 + w
-    ql, qr = self._step_out(y, ql, qr, w)
-    q, lp, ql, qr = self._shrink(y, q0, ql, qr)
+    if self.merge_first:
+      q, lp, ql, qr = self._first_batch(y, q0, ql, qr, w)
+    else:
+      ql, qr = self._step_out(y, ql, qr, w)
+      q, lp, ql, qr = self._shrink(y, q0, ql, qr)
     if self.tune:
       self.w = w * (self.n_tunes / (self.n_tunes + 1)) + (qr - ql) / (self.n_tunes + 1)
       self.n_tunes += 1

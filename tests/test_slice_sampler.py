@@ -24,6 +24,13 @@ def test_chain_is_the_reference_chain(name, logp, start, num, burn, seed):
     if (ahead_step, ahead_shrink) == (3, 4):
       assert sampler.batches * 2.5 < sampler.consumed                 # ... fetched in far fewer calls
       assert sampler.evaluated < 3 * sampler.consumed
+      # the stepping-out and the shrinking share their first batch: the same chain with them apart, in more calls
+      apart = SpeculativeSlice(lambda xs: [logp(x) for x in xs], ahead_step=ahead_step, ahead_shrink=ahead_shrink,
+                               merge_first=False)
+      np.random.seed(seed)
+      assert np.array_equal(apart.sample(start, num, burn), chain) and np.random.random() == float(g[name + '_next_random'])
+      assert apart.consumed == sampler.consumed and apart.merged_done == 0
+      assert sampler.merged_done > 0 and sampler.batches < apart.batches
 
 
 def test_unreading_draws_lands_where_the_state_copy_lands():
