@@ -71,3 +71,27 @@ def test_library_exports_nothing_beyond_the_header():
   out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
   exported = sorted(set(re.findall(r'\bT (dfh_[a-z0-9_]+)\b', out)))
   assert exported == declared_functions()
+
+
+def test_array_addresses_go_to_void_pointer_parameters_only():
+  """ engine._ptr hands a NumPy array to the C-ABI as its address, an integer (no ctypes view per argument): ctypes takes
+      an integer for a c_void_p parameter and for no typed pointer, so every _ptr(...) argument of every call of the
+      library in the package must land on a c_void_p of the signature table -- and the array must be a named local of the
+      calling function, alive across the call (an integer keeps nothing alive) """
+  import ast
+  pkg = os.path.join(ROOT, 'dragonfly_amd')
+  seen = 0
+  for fn in sorted(os.listdir(pkg)):
+    if not fn.endswith('.py'):
+      continue
+    tree = ast.parse(open(os.path.join(pkg, fn)).read())
+    for node in ast.walk(tree):
+      if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in _lib.SIGNATURES:
+        _, argtypes = _lib.SIGNATURES[node.func.attr]
+        for i, arg in enumerate(node.args):
+          if isinstance(arg, ast.Call) and isinstance(arg.func, ast.Name) and arg.func.id in ('_ptr', '_engine_ptr'):
+            seen += 1
+            assert argtypes[i] is ctypes.c_void_p, '%s:%d %s argument %d' % (fn, node.lineno, node.func.attr, i)
+            assert len(arg.args) == 1 and isinstance(arg.args[0], ast.Name), \
+                '%s:%d %s argument %d: a temporary would be freed before the call' % (fn, node.lineno, node.func.attr, i)
+  assert seen >= 60
