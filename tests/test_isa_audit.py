@@ -55,6 +55,14 @@ def test_the_fault_is_what_the_audit_finds():
   assert isa_audit.audit_function(repaired) == []
 
 
+def test_a_reload_of_bytes_nobody_spilled_is_found_too():
+  spill = ['scratch_store_dwordx3 off, v[10:12], off offset:384', 'scratch_store_dwordx4 off, v[98:101], off offset:352']
+  assert isa_audit.audit_scratch(spill + ['scratch_load_dwordx3 a[192:194], off, off offset:384']) == []
+  assert [o for o, _ in isa_audit.audit_scratch(spill + ['scratch_load_dwordx4 a[192:195], off, off offset:384'])] == [384]
+  assert isa_audit.audit_scratch(['scratch_load_dword v1, v2, off offset:16']) == []          # a local array: not a spill slot
+  assert isa_audit.audit_scratch(['scratch_store_dword off, v1, off', 'scratch_load_dword v3, off, off']) == []
+
+
 def test_operands_are_sorted_into_reads_and_writes():
   # stores and LDS writes have no destination; a call makes written-only vector registers legitimate (arguments)
   assert isa_audit.audit_function(['v_mov_b32_e32 v1, 0', 'global_store_dword v2, v1, s[0:1]']) == []

@@ -14,7 +14,9 @@ code), so that is what this looks for, kernel by kernel:
   * accumulator registers (aN) in every function -- the unified register file's AGPRs are the allocator's
     spill space on gfx90a+, they never carry call arguments;
   * vector registers (vN) in functions that make no call (arguments of a call are written and not read).
-The check is flow-insensitive (a read anywhere counts), so it cannot prove a build right; it finds this fault.
+and, for the variant of the fault that parks the piece in scratch, fixed-offset scratch reloads of bytes that no
+fixed-offset scratch store of the function writes (audit_scratch).
+The checks are flow-insensitive (a read / a store anywhere counts), so they cannot prove a build right; they find this fault.
 
 `python tools/isa_audit.py --resources [lib]` prints every kernel's registers, scratch bytes per lane, LDS and spill counts
 from the code objects' metadata (tests/test_isa_audit.py holds the latency-chain kernels to their recorded scratch).
@@ -73,6 +75,33 @@ def audit_function(lines):
       read |= _regs(o)
   flagged = [(r, n) for r, n in written.items() if r not in read and (r[0] == 'a' or not calls)]
   return sorted(flagged)
+
+
+_SCRATCH = re.compile(r'^scratch_(load|store)_(dword(?:x(\d))?|[su]?byte|[su]?short)\w*\s+(.*)$')
+
+
+def audit_scratch(lines):
+  """ The same fault with the lost piece parked in scratch instead of an AGPR would read as a reload of bytes no spill
+      wrote: scratch_load from a fixed offset (`off, off offset:K`) covering bytes that no fixed-offset scratch_store
+      of the function writes.  Register-addressed scratch (real local arrays) is left alone.  Returns [(offset, text)]. """
+  stored, loads = set(), []
+  for ins in lines:
+    ins = ins.split(';')[0].strip()
+    m = _SCRATCH.match(ins)
+    if not m:
+      continue
+    nbytes = 4 * int(m.group(3) or 1) if m.group(2).startswith('dword') else (1 if 'byte' in m.group(2) else 2)
+    ops = [re.sub(r'\s*offset:.*', '', o.strip()) for o in m.group(4).split(',')]
+    offm = re.search(r'offset:(-?\d+)', ins)
+    off = int(offm.group(1)) if offm else 0
+    addr = (ops[0:1] + ops[2:3]) if m.group(1) == 'store' else ops[1:3]
+    if any(o != 'off' for o in addr):
+      continue
+    if m.group(1) == 'store':
+      stored.update(range(off, off + nbytes))
+    else:
+      loads.append((off, nbytes, ins))
+  return [(off, ins) for off, nbytes, ins in loads if any(b not in stored for b in range(off, off + nbytes))]
 
 
 def functions_of_asm(path):
@@ -185,6 +214,8 @@ def audit(path):
     n += 1
     for reg, writes in audit_function(body):
       bad.append((name, '%s%d' % reg, writes))
+    for off, ins in audit_scratch(body):
+      bad.append((name, 'scratch+%d (%s)' % (off, ins), 0))
   return n, bad
 
 
@@ -203,9 +234,9 @@ def main(argv):
   rc = 0
   for p in paths:
     n, bad = audit(p)
-    print('%s: %d functions, %d written-never-read registers' % (os.path.relpath(p), n, len(bad)))
+    print('%s: %d functions, %d findings (registers written and never read, scratch reloads never spilled)' % (os.path.relpath(p), n, len(bad)))
     for name, reg, writes in bad:
-      print('  %s  in  %s  (%d write%s, no read)' % (reg, name, writes, '' if writes == 1 else 's'))
+      print('  %s  in  %s  (%s)' % (reg, name, 'reloaded, never spilled' if writes == 0 else '%d write%s, no read' % (writes, '' if writes == 1 else 's')))
       rc = 1
   return rc
 
