@@ -66,3 +66,34 @@ def test_unreading_draws_lands_where_the_state_copy_lands():
     assert fast_seen > 0 and slow_seen > 0
   finally:
     nr.set_state(saved)
+
+
+def test_merged_first_batch_is_the_same_chain_over_many_streams():
+  """ merge_first against the loops apart: the same chain and the same stream position for every seed, target and
+      look-ahead -- including the updates whose speculative draws cross the 624-word block of the MT19937 state (the
+      state-copy route of giving draws back) and targets with regions of zero density """
+  from dragonfly_amd.slice_sampler import SpeculativeSlice
+  targets = [
+    lambda x: -0.5 * x * x,
+    lambda x: float(np.logaddexp(-0.5 * (x + 3.0) ** 2, -2.0 * (x - 2.0) ** 2)),
+    lambda x: -abs(x) ** 0.7 if -4.0 < x < 6.0 else -np.inf,
+    lambda x: -50.0 * (x - 0.3) ** 2,                       # much narrower than the initial width: long shrinking
+    lambda x: -0.001 * x * x,                               # much wider: long stepping-out
+  ]
+  merged_total = 0
+  for t, logp in enumerate(targets):
+    for seed in range(12):
+      for ahead in ((3, 4), (1, 2), (5, 7)):
+        chains, ends, stats = [], [], []
+        for merge in (True, False):
+          sampler = SpeculativeSlice(lambda xs, f=logp: [f(x) for x in xs], ahead_step=ahead[0], ahead_shrink=ahead[1],
+                                     merge_first=merge)
+          np.random.seed(1000 * t + seed)
+          np.random.rand(seed * 37 % 311)                   # start at different places of the state's block
+          chains.append(sampler.sample(0.1, 60, 25))
+          ends.append(np.random.random())
+          stats.append((sampler.consumed, sampler.batches, sampler.merged_done))
+        assert np.array_equal(chains[0], chains[1]) and ends[0] == ends[1]
+        assert stats[0][0] == stats[1][0] and stats[0][1] <= stats[1][1] and stats[1][2] == 0
+        merged_total += stats[0][2]
+  assert merged_total > 1000
