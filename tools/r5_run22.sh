@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 5: the one-product-per-block row solve (docs/NOTES_r05.md section 8): BASELINE configs 2 and 5 with and without
-# it (bench.other_configs, one process each), then the parity files whose sizes reach it
+# it (bench.other_configs, one process each), then the parity files whose sizes reach it.  The experiment is not in the
+# tree: `git apply docs/experiments/r05_trsm_one_product.patch && python -m dragonfly_amd.build` first (DFH_TRSM_FUSED
+# does nothing without it).
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/r5u; mkdir -p $O
 for f in 1 0; do

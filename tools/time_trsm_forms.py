@@ -1,5 +1,6 @@
 """Config 2's candidate stage (n = 4096, 65536 candidates) with the GEMM launches timed one by one (dfh_ctx_gemm_profile):
-run once with DFH_TRSM_FUSED=1 and once with 0 to see where the row solve's time goes in either form."""
+run once with DFH_TRSM_FUSED=1 and once with 0 to see where the row solve's time goes in either form (the one-product
+form is docs/experiments/r05_trsm_one_product.patch; without it both runs time the two-launch form)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
