@@ -135,6 +135,13 @@ def hp_tuning(eng):
       _median_ms(lambda: eng.gp_lml_batch(specs[:small], Xd, Y, means[:small], noises[:small]), eng.sync, reps=2, warm=1)
       row['ms_batch_of_%d' % small] = round(_median_ms(lambda: eng.gp_lml_batch(specs[:small], Xd, Y, means[:small], noises[:small]),
                                                        eng.sync, reps=5, warm=0), 4)
+    if n == 50:
+      # the slice sampler's call (dragonfly/gp/gp_core.py:551-574 under sampling/slice.py): ONE candidate per call
+      _median_ms(lambda: eng.gp_lml_batch(specs[:1], Xd, Y, means[:1], noises[:1]), eng.sync, reps=20, warm=5)
+      t0 = time.perf_counter()
+      for c in range(1000):
+        eng.gp_lml_batch(specs[c:c + 1], Xd, Y, means[c:c + 1], noises[c:c + 1])
+      row['ms_one_candidate'] = round((time.perf_counter() - t0), 5)      # s per 1000 calls == ms per call
     kc = 24 if n <= 1000 else 6
     t0 = time.perf_counter()
     ref = [O.GPOracle(X, Y, O.KernelSpec('se', d, scales[c], bws[c]), means[c], noises[c]).lml() for c in range(kc)]
@@ -144,9 +151,66 @@ def hp_tuning(eng):
     row['lml_parity'] = bool(row['lml_rel_max'] <= 1e-10)
     out['n%d' % n] = row
     Xd.free()
+  # n = 2000: 512 candidates in one call (the one-workgroup-per-candidate objective at its largest size class)
+  try:
+    n, d, nb = 2000, 6, 512
+    rs = np.random.RandomState(n)
+    X = rs.rand(n, d)
+    Y = np.sin(4 * X.sum(axis=1)) + 0.1 * rs.randn(n)
+    yv = float(Y.var())
+    specs = [KernelSpec('se', d, yv * np.exp(rs.randn()), np.exp(rs.uniform(np.log(0.3), np.log(3.0), size=d))) for _ in range(nb)]
+    means = list(rs.randn(nb) * 0.1)
+    noises = list(yv * np.exp(rs.uniform(np.log(0.005), np.log(0.2), size=nb)))
+    Xd = eng.to_device(X)
+    eng.gp_lml_batch(specs[:8], Xd, Y, means[:8], noises[:8])
+    eng.sync()
+    t0 = time.perf_counter()
+    lml = eng.gp_lml_batch(specs, Xd, Y, means, noises)
+    eng.sync()
+    us = (time.perf_counter() - t0) * 1e6 / nb
+    ref = [O.GPOracle(X, Y, O.KernelSpec('se', d, specs[c].scale, specs[c].bandwidths), means[c], noises[c]).lml() for c in range(3)]
+    out['n2000'] = {'us_each_of_512': round(us, 2), 'lml_rel_max': max(abs(lml[c] - ref[c]) / abs(ref[c]) for c in range(3))}
+    Xd.free()
+  except Exception as e:      # pylint: disable=broad-except
+    out['n2000'] = {'error': repr(e)}
   out['what'] = ('log marginal likelihood of 500 / 10000 hyper-parameter candidates per call sequence (SE-ARD d = 3 / 6), '
                  'dfh_gp_lml_batch; ms_batch_of_64 / _8: one call with that many candidates (wall, host side included); '
                  'oracle = one NumPy fit per candidate (sample of 24 / 6)')
+  return out
+
+
+def chol_sizes(eng):
+  """ The fit's sections at the sizes between the configurations (SE-ARD, d = 8): kernel matrix, factorisation, the two
+      solves + lml -- general_utils.py:178, gp_core.py:161-163, 222-227. """
+  from dragonfly_amd.engine import KernelSpec
+  out = {}
+  for n in (4096, 8192):
+    rs = np.random.RandomState(n)
+    d = 8
+    X = rs.rand(n, d)
+    Y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(n)
+    spec = KernelSpec('se', d, float(Y.var()), 0.2 * np.sqrt(d) * np.ones(d))
+    noise = float(Y.var() / 20)
+    Xd, yd = eng.to_device(X), eng.to_device(Y - float(np.median(Y)))
+
+    def fit():
+      eng.gp_fit(spec, Xd, yd, noise).free()
+    for _ in range(2):
+      fit()
+    eng.sync()
+    best = None
+    for _ in range(5):
+      eng.timings(True)
+      fit()
+      eng.sync()
+      s = eng.timings(False)
+      if best is None or s['chol'] < best['chol']:
+        best = s
+    out['n%d' % n] = {'ms': round(best['chol'], 4), 'solve_ms': round(best['solve'], 4), 'kernmat_ms': round(best['kernmat'], 4),
+                      'frac_of_fp64_mfma_peak': round(float(n) ** 3 / 3 / (best['chol'] * 1e-3) / 1e12 / 78.6, 4)}
+    Xd.free()
+    yd.free()
+  out['what'] = 'fit sections (section timers on: host-synchronised), best of 5, SE-ARD d = 8'
   return out
 
 
@@ -362,6 +426,7 @@ def bo_wallclock():
 def run_all(eng, prob, spec, include_c4_full=True):
   out = {}
   for name, fn in (('C1', lambda: config1(eng)), ('hp_tuning', lambda: hp_tuning(eng)), ('append', lambda: append(eng)),
+                   ('chol_sizes', lambda: chol_sizes(eng)),
                    ('pdoo', lambda: pdoo(eng)), ('hallucinated_batch', lambda: hallucinated_batch(eng)),
                    ('bo_wallclock', bo_wallclock)):
     try:

@@ -22,7 +22,8 @@ edited):
                Opt-in because the reference class cannot be reached once the name is rebound (its
                __init__ calls super(EuclideanMFGP, self)).
   S2'' CP GP   (only with install(cartesian_product=True)) dragonfly.gp.cartesian_product_gp.CPGP ->
-               dragonfly_amd.cartesian_product_gp.CPGP: the kernel (the reference's
+               dragonfly_amd.cartesian_product_gp.device_cpgp_class(...): the reference's own class body over the
+               device GP; the kernel (the reference's
                CartesianProductKernel) stays on the host, the 'project_first' eigen-projection of
                the Gram matrix and of every posterior covariance (gp_core.py:838-841, 849-857), the
                factorisation and the posterior run on the device.  The CP fitter constructs its GP
@@ -79,7 +80,7 @@ def install(multi_fidelity=False, batched_tuning=True, cartesian_product=False):
   if cartesian_product:
     import dragonfly.gp.cartesian_product_gp as ref_cpgp
     from . import cartesian_product_gp
-    _set(ref_cpgp, 'CPGP', cartesian_product_gp.CPGP)
+    _set(ref_cpgp, 'CPGP', cartesian_product_gp.device_cpgp_class(ref_cpgp))
   for ns_name in ('asy', 'syn', 'seq'):
     ref_ns = getattr(ref_acq, ns_name)
     our_ns = getattr(gpb_acquisitions, ns_name)

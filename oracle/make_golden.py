@@ -738,21 +738,13 @@ def gen_nonpsd_cases():
   print('wrote nonpsd_gp (min eig K: plain %.3f, cp %.3f)' % (res['min_eig_K'], res['cp_min_eig_K']))
 
 
-def gen_engine_traces():
-  """ For each of the 25 configurations of tests/test_gpu_install_end_to_end.py: the UNMODIFIED reference optimiser with
-      dragonfly_amd.install(), on the NumPy stand-in engine behind a recorder (tests/engine_trace.py) -- every call that
-      reaches the engine object, in order, with arguments and results -> tests/golden/engine_trace_<name>.npz.  Before
-      anything is written the run is checked against the same run WITHOUT install(): the same points, bit for bit
-      (dragonfly/opt/gp_bandit.py:405-421, 490, 647-673; apis/opt.py:138). """
+def engine_trace_scenarios():
+  """ (name, run, install keyword arguments, meta) for each of the 25 configurations of tests/test_gpu_install_end_to_end.py """
   tests_dir = os.path.join(os.path.dirname(HERE), 'tests')
   if tests_dir not in sys.path:
     sys.path.insert(0, tests_dir)
   import_reference()
-  import engine_trace as ET
   import test_install_end_to_end as E
-  from dragonfly_amd import install
-  from dragonfly_amd import euclidean_gp, general_utils, gp_core, gpb_acquisitions, kernel
-  from dragonfly_amd import engine as engine_mod
 
   def maximise_function_run():
     from dragonfly import maximise_function
@@ -779,25 +771,53 @@ def gen_engine_traces():
                       (lambda w=workers, a=acq: [np.array(v) for v in E._mf_run(w, a)[:2]]), dict(multi_fidelity=True),   # pylint: disable=protected-access
                       dict(kind='multi-fidelity', workers=workers, acq=acq)))
   scenarios.append(('maximise_function_defaults', maximise_function_run, {}, dict(kind='dragonfly.maximise_function, default options')))
+  return scenarios
 
+
+def record_engine_trace(run, install_kwargs):
+  """ One scenario: the reference as it is, then the same run with install() on the recording stand-in engine.
+      Returns (the reference's results, the install() run's results, the log of engine calls). """
+  tests_dir = os.path.join(os.path.dirname(HERE), 'tests')
+  if tests_dir not in sys.path:
+    sys.path.insert(0, tests_dir)
+  import engine_trace as ET
+  from dragonfly_amd import install
+  from dragonfly_amd import euclidean_gp, general_utils, gp_core, gpb_acquisitions, kernel
+  from dragonfly_amd import engine as engine_mod
   mods = (engine_mod, euclidean_gp, general_utils, gp_core, kernel)
+  want = run()                                   # the reference as it is
+  eng, log = ET.recording_engine()
+  saved = [(m, m.get_engine) for m in mods]
+  saved_dc = gpb_acquisitions.DEVICE_CANDIDATES
+  for m in mods:
+    m.get_engine = (lambda _e=eng: _e)
+  gpb_acquisitions.DEVICE_CANDIDATES = False
+  install.install(**install_kwargs)
+  try:
+    got = run()
+  finally:
+    install.uninstall()
+    for m, fn in saved:
+      m.get_engine = fn
+    gpb_acquisitions.DEVICE_CANDIDATES = saved_dc
+  return want, got, log
+
+
+def gen_engine_traces():
+  """ For each of the 25 configurations of tests/test_gpu_install_end_to_end.py: the UNMODIFIED reference optimiser with
+      dragonfly_amd.install(), on the NumPy stand-in engine behind a recorder (tests/engine_trace.py) -- every call that
+      reaches the engine object, in order, with arguments and results -> tests/golden/engine_trace_<name>.npz.  Before
+      anything is written the run is checked against the same run WITHOUT install(): the same points, bit for bit
+      (dragonfly/opt/gp_bandit.py:405-421, 490, 647-673; apis/opt.py:138).
+      The traces record the call stream of the install() of THIS commit: any change to what dragonfly_amd sends through
+      the engine object (batching in slice_sampler.py, install.py, the mirrors) needs them re-recorded --
+      tests/test_engine_traces_cpu.py::test_committed_trace_is_the_call_stream_of_this_tree re-records one and fails
+      when the committed trace is stale. """
+  scenarios = engine_trace_scenarios()
+  import engine_trace as ET
   total = 0
   for name, run, install_kwargs, meta in scenarios:
-    want = run()                                   # the reference as it is
-    eng, log = ET.recording_engine()
-    saved = [(m, m.get_engine) for m in mods]
-    saved_dc = gpb_acquisitions.DEVICE_CANDIDATES
-    for m in mods:
-      m.get_engine = (lambda _e=eng: _e)
-    gpb_acquisitions.DEVICE_CANDIDATES = False
-    install.install(**install_kwargs)
-    try:
-      got = run()
-    finally:
-      install.uninstall()
-      for m, fn in saved:
-        m.get_engine = fn
-      gpb_acquisitions.DEVICE_CANDIDATES = saved_dc
+    want, got, log = record_engine_trace(run, install_kwargs)
     assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want)), name
     meta = dict(meta, name=name, events=len(log.events), reference_points_equal=True,
                 result_shapes=[list(np.shape(w)) for w in want])
@@ -806,7 +826,7 @@ def gen_engine_traces():
     for ev in log.events:
       kinds[ev['m']] = kinds.get(ev['m'], 0) + 1
     total += len(log.events)
-    print('wrote engine_trace_%s: %d calls %s' % (name, len(log.events), kinds))
+    print('wrote engine_trace_%s: %d calls %s' % (name, len(log.events), kinds), flush=True)
   print('engine traces: %d scenarios, %d calls' % (len(scenarios), total))
 
 

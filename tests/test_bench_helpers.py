@@ -52,3 +52,28 @@ def test_cpu_legs_agree_stage_by_stage(monkeypatch, n, m):
     assert np.array_equal(a['blocks'][0][key], b['blocks'][0][key])
   assert a['blocks'][0]['argmax'] == b['blocks'][0]['argmax']
   assert np.array_equal(a['posterior'][0]['sd'], b['posterior'][0]['sd'])
+
+
+def test_contract_line_carries_the_side_targets_inside_roofline():
+  """ The last stdout line of bench.py is the contract's JSON line cut from the full record: short enough to survive a
+      tail, every side target a scalar INSIDE `roofline` (a record that keeps roofline's scalars keeps them). """
+  import json
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  full = None
+  for ln in open(os.path.join(root, 'profiles', 'r05_bench.json')):
+    if ln.startswith('{"metric'):
+      full = json.loads(ln)
+  line = bench.contract_line(full)
+  text = json.dumps(line)
+  assert len(text) < 4000
+  for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+    assert key in line
+  r = line['roofline']
+  assert all(not isinstance(v, (dict, list)) for v in r.values())
+  assert r['cholesky_frac_of_fp64_mfma_peak'] == full['roofline']['side_targets']['cholesky_frac_of_fp64_mfma_peak']
+  assert r['kernel_matrix_frac_by_section8d_bytes'] == full['roofline']['side_targets']['kernel_matrix_frac_by_section8d_bytes']
+  assert r['chol_ms'] == full['chol_ms'] and r['solve_ms'] == full['solve_ms'] and r['comm_ranks_formed'] == 1
+  assert r['C2_chol_ms'] == full['configs']['C2']['sections_ms']['chol']
+  assert set(line['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'}
+  assert 'workload' in line['config'] and 'model' not in line['config']

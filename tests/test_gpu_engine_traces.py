@@ -5,7 +5,7 @@ every acquisition / maximiser / tuning criterion (11 configurations), whole runs
 (8), multi-objective (3) and multi-fidelity (2) bandits and dragonfly.maximise_function with its defaults --
 with dragonfly_amd.install() on the NumPy stand-in engine, checked that each run returns the reference's own points
 bit for bit, and recorded every call on the engine object (dragonfly/opt/gp_bandit.py:405-421, 490, 647-673 ->
-fitters, GPs, acquisitions -> Engine / FittedGP).  Here the same 42 286 calls go to libdfhip.so: fits and appends
+fitters, GPs, acquisitions -> Engine / FittedGP).  Here the same 34 990 calls go to libdfhip.so: fits and appends
 (lml within 1e-10, jitter powers equal), tuning batches, posterior mean / std / covariance, fused acquisition
 arg-maxes (values within 1e-10, indices equal), Thompson draws, additive-UCB groups.  This is the driver-visible half
 of tests/test_gpu_install_end_to_end.py (which needs the checkout beside the GPU)."""
