@@ -17,6 +17,7 @@ KERNEL_SE, KERNEL_MATERN, KERNEL_ADDITIVE, KERNEL_PRODUCT, KERNEL_POLY, KERNEL_E
 ACQ_MEAN, ACQ_UCB, ACQ_EI, ACQ_PI, ACQ_TTEI, ACQ_STD = 0, 1, 2, 3, 4, 5
 GET_L, GET_ALPHA, GET_K = 0, 1, 2
 FIT_NO_JITTER, FIT_PROJECT_FIRST, FIT_TRY_BEFORE_PROJECT = 1, 2, 4
+LML_X_IS_DEVICE, LML_Y_IS_HOST = 0x100, 0x200       # include/dfhip.h: pointer-kind hints of dfh_gp_lml_batch
 T_NAMES = ['kernmat', 'chol', 'solve', 'cross', 'trsm', 'acq', 'ts', 'spare']
 INT32_MIN = -2**31
 UNIQUE_ID_BYTES = 128

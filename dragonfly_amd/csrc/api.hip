@@ -1427,7 +1427,8 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   for (int c = 0; c < nb; ++c) DFH_ARG(descs[c].dim == d);
   DFH_HIP(hipSetDevice(ctx->device));
   const double* dX = nullptr;
-  DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
+  if (flags & DFH_LML_X_IS_DEVICE) dX = X;
+  else DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
   static const bool tiny_enabled = []() { const char* e = getenv("DFH_LML_TINY"); return e ? atoi(e) != 0 : true; }();
   if (tiny_enabled && n <= TINY_MAX_N) {
     // small problems: pack, Gram matrix, stable_cholesky and the solve of every candidate in ONE
@@ -1435,15 +1436,16 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
     std::vector<KernDev> all((size_t)nb);
     for (int c = 0; c < nb; ++c) DFH_TRY(kerndev_build_host(&descs[c], &all[c]));
     if (lml_tiny_applies(all.data(), nb, n)) {
-      std::vector<double> y_host((size_t)n), ld_dot((size_t)nb * 2);
-      if (is_device_ptr(y)) {
-        DFH_HIP(hipMemcpyAsync(y_host.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+      std::vector<double> y_dl, ld_dot((size_t)nb * 2);
+      const double* y_host = y;
+      if (!(flags & DFH_LML_Y_IS_HOST) && is_device_ptr(y)) {
+        y_dl.resize((size_t)n);
+        DFH_HIP(hipMemcpyAsync(y_dl.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
         DFH_HIP(hipStreamSynchronize(ctx->stream));
-      } else {
-        std::memcpy(y_host.data(), y, (size_t)n * 8);
+        y_host = y_dl.data();
       }
       SectionTimer t(ctx, DFH_T_CHOL);
-      DFH_TRY(lml_tiny_batch(ctx, all.data(), nb, dX, n, d, y_host.data(), noise_vars, mean_consts,
+      DFH_TRY(lml_tiny_batch(ctx, all.data(), nb, dX, n, d, y_host, noise_vars, mean_consts,
                              !(flags & DFH_FIT_NO_JITTER), ld_dot.data(), jitter_powers));
       for (int c = 0; c < nb; ++c)     // gp_core.py:224-226
         lml_out[c] = -0.5 * ld_dot[2 * c + 1] - ld_dot[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);

@@ -15,6 +15,8 @@
 // only HBM traffic is the coalesced write of K (the pass is HBM-write bound:
 // 8*(n1*n2 + (n1+n2)*d) algorithmic bytes).
 #include "common.h"
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <math.h>
 #include <stdlib.h>
@@ -1133,8 +1135,23 @@ struct TinyArgs {
   const char* blob;                // TinyCand[count] | kernel images | y[n] | pow10[16]
   long y_off, pow_off;
   int n, count, allow_jitter;
+  int direct;                      // blob and out are host memory mapped into the device (small groups: no copies)
   double* out;                     // [count][4] = {sum log L_ii, |L^-1 (y - m)|^2, jitter power or -100, status}
 };
+
+// Results of a candidate.  direct: `out` is pinned host memory and the host is polling out[3] -- the three values go out
+// as system-scope (write-through) stores, are drained, and only then the status word follows.
+__device__ __forceinline__ void tiny_publish(double* out, bool direct, double v0, double v1, double v2, double status) {
+  if (direct) {
+    __hip_atomic_store(out + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(out + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(out + 2, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(out + 3, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    out[0] = v0; out[1] = v1; out[2] = v2; out[3] = status;
+  }
+}
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, j <= i
 
@@ -1308,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
 
   double* out = a.out + 4 * (long)c;
   if (s_fail) {
-    if (tid == 0) { out[0] = NAN; out[1] = NAN; out[2] = (double)power; out[3] = power == 98 ? 1.0 : 2.0; }
+    if (tid == 0) tiny_publish(out, a.direct != 0, NAN, NAN, (double)power, power == 98 ? 1.0 : 2.0);
     return;
   }
   double ld = 0.0, zz = 0.0;
@@ -1321,12 +1338,9 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
   __shared__ double s_ld[4], s_zz[4];
   if ((tid & 63) == 0) { s_ld[tid >> 6] = ld; s_zz[tid >> 6] = zz; }
   __syncthreads();
-  if (tid == 0) {
-    out[0] = (s_ld[0] + s_ld[1]) + (s_ld[2] + s_ld[3]);
-    out[1] = (s_zz[0] + s_zz[1]) + (s_zz[2] + s_zz[3]);
-    out[2] = (double)power;
-    out[3] = 0.0;
-  }
+  if (tid == 0)
+    tiny_publish(out, a.direct != 0, (s_ld[0] + s_ld[1]) + (s_ld[2] + s_ld[3]), (s_zz[0] + s_zz[1]) + (s_zz[2] + s_zz[3]),
+                 (double)power, 0.0);
 }
 
 }  // namespace
@@ -1378,18 +1392,31 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   std::memcpy(host_blob + y_off, y_host, sizeof(double) * (size_t)n);
   double* pw = reinterpret_cast<double*>(host_blob + pow_off);
   for (int p = -11; p < 5; ++p) pw[p + 11] = pow(10.0, (double)p);      // 10 ** diag_noise_power
+  // A handful of candidates (a slice sampler's or a tree search's call: gp_core.py:551-574 under sampling/slice.py,
+  // utils/doo.py) is latency, not work: the kernel reads the descriptors straight from the pinned buffer (mapped into
+  // the device: a few hundred bytes over PCIe) and writes its four numbers per candidate straight back into it, status
+  // word last, while the host polls that word -- one launch, no copy, no stream synchronisation.  DFH_LML_DIRECT=0: off;
+  // =N: groups of up to N candidates (default 16).
+  static const int direct_max = []() { const char* e = getenv("DFH_LML_DIRECT"); return e ? atoi(e) : 16; }();
+  const bool direct = count <= direct_max && at <= (size_t)32768 && !ctx->timing;
   void* d_blob = nullptr;
   double* d_out = nullptr;
-  DFH_TRY(scratch_get(ctx, SCR_AUG2, at, &d_blob));
-  DFH_TRY(scratch_get(ctx, SCR_OUT2, sizeof(double) * 4 * (size_t)count, (void**)&d_out));
-  DFH_HIP(hipMemcpyAsync(d_blob, host_blob, at, hipMemcpyHostToDevice, ctx->stream));
+  if (!direct) {
+    DFH_TRY(scratch_get(ctx, SCR_AUG2, at, &d_blob));
+    DFH_TRY(scratch_get(ctx, SCR_OUT2, sizeof(double) * 4 * (size_t)count, (void**)&d_out));
+    DFH_HIP(hipMemcpyAsync(d_blob, host_blob, at, hipMemcpyHostToDevice, ctx->stream));
+  }
   TinyArgs a;
   a.ec = kExpConsts;
   a.X = dX; a.ldx = ldx;
-  a.blob = static_cast<const char*>(d_blob);
+  a.blob = direct ? host_blob : static_cast<const char*>(d_blob);
   a.y_off = (long)y_off; a.pow_off = (long)pow_off;
   a.n = (int)n; a.count = count; a.allow_jitter = allow_jitter ? 1 : 0;
-  a.out = d_out;
+  a.direct = direct ? 1 : 0;
+  a.out = direct ? res : d_out;
+  volatile double* vres = res;
+  if (direct)
+    for (int c = 0; c < count; ++c) vres[4 * c + 3] = -1.0;      // "not there yet": the kernel's status is 0, 1 or 2
   const size_t lds_bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n * Pmax + (size_t)n * parts_max);
   static bool attr_set[DFH_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device]) {
@@ -1399,8 +1426,28 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   }
   hipLaunchKernelGGL(k_lml_tiny, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
   DFH_LAUNCH_CHECK();
-  DFH_HIP(hipMemcpyAsync(res, d_out, sizeof(double) * 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
-  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  if (direct) {
+    // bounded poll (a kernel of this size runs tens of microseconds; a ladder over seventeen attempts a millisecond);
+    // past the budget the stream is synchronised like any other call and a kernel that never wrote is an error
+    bool all_in = false;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (long spin = 0; !all_in; ++spin) {
+      all_in = true;
+      for (int c = 0; c < count; ++c) all_in = all_in && vres[4 * c + 3] != -1.0;
+      if (all_in) break;
+      if ((spin & 1023) == 1023 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 0.25) break;
+    }
+    if (!all_in) {
+      DFH_HIP(hipStreamSynchronize(ctx->stream));
+      for (int c = 0; c < count; ++c)
+        if (vres[4 * c + 3] == -1.0) { dfh_set_error("k_lml_tiny: no result for candidate %d", c); return DFH_ERR_HIP; }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    DFH_HIP(hipMemcpyAsync(res, d_out, sizeof(double) * 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+  }
   for (int c = 0; c < count; ++c) {
     const int status = (int)res[4 * c + 3];
     if (status == 1) {

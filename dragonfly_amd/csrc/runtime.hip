@@ -159,7 +159,14 @@ int pinned_get(dfh_ctx* ctx, size_t bytes, void** out) {
     if (ctx->h_stage) { DFH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
     size_t cap = 1 << 16;
     while (cap < bytes) cap <<= 1;
-    DFH_HIP(hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+    // mapped + coherent: kernels of the small-call paths read descriptors from it and write results into it directly
+    DFH_HIP(hipHostMalloc(&ctx->h_stage, cap, hipHostMallocMapped | hipHostMallocCoherent));
+    void* dev_view = nullptr;
+    DFH_HIP(hipHostGetDevicePointer(&dev_view, ctx->h_stage, 0));
+    if (dev_view != ctx->h_stage) {        // (one address space on this platform; anything else is not supported here)
+      dfh_set_error("pinned staging buffer: device view %p differs from host address %p", dev_view, ctx->h_stage);
+      return DFH_ERR_HIP;
+    }
     ctx->h_stage_bytes = cap;
   }
   *out = ctx->h_stage;

@@ -504,8 +504,13 @@ class Engine(object):
       raise ValueError('gp_lml_batch: need one mean constant and one noise variance per candidate.')
     lml = np.empty(nb, dtype=np.float64)
     jps = np.empty(nb, dtype=np.int32)
+    flags = 0 if allow_jitter else _lib.FIT_NO_JITTER
+    if isinstance(Xh, DeviceArray):
+      flags |= _lib.LML_X_IS_DEVICE
+    if not isinstance(yh, DeviceArray):
+      flags |= _lib.LML_Y_IS_HOST
     check(self.lib.dfh_gp_lml_batch(self.ctx, descs, nb, _ptr(Xh), n, d, _ptr(yh), _ptr(mc), _ptr(nv),
-                                    0 if allow_jitter else _lib.FIT_NO_JITTER, _ptr(lml), _ptr(jps)))
+                                    flags, _ptr(lml), _ptr(jps)))
     if return_powers:
       return lml, [None if p == INT32_MIN else int(p) for p in jps]
     return lml

@@ -234,6 +234,10 @@ int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const double* y_cen
  * needs the stable_cholesky ladder gets it individually (jitter_powers[c], INT32_MIN = none).
  * Errors as dfh_gp_fit (DFH_ERR_NOT_PD with DFH_FIT_NO_JITTER, DFH_ERR_JITTER when the ladder is
  * exhausted, utils/general_utils.py:200).                                                        */
+/* Optional hints in `flags` of dfh_gp_lml_batch (a caller that knows where its buffers live saves the library one
+ * pointer query each -- microseconds that matter when a slice sampler calls with one candidate at n = 50):          */
+#define DFH_LML_X_IS_DEVICE 0x100   /* X is device memory (a dfh_alloc buffer)                                   */
+#define DFH_LML_Y_IS_HOST   0x200   /* y is ordinary host memory                                                 */
 int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, const double* X, int64_t n,
                      int64_t d, const double* y, const double* mean_consts, const double* noise_vars,
                      int flags, double* lml_out /* [nb] */, int32_t* jitter_powers /* [nb] or NULL */);
