@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -1136,6 +1137,9 @@ struct TinyArgs {
   long y_off, pow_off;
   int n, count, allow_jitter;
   int direct;                      // blob and out are host memory mapped into the device (small groups: no copies)
+#ifdef DFH_DEBUG_HOOKS
+  long long* stamps;               // diagnostics (DFH_TINY_STAMPS=1): [count][16] s_memrealtime (100 MHz) of k_lml_tiny64's phases
+#endif
   double* out;                     // [count][4] = {sum log L_ii, |L^-1 (y - m)|^2, jitter power or -100, status}
 };
 
@@ -1343,6 +1347,232 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
                  (double)power, 0.0);
 }
 
+
+#include "factor64.h"   // factor64's owner / consumer steps (shared with chol.hip)
+
+// ---------------------------------------------------------------------------------------
+// The same objective for n <= 63 with the factorisation on the 64 x 64 machinery of chol.hip (round 6).
+// k_lml_tiny's column loop costs two workgroup barriers, an LDS round trip, a square root and a division per
+// column, ~1100 cycles each: 39 us for n = 50 on an otherwise idle device (profiles/r06_small_calls_before.txt), most
+// of a slice sampler's call.  Here the system [[K + s2 I, .], [(y - m)^T, 1]] is staged as ONE 64 x 64 tile (identity
+// below row n) and factored by the four waves without barriers -- the owner chain of f64_owner_step is ~225 cycles
+// per column -- and only as far as column n - 1: row n of the factor, z = L^-1 (y - m), is final in column k as soon as
+// column k is, so the augmented row never has to be a pivot, and the waves whose sixteen columns lie beyond n - 1 sit
+// the factorisation out.  Everything else -- packing, Gram entries, the jitter ladder, the results -- is k_lml_tiny's.
+// ---------------------------------------------------------------------------------------
+template <int... KLs>
+__device__ __forceinline__ void f64_owner_block_upto(double (&a)[16], int lane, int w, double* ring, int& bad, int klast,
+                                                     std::integer_sequence<int, KLs...>) {
+  double mprev = 0.0;
+  ((16 * w + KLs <= klast ? f64_owner_step<KLs>(a, lane, w, ring, bad, mprev) : (void)0), ...);
+}
+
+// factor64_waves without the 16 x 16 inverses, columns 0 .. klast only.  a[]: this wave's sixteen columns of L, row per
+// lane (garbage in columns beyond klast).  Returns the first non-positive pivot column of the wave's block or -1.
+__device__ __forceinline__ int tiny64_factor(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
+                                             double* ring, int klast, int* ring_timeout) {
+  int bad = -1;
+  const bool active = 16 * w <= klast;                 // wave-uniform
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = stage[lane * SPP_STAGE + j];
+    __syncthreads();
+  } else {
+    double4_t acc[4];
+    const int kq = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = stage[(16 * t + kq + 4 * r) * SPP_STAGE + 16 * w + l15];
+    __syncthreads();
+    if (!active) return -1;
+    for (int kb = 0; kb < w; ++kb) f64_consume_block(acc, lane, w, kb, ring, ring_timeout);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tbuf[(16 * t + kq + 4 * r) * 17 + l15] = acc[t][r];
+    COMPILER_BARRIER();                                // same wave: LDS executes its operations in order
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = tbuf[lane * 17 + j];
+  }
+  f64_owner_block_upto(a, lane, w, ring, bad, klast, std::make_integer_sequence<int, 16>{});
+  // L[:,k] = u[:,k] * sqrt(1/d_k), sixteen independent chains stage by stage (as factor64_waves)
+  double x[16], y[16], h[16], e[16], sq[16];
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) { x[kl] = ring[(16 * w + kl) * PB]; x[kl] = (16 * w + kl <= klast) ? x[kl] : 1.0; }
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) { y[kl] = __builtin_amdgcn_rsq(x[kl]); h[kl] = 0.5 * x[kl]; }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-(h[kl] * y[kl]), y[kl], 0.5);
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) y[kl] = fma(y[kl], e[kl], y[kl]);
+  }
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) sq[kl] = x[kl] * y[kl];
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) sq[kl] = fma(fma(-sq[kl], sq[kl], x[kl]), 0.5 * y[kl], sq[kl]);
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-sq[kl], y[kl], 1.0);
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) y[kl] = fma(e[kl], y[kl], y[kl]);
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) {
+    const int k = 16 * w + kl;
+    a[kl] = (lane == k) ? y[kl] : ((lane > k) ? a[kl] * sq[kl] : 0.0);
+  }
+  return bad;
+}
+
+#ifdef DFH_DEBUG_HOOKS
+#define TSTAMP(a, e) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(long)blockIdx.x * 16 + (e)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(a, e) do {} while (0)
+#endif
+constexpr int TINY64_MAX_N = 63;
+constexpr size_t TINY64_FIXED_LDS = sizeof(double) * (PB * SPP_STAGE + PB * PB + 3 * PB * 17);
+
+__global__ __launch_bounds__(256, 1) void k_lml_tiny64(TinyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int c = blockIdx.x, tid = threadIdx.x, n = a.n;
+  const int lane = tid & 63, w = tid >> 6;
+  TSTAMP(a, 0);
+  const TinyCand cand = reinterpret_cast<const TinyCand*>(a.blob)[c];
+  const char* image = a.blob + cand.image;
+  const int P = cand.P, n_parts = cand.n_parts;
+  const size_t off_bw = (sizeof(PartDev) * n_parts + 15) & ~size_t(15);
+  const size_t off_cols = off_bw + ((sizeof(double) * (P ? P : 1) + 15) & ~size_t(15));
+  const PartDev* parts_g = reinterpret_cast<const PartDev*>(image);
+  __shared__ PartDev parts[TINY_MAX_PARTS];
+  for (int q = tid; q < n_parts * (int)(sizeof(PartDev) / sizeof(int)); q += 256)
+    reinterpret_cast<int*>(parts)[q] = reinterpret_cast<const int*>(parts_g)[q];
+  const double* bw = reinterpret_cast<const double*>(image + off_bw);
+  const int* cols = reinterpret_cast<const int*>(image + off_cols);
+  const double* y = reinterpret_cast<const double*>(a.blob + a.y_off);
+  const double* pow10 = reinterpret_cast<const double*>(a.blob + a.pow_off);
+
+  double* stage = lds;                               // [64][SPP_STAGE] the system, lower triangle
+  double* ring = stage + PB * SPP_STAGE;             // [64][64] published columns
+  double* tbuf0 = ring + PB * PB;                    // 3 x [64][17] layout buffers of waves 1..3
+  double* Xp = tbuf0 + 3 * PB * 17;                  // [n][P]
+  double* Np = Xp + n * P;                           // [n][n_parts]
+  __shared__ int s_badv[4];
+  __shared__ int s_ring_timeout;
+  __shared__ double s_ld[4], s_zz[4];
+
+  TSTAMP(a, 1);
+  // identity below row n, zero above the diagonal; row n = y - m with a unit diagonal
+  for (int idx = tid; idx < PB * PB; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    stage[i * SPP_STAGE + j] = (i == j && i >= n) ? 1.0 : 0.0;
+  }
+  for (int idx = tid; idx < n * P; idx += 256) {
+    const int row = idx / P, pc = idx - row * P;
+    const int col = cols[pc];
+    Xp[idx] = col >= 0 ? a.X[(long)row * a.ldx + col] / bw[pc] : 0.0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * n_parts; idx += 256) {
+    const int row = idx / n_parts, part = idx - row * n_parts;
+    const PartDev& pd = parts[part];
+    int nreal = 0;
+    for (int q = 0; q < pd.kc; ++q) nreal += cols[pd.poff + q] >= 0;
+    Np[idx] = np_sumsq(Xp + row * P + pd.poff, nreal);
+  }
+  for (int j = tid; j < n; j += 256) stage[n * SPP_STAGE + j] = y[j] - cand.mean;
+  __syncthreads();
+
+  TSTAMP(a, 2);
+  double max_diag = 0.0;
+  int power = -100;
+  bool failed = false;
+  double av[16];
+  for (int attempt = 0; attempt < 17; ++attempt) {
+    double jitter = 0.0;
+    if (attempt > 0) {
+      if (attempt == 1) {                            // np.diag(M).max() of the un-jittered matrix, still staged
+        double m = -INFINITY;
+        bool any_nan = false;
+        for (int i = 0; i < n; ++i) { const double v = stage[i * SPP_STAGE + i]; any_nan |= (v != v); m = v > m ? v : m; }
+        max_diag = any_nan ? NAN : m;
+        __syncthreads();                             // every thread has read the old diagonal
+      }
+      power = attempt - 12;                          // -11 ... 4 (general_utils.py:183-203)
+      jitter = pow10[attempt - 1] * max_diag;
+    }
+    // the lower triangle as a rectangle: row p and row n - 1 - p together hold n + 1 entries
+    for (int idx = tid; idx < ((n + 1) >> 1) * (n + 1); idx += 256) {
+      {
+        const int p = idx / (n + 1), q = idx - p * (n + 1);
+        const int i = q <= p ? p : n - 1 - p, j = q <= p ? q : q - p - 1;
+        if (q > p && n - 1 - p == p) continue;       // (odd n: the middle row is its own partner)
+        double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
+        double fsum = 0.0;
+        for (int part = 0; part < n_parts; ++part) {
+          const PartDev& pd = parts[part];
+          const double* xi = Xp + i * P + pd.poff;
+          const double* xj = Xp + j * P + pd.poff;
+          double dot = 0.0;
+          for (int q = 0; q < pd.kc; ++q) dot = fma(xi[q], xj[q], dot);
+          double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
+          dsq = dsq < 0.0 ? 0.0 : dsq;
+          const double kv = kern_eval(pd, dsq, a.ec);
+          if (!cand.multi) res = kv;
+          else if (!cand.product) res = res + kv;
+          else combine_nested(pd, kv, res, fsum);
+        }
+        if (cand.multi && !cand.product) res = cand.outer * res;
+        if (i == j) {
+          res += cand.noise;                         // gp_core.py:843
+          if (attempt > 0) res += jitter;            // M + diag_noise * np.eye(n)
+        }
+        stage[i * SPP_STAGE + j] = res;
+      }
+    }
+    if (tid < PB) ring[tid * PB] = 0.0;              // row-0 entries double as the "published" flags
+    if (tid == 0) s_ring_timeout = 0;
+    __syncthreads();
+    TSTAMP(a, 3);
+    double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
+    const int bad = tiny64_factor(av, lane, w, stage, tbuf, ring, n - 1, &s_ring_timeout);
+    if (lane == 0) s_badv[w] = (bad >= 0 && bad < n) ? bad : -1;
+    __syncthreads();
+    TSTAMP(a, 4);
+    failed = s_badv[0] >= 0 || s_badv[1] >= 0 || s_badv[2] >= 0 || s_badv[3] >= 0 || s_ring_timeout != 0;
+    if (!failed) break;
+    if (!a.allow_jitter || attempt == 16) { power = attempt == 16 ? 99 : 98; break; }
+    __syncthreads();                                 // the verdict is read before the next attempt rewrites it
+  }
+
+  double* out = a.out + 4 * (long)c;
+  if (failed) {
+    if (tid == 0) tiny_publish(out, a.direct != 0, NAN, NAN, (double)power, power == 98 ? 1.0 : 2.0);
+    return;
+  }
+  // sum log L_kk (lane k of the wave that owns column k) and z.z (row n = lane n)
+  double lkk = 1.0, zz = 0.0;                        // (one logarithm per lane: log(1) = 0 in the lanes that own no column)
+  if (16 * w <= n - 1) {
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) {
+      const int k = 16 * w + kl;
+      if (k < n) {
+        lkk = (lane == k) ? av[kl] : lkk;
+        if (lane == n) zz = fma(av[kl], av[kl], zz);
+      }
+    }
+  }
+  double ldv = log(lkk);
+  for (int o = 32; o > 0; o >>= 1) { ldv += __shfl_down(ldv, o, 64); zz += __shfl_down(zz, o, 64); }
+  if (lane == 0) { s_ld[w] = ldv; s_zz[w] = zz; }
+  __syncthreads();
+  TSTAMP(a, 5);
+  if (tid == 0)
+    tiny_publish(out, a.direct != 0, (s_ld[0] + s_ld[1]) + (s_ld[2] + s_ld[3]), (s_zz[0] + s_zz[1]) + (s_zz[2] + s_zz[3]),
+                 (double)power, 0.0);
+  TSTAMP(a, 6);
+}
+
 }  // namespace
 
 bool lml_tiny_applies(const KernDev* kds, int count, int64_t n) {
@@ -1391,7 +1621,12 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   }
   std::memcpy(host_blob + y_off, y_host, sizeof(double) * (size_t)n);
   double* pw = reinterpret_cast<double*>(host_blob + pow_off);
-  for (int p = -11; p < 5; ++p) pw[p + 11] = pow(10.0, (double)p);      // 10 ** diag_noise_power
+  static const std::vector<double> pow10_table = []() {                 // 10 ** diag_noise_power, once per process
+    std::vector<double> t(16);
+    for (int p = -11; p < 5; ++p) t[(size_t)(p + 11)] = pow(10.0, (double)p);
+    return t;
+  }();
+  std::memcpy(pw, pow10_table.data(), sizeof(double) * 16);
   // A handful of candidates (a slice sampler's or a tree search's call: gp_core.py:551-574 under sampling/slice.py,
   // utils/doo.py) is latency, not work: the kernel reads the descriptors straight from the pinned buffer (mapped into
   // the device: a few hundred bytes over PCIe) and writes its four numbers per candidate straight back into it, status
@@ -1414,17 +1649,32 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   a.n = (int)n; a.count = count; a.allow_jitter = allow_jitter ? 1 : 0;
   a.direct = direct ? 1 : 0;
   a.out = direct ? res : d_out;
+#ifdef DFH_DEBUG_HOOKS
+  static long long* d_stamps = nullptr;
+  static const bool want_stamps = getenv("DFH_TINY_STAMPS") != nullptr;
+  if (want_stamps && !d_stamps) DFH_HIP(hipMalloc((void**)&d_stamps, 64 * 16 * 8));
+  a.stamps = (want_stamps && count <= 64) ? d_stamps : nullptr;
+#endif
   volatile double* vres = res;
   if (direct)
     for (int c = 0; c < count; ++c) vres[4 * c + 3] = -1.0;      // "not there yet": the kernel's status is 0, 1 or 2
-  const size_t lds_bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n * Pmax + (size_t)n * parts_max);
   static bool attr_set[DFH_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device]) {
     DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lml_tiny), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 4096));      // static LDS (kernel parts, flags) takes ~2 KB
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lml_tiny64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 4096));
     attr_set[ctx->device] = true;
   }
-  hipLaunchKernelGGL(k_lml_tiny, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
+  // n <= 63: the system is one 64 x 64 tile for the barrier-free factorisation (k_lml_tiny64); DFH_LML_TINY64=0: k_lml_tiny
+  static const bool tiny64 = []() { const char* e = getenv("DFH_LML_TINY64"); return e ? atoi(e) != 0 : true; }();
+  if (tiny64 && n <= TINY64_MAX_N) {
+    const size_t lds_bytes = TINY64_FIXED_LDS + sizeof(double) * ((size_t)n * Pmax + (size_t)n * parts_max);
+    hipLaunchKernelGGL(k_lml_tiny64, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
+  } else {
+    const size_t lds_bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n * Pmax + (size_t)n * parts_max);
+    hipLaunchKernelGGL(k_lml_tiny, dim3((unsigned)count), dim3(256), lds_bytes, ctx->stream, a);
+  }
   DFH_LAUNCH_CHECK();
   if (direct) {
     // bounded poll (a kernel of this size runs tens of microseconds; a ladder over seventeen attempts a millisecond);
@@ -1448,6 +1698,19 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
     DFH_HIP(hipMemcpyAsync(res, d_out, sizeof(double) * 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     DFH_HIP(hipStreamSynchronize(ctx->stream));
   }
+#ifdef DFH_DEBUG_HOOKS
+  if (a.stamps) {
+    static long long acc[8] = {0}; static long calls = 0;
+    long long hs[16];
+    DFH_HIP(hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int e = 0; e < 6; ++e) acc[e] += hs[e + 1] - hs[e];
+    if (++calls % 1000 == 0) {
+      fprintf(stderr, "[tiny64 stamps, mean of 1000, us] cand %.2f | descr+fill %.2f | pack+norms %.2f | gram %.2f | factor %.2f | reduce %.2f | publish %.2f\n",
+              0.0, acc[0] / 1e5, acc[1] / 1e5, acc[2] / 1e5, acc[3] / 1e5, acc[4] / 1e5, acc[5] / 1e5);
+      for (int e = 0; e < 8; ++e) acc[e] = 0;
+    }
+  }
+#endif
   for (int c = 0; c < count; ++c) {
     const int status = (int)res[4 * c + 3];
     if (status == 1) {

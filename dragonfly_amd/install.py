@@ -313,7 +313,7 @@ def make_batched_fitter(ref_fitter_cls):
         gp = self.build_gp(cts, dscr, other_gp_params=other_gp_params, build_posterior=False)
       finally:
         _ref_egp.EuclideanGP = saved_cls
-      if gp.host_kernel:
+      if getattr(gp, 'host_kernel', getattr(gp, '_generic', True)):
         return None
       return (gp.kernel.to_spec(self.dim).signature(), float(gp.mean_func([np.zeros(self.dim)])[0]), float(gp.noise_var))
 
@@ -345,7 +345,9 @@ def make_batched_fitter(ref_fitter_cls):
         for i, cts in enumerate(cts_hps_list):
           dscr = list(dscr_hps[i]) if per_cand else list(dscr_hps)
           gp = self.build_gp(cts, dscr, other_gp_params=other_gp_params, build_posterior=False)
-          if user_mean or gp.host_kernel:
+          # (a fitter subclass that builds its GP through its own import gets a real GP here, not the stand-in: it has
+          #  no `host_kernel`; what the mirror's GP calls `_generic` says the same, and anything else takes the safe route)
+          if user_mean or getattr(gp, 'host_kernel', getattr(gp, '_generic', True)):
             specs = None
             break
           specs.append(gp.kernel.to_spec(self.dim))

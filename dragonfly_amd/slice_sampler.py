@@ -38,7 +38,11 @@ class _GlobalStreamPosition(object):
       block boundary inside the draws -- the caller takes the state-copy route. """
 
   def __init__(self):
+    self._bind()
+
+  def _bind(self):
     self.pos = None
+    self._bitgen = None
     try:
       bitgen = nr.mtrand._rand._bit_generator      # pylint: disable=protected-access
       if type(bitgen).__name__ != 'MT19937':
@@ -52,6 +56,10 @@ class _GlobalStreamPosition(object):
 
   def room_for(self, doubles):
     """ True if the next `doubles` calls' worth of words all come from the current block (so they can be un-read) """
+    # (np.random.set_bit_generator / a re-seeded legacy RandomState puts ANOTHER generator behind np.random: the cached
+    #  position would then belong to the old one and `unread` would rewind the wrong state -- bind again when it changed)
+    if nr.mtrand._rand._bit_generator is not self._bitgen:      # pylint: disable=protected-access
+      self._bind()
     return self.pos is not None and 0 <= self.pos.value and self.pos.value + 2 * doubles <= 624
 
   def unread(self, doubles):

@@ -36,8 +36,12 @@ TARGET = 'hipv4-amdgcn-amd-amdhsa--gfx950'
 
 _REG = re.compile(r'\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]')
 # no destination register in the first operand: stores, LDS writes, scalar / control instructions, VOPC to vcc
+# (matched against the WHOLE instruction text: whether an atomic returns a value is said by `sc0` among its modifiers
+#  -- gfx940+ -- or by `_rtn` in an LDS atomic's mnemonic, not by the mnemonic's stem)
 _NO_DEST = re.compile(r'^(global_store|scratch_store|flat_store|buffer_store|ds_write|ds_store|ds_gws|s_|v_cmpx?_\w+_e32|'
-                      r'v_nop|exp|buffer_wbl2|buffer_inv|global_atomic_(?!.*\bsc0\b))')
+                      r'v_nop|exp|buffer_wbl2|buffer_inv|'
+                      r'(global|flat|buffer)_atomic_(?!.*\bsc0\b)|'
+                      r'ds_(add|sub|rsub|inc|dec|min|max|and|or|xor|mskor|cmpst|pk_add)_(?!rtn)\w*\s)')
 _CALL = re.compile(r'^s_(swappc|setpc)_b64')
 
 
@@ -54,6 +58,7 @@ def _regs(text):
 def audit_function(lines):
   """lines: instruction texts ('mnemonic operands') of one function. Returns sorted [(reg, n_writes)]."""
   written, read = {}, set()
+  tuples = []
   calls = False
   for ins in lines:
     ins = ins.split(';')[0].strip()
@@ -65,16 +70,34 @@ def audit_function(lines):
     operands = [o.strip() for o in ops.split(',')] if ops else []
     if not operands:
       continue
-    if _NO_DEST.match(mnem):
+    if _NO_DEST.match(ins):
       for o in operands:
         read |= _regs(o)
       continue
-    for r in _regs(operands[0]):
+    dest = _regs(operands[0])
+    for r in dest:
       written[r] = written.get(r, 0) + 1
+    if len(dest) > 1:
+      tuples.append(dest)
     for o in operands[1:]:
       read |= _regs(o)
-  flagged = [(r, n) for r, n in written.items() if r not in read and (r[0] == 'a' or not calls)]
+  # a tuple destination (a dwordx4 load, an MFMA result) is one write: its registers are "never read" only if NONE of
+  # them is -- a partly used tuple is ordinary code, not the fault
+  partly_used = set()
+  for dest in tuples:
+    if any(r in read for r in dest):
+      partly_used |= dest
+  flagged = [(r, n) for r, n in written.items()
+             if r not in read and r not in partly_used and (r[0] == 'a' or not calls)]
   return sorted(flagged)
+
+
+def severity(reg):
+  """ 'error' for what was root-caused (docs/NOTES_r05.md section 2): an ACCUMULATOR register written and never read --
+      on this register file the AGPRs of a kernel under pressure are the allocator's spill space, a dead write there is
+      a lost spill piece -- and a reload of unspilled scratch.  A written-never-read VECTOR register is a 'warning':
+      the heuristic is flow-insensitive and an odd but correct code sequence can show it. """
+  return 'error' if reg.startswith('a') or reg.startswith('scratch') else 'warning'
 
 
 _SCRATCH = re.compile(r'^scratch_(load|store)_(dword(?:x(\d))?|[su]?byte|[su]?short)\w*\s+(.*)$')
@@ -236,8 +259,9 @@ def main(argv):
     n, bad = audit(p)
     print('%s: %d functions, %d findings (registers written and never read, scratch reloads never spilled)' % (os.path.relpath(p), n, len(bad)))
     for name, reg, writes in bad:
-      print('  %s  in  %s  (%s)' % (reg, name, 'reloaded, never spilled' if writes == 0 else '%d write%s, no read' % (writes, '' if writes == 1 else 's')))
-      rc = 1
+      print('  %-7s %s  in  %s  (%s)' % (severity(reg), reg, name, 'reloaded, never spilled' if writes == 0 else '%d write%s, no read' % (writes, '' if writes == 1 else 's')))
+      if severity(reg) == 'error':
+        rc = 1
   return rc
 
 
