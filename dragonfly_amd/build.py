@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ_DIR = os.path.join(HERE, 'csrc', '_obj')
 LIB_PATH = os.path.join(HERE, 'libdfhip.so')
 SOURCES = ['runtime.hip', 'gemm_f64.hip', 'kernmat.hip', 'chol.hip', 'api.hip', 'rng.hip', 'mgpu.hip', 'psdproj.hip', 'mtjump.hip']
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "factor64.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "factor64.h"), os.path.join(CSRC, "kerneval.h"),
            os.path.join(HERE, '..', 'include', 'dfhip.h')]
 # -ffp-contract=off: no implicit a*b+c fusion, so the elementwise epilogues round exactly where the
 # NumPy expressions they replace round; fused multiply-adds are written explicitly (fma) where wanted.

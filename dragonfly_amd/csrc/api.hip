@@ -635,8 +635,7 @@ static int gp_alpha_and_lml(dfh_gp* gp, const double* dy, double* lml) {
   const int64_t n = gp->n;
   SectionTimer t(ctx, DFH_T_SOLVE);
   DFH_HIP(hipMemcpyAsync(gp->alpha, dy, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  DFH_TRY(trsv_forward(ctx, gp->L, n, n, gp->inv, gp->alpha, gp->refine.data()));
-  DFH_TRY(trsv_backward(ctx, gp->L, n, n, gp->inv, gp->alpha, gp->refine.data()));
+  DFH_TRY(trsv_both(ctx, gp->L, n, n, gp->inv, gp->alpha, gp->refine.data()));
   double logdet = 0.0, dot = 0.0;
   DFH_TRY(logdet_and_dot(ctx, gp->L, n, n, dy, gp->alpha, &logdet, &dot));
   if (lml) *lml = -0.5 * dot - logdet - 0.5 * (double)n * log(2.0 * M_PI);
@@ -1277,8 +1276,7 @@ static int lml_batch_lockstep(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_
             hipLaunchKernelGGL(k_centre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dy, hpar[g + c], yc, alpha, (long)n);
             DFH_LAUNCH_CHECK();
             // alpha = L^T \ (L \ (y - m))      (gp_core.py:161-163)
-            DFH_TRY(trsv_forward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
-            DFH_TRY(trsv_backward(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
+            DFH_TRY(trsv_both(ctx, Kb + c * strideK, n, ldK, invb + c * strideInv, alpha, refine.data() + (size_t)c * nblk));
             DFH_TRY(logdet_and_dot_device(ctx, Kb + c * strideK, n, ldK, yc, alpha, red + 2 * c));
           }
         }
@@ -1430,6 +1428,37 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   if (flags & DFH_LML_X_IS_DEVICE) dX = X;
   else DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
   static const bool tiny_enabled = []() { const char* e = getenv("DFH_LML_TINY"); return e ? atoi(e) != 0 : true; }();
+  if (tiny_enabled && n > TINY64_MAX_N && n <= LMLF_MAX_N && nb <= 64) {
+    // a handful of mid-sized candidates (a slice sampler's call at 64 <= n <= 191): Gram matrix, factorisation and
+    // forward solve of each in ONE launch by one workgroup, nothing copied (chol.hip: lml_wgf_kernel)
+    std::vector<KernDev> all((size_t)nb);
+    for (int c = 0; c < nb; ++c) DFH_TRY(kerndev_build_host(&descs[c], &all[c]));
+    if (lml_wg_fused_applies(all.data(), nb, n)) {
+      std::vector<double> y_dl, ld_dot((size_t)nb * 2);
+      std::vector<long long> info((size_t)nb);
+      const double* y_host = y;
+      if (!(flags & DFH_LML_Y_IS_HOST) && is_device_ptr(y)) {
+        y_dl.resize((size_t)n);
+        DFH_HIP(hipMemcpyAsync(y_dl.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        DFH_HIP(hipStreamSynchronize(ctx->stream));
+        y_host = y_dl.data();
+      }
+      {
+        SectionTimer t(ctx, DFH_T_CHOL);
+        DFH_TRY(lml_wg_fused_batch(ctx, all.data(), nb, dX, n, d, y_host, noise_vars, mean_consts, ld_dot.data(), info.data()));
+      }
+      for (int c = 0; c < nb; ++c) {
+        if (info[c] != 0) {        // a failed pivot (the ladder) or no bound on the augmented pivot: the lock-step schedule, alone
+          DFH_TRY(lml_batch_lockstep(ctx, descs + c, 1, dX, n, d, y, mean_consts ? mean_consts + c : nullptr, noise_vars + c,
+                                     flags, lml_out + c, jitter_powers ? jitter_powers + c : nullptr, c));
+          continue;
+        }
+        if (jitter_powers) jitter_powers[c] = INT32_MIN;
+        lml_out[c] = -0.5 * ld_dot[2 * c + 1] - ld_dot[2 * c] - 0.5 * (double)n * log(2.0 * M_PI);     // gp_core.py:224-226
+      }
+      return DFH_OK;
+    }
+  }
   if (tiny_enabled && n <= TINY_MAX_N) {
     // small problems: pack, Gram matrix, stable_cholesky and the solve of every candidate in ONE
     // launch (kernmat.hip: k_lml_tiny)

@@ -16,6 +16,7 @@
 //   solve (trsm_rows) and the alpha solves (trsv_*) reuse them, which turns every triangular
 //   solve on the hot path into GEMM / GEMV work.
 #include "common.h"
+#include <cmath>
 #include <functional>
 #include <utility>
 #include <math.h>
@@ -33,6 +34,7 @@ constexpr unsigned SYNC_ST_GATE = 4;      // a gate kernel / resident diagonal k
 constexpr int SPIN_LIMIT_DEFAULT = 1 << 21;   // polls of ~0.5 us each: a second, a few hundred times the longest legitimate wait
 
 #include "factor64.h"   // factor64_waves and its helpers (PB, SYNC_ST_RING, fast_rcp, perm16, quad_sum, ...)
+#include "kerneval.h"   // kernel evaluation (the fused tuning objective builds its Gram matrix itself)
 
 // One 64-wide step of the diagonal-block factorisation, one launch:
 //   workgroup 0     : factors the nb x nb pivot block at D and writes the factor to Lout;
@@ -395,7 +397,23 @@ __device__ __forceinline__ void lmlwg_solve_store(const double4_t (&acc)[4], con
   COMPILER_BARRIER();                                // (the next tile's substitution overwrites Rw)
 }
 
-__global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
+// FUSED (round 6): the workgroup first builds its candidate's Gram matrix itself -- descriptor, inputs and labels as
+// k_lml_tiny takes them (kernmat.hip; LmlFuse), scaled inputs in the LDS the factorisation uses later -- writes the n x n
+// lower triangle to Km, and publishes {sum log L_ii, z.z, failed pivot or 0, done} per candidate the way tiny_publish does:
+// a small group of mid-sized candidates (a slice sampler's call at 64 <= n <= 191) is then ONE launch with no copy at all.
+struct LmlFuse {
+  ExpConsts ec;
+  const double* X; long ldx;       // [n x d] raw inputs (device)
+  const char* blob;                // TinyCand[count] | kernel images | y[n]   (pinned host memory when direct)
+  long y_off;
+  double* ybuf;                    // [n] device copy of y (every workgroup writes the same values)
+  double* out4;                    // [count][4]
+  int direct;
+};
+constexpr int LMLF_LDS_DOUBLES = PB * PB + 3 * PB * 17 + 8 * 16 * 17;     // ring .. linv: free until the first factorisation
+
+template <bool FUSED>
+__device__ __forceinline__ void lml_wg_body(const LmlWgArgs& a, const LmlFuse& f) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* Sp = dsm;                                  // [64][SPP] staged diagonal tile, then the factor image (perm16 columns)
   double* R = dsm + PB * SPP_STAGE;                  // [64][65] solved rows, 16 per wave
@@ -414,7 +432,79 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
   double* __restrict__ Km = a.K + (long)c * a.sK;
   const long ld = a.ld;
   const int n = a.n, nbt = a.nbt;
-  const double cdiag = a.par[c], mean = a.par[a.count + c];
+  double cdiag, mean;
+  if constexpr (FUSED) {
+    __shared__ PartDev parts[TINY_MAX_PARTS];
+    __shared__ double s_fz[4];
+    const TinyCand cand = reinterpret_cast<const TinyCand*>(f.blob)[c];
+    const char* image = f.blob + cand.image;
+    const int P = cand.P, n_parts = cand.n_parts;
+    const size_t off_bw = (sizeof(PartDev) * n_parts + 15) & ~size_t(15);
+    const size_t off_cols = off_bw + ((sizeof(double) * (P ? P : 1) + 15) & ~size_t(15));
+    for (int q = tid; q < n_parts * (int)(sizeof(PartDev) / sizeof(int)); q += 256)
+      reinterpret_cast<int*>(parts)[q] = reinterpret_cast<const int*>(image)[q];
+    const double* bw = reinterpret_cast<const double*>(image + off_bw);
+    const int* cols = reinterpret_cast<const int*>(image + off_cols);
+    const double* yb = reinterpret_cast<const double*>(f.blob + f.y_off);
+    double* Xp = ring;                               // [n][P], then Np [n][n_parts]
+    double* Np = Xp + n * P;
+    double r2 = 0.0;
+    for (int j = tid; j < n; j += 256) { const double v = yb[j]; f.ybuf[j] = v; r2 = fma(v - cand.mean, v - cand.mean, r2); }
+    for (int idx = tid; idx < n * P; idx += 256) {
+      const int row = idx / P, pc = idx - row * P;
+      const int col = cols[pc];
+      Xp[idx] = col >= 0 ? f.X[(long)row * f.ldx + col] / bw[pc] : 0.0;       // kernel.py:179-181
+    }
+    for (int off = 32; off > 0; off >>= 1) r2 += __shfl_down(r2, off, 64);
+    if (lane == 0) s_fz[w] = r2;
+    __syncthreads();
+    for (int idx = tid; idx < n * n_parts; idx += 256) {
+      const int row = idx / n_parts, part = idx - row * n_parts;
+      const PartDev& pd = parts[part];
+      int nreal = 0;
+      for (int q = 0; q < pd.kc; ++q) nreal += cols[pd.poff + q] >= 0;
+      Np[idx] = np_sumsq(Xp + row * P + pd.poff, nreal);                     // general_utils.py:66-67
+    }
+    __syncthreads();
+    // the augmented row's diagonal entry c = 1 + |y - m|^2 / s2 > z.z (a hair of slack for the sum's rounding)
+    mean = cand.mean;
+    const double rr = ((s_fz[0] + s_fz[1]) + (s_fz[2] + s_fz[3])) * (1.0 + 1e-6);
+    cdiag = 1.0 + rr / cand.noise;
+    if (!(cand.noise > 0.0) || !(cdiag < INFINITY)) {          // (uniform) nothing bounds z.z: the host takes this candidate elsewhere
+      if (tid == 0) tiny_publish(f.out4 + 4 * (long)c, f.direct != 0, NAN, NAN, -1.0, 1.0);
+      return;
+    }
+    // the lower triangle as a rectangle: row p and row n - 1 - p together hold n + 1 entries
+    for (int idx = tid; idx < ((n + 1) >> 1) * (n + 1); idx += 256) {
+      const int p = idx / (n + 1), q = idx - p * (n + 1);
+      const int i = q <= p ? p : n - 1 - p, j = q <= p ? q : q - p - 1;
+      if (q > p && n - 1 - p == p) continue;         // (odd n: the middle row is its own partner)
+      double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
+      double fsum = 0.0;
+      for (int part = 0; part < n_parts; ++part) {
+        const PartDev& pd = parts[part];
+        const double* xi = Xp + i * P + pd.poff;
+        const double* xj = Xp + j * P + pd.poff;
+        double dot = 0.0;
+        for (int qq = 0; qq < pd.kc; ++qq) dot = fma(xi[qq], xj[qq], dot);
+        double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
+        dsq = dsq < 0.0 ? 0.0 : dsq;
+        const double kv = kern_eval(pd, dsq, f.ec);
+        if (!cand.multi) res = kv;
+        else if (!cand.product) res = res + kv;
+        else combine_nested(pd, kv, res, fsum);
+      }
+      if (cand.multi && !cand.product) res = cand.outer * res;
+      if (i == j) res += cand.noise;                 // gp_core.py:843
+      Km[(long)i * ld + j] = res;
+    }
+    // the matrix and the labels are out: every wave drains its stores, then all of them may read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    cdiag = a.par[c];
+    mean = a.par[a.count + c];
+  }
   double* Rw = R + 16 * w * PBP;
   double* Tt = tbuf0 + w * (16 * 17);
   for (int j = 0; j < nbt; ++j) {
@@ -453,7 +543,10 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
     __syncthreads();
     const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];
     if (s_bad >= 0 || s_ring_timeout) {                // (uniform) not positive definite as it stands: the host takes the ladder
-      if (tid == 0) a.info[c] = 64ll * j + (s_bad >= 0 ? s_bad : 0) + 1;
+      if (tid == 0) {
+        if constexpr (FUSED) tiny_publish(f.out4 + 4 * (long)c, f.direct != 0, NAN, NAN, (double)(64ll * j + (s_bad >= 0 ? s_bad : 0) + 1), 1.0);
+        else a.info[c] = 64ll * j + (s_bad >= 0 ? s_bad : 0) + 1;
+      }
       return;
     }
     {
@@ -503,10 +596,18 @@ __global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) {
   if (lane == 0) { s_red[w] = ldv; s_red[4 + w] = dt; }
   __syncthreads();
   if (tid == 0) {
-    a.out2[2 * c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    a.out2[2 * c + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    if constexpr (FUSED) {
+      tiny_publish(f.out4 + 4 * (long)c, f.direct != 0, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]),
+                   (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]), 0.0, 1.0);
+    } else {
+      a.out2[2 * c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      a.out2[2 * c + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    }
   }
 }
+
+__global__ __launch_bounds__(256, 1) void lml_wg_kernel(LmlWgArgs a) { lml_wg_body<false>(a, LmlFuse()); }
+__global__ __launch_bounds__(256, 1) void lml_wgf_kernel(LmlWgArgs a, LmlFuse f) { lml_wg_body<true>(a, f); }
 
 // The same objective with a TEAM of T workgroups per candidate (few candidates: one workgroup each would leave
 // most of the device idle and take 3 ms at n = 1000).  Tile row i belongs to member i mod T; in block column j
@@ -2264,9 +2365,189 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
 // Right-looking block substitution: once x_i is final it is pushed into every remaining row
 // (wide, short GEMVs -> thousands of independent rows per launch instead of one long dependent
 // chain).  The pass is HBM-bound: the lower triangle of L is read once per solve.
+// ---------------------------------------------------------------------------------------------
+// The two substitutions of GP.build_posterior (gp_core.py:161-163) on the 512-block inverses, round 6.
+// A step of either direction is a chain of two dependent launches -- the block's solve by its explicit inverse, then the
+// block's contribution to everything it feeds -- and the old steps spent their time INSIDE their kernels (trace of round
+// 5: one workgroup per row of 4 KB in the forward update, 15 us; a partial + reduce pair of 16 + 6 us per transposed
+// product; a device-to-device copy per step because the block's solve ran in place).  Here: r is updated in place, the
+// solution goes to a vector of its own (no copy), and each kernel is shaped for its operand:
+//   k_trsv_blk_fwd   z_b = M_b r_b             one wave per row of the lower-triangular inverse, columns <= row only
+//   k_trsv_upd_fwd   r_i -= L[i, b] z_b        eight rows per wave, z_b in registers, 32 KB of loads in flight per wave
+//   k_trsv_blk_bwd   a_b = M_b^T r_b           64 columns per workgroup, rows dealt to the four waves, one LDS reduce
+//   k_trsv_upd_bwd   r_j -= L[b, j]^T a_b      64 columns per workgroup, a_b in LDS, sixteen row loads in flight per wave
+// Sums run in a fixed order (deterministic); a block that needs refinement steps takes the general route below.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsv_blk_fwd(const double* __restrict__ M, int w, const double* __restrict__ r,
+                                                      double* __restrict__ z) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= w) return;
+  const double2_t* a = reinterpret_cast<const double2_t*>(M + (long)row * CHOL_NB);
+  const double2_t* x = reinterpret_cast<const double2_t*>(r);
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = lane; 2 * j <= row; j += 64) {          // (the inverse is exactly zero above its diagonal)
+    const double2_t av = a[j], xv = x[j];
+    s0 = fma(av.x, xv.x, s0);
+    s1 = fma(av.y, (2 * j + 1 < w) ? xv.y : 0.0, s1);
+  }
+  double sum = s0 + s1;
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) z[row] = sum;
+}
+
+constexpr int TRSV_RPW = 8;                            // rows per wave of the forward update
+__global__ __launch_bounds__(256) void k_trsv_upd_fwd(const double* __restrict__ Lp, long ldl, long rows,
+                                                      const double* __restrict__ z, double* __restrict__ r) {
+  // Lp: the panel below the block (rows x 512, stride ldl); z: the block's solution (512); r: the rows' residuals
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * 4 + wv) * TRSV_RPW;
+  if (row0 >= rows) return;
+  double2_t zv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) zv[k] = reinterpret_cast<const double2_t*>(z)[lane + 64 * k];
+  double2_t av[TRSV_RPW][4];
+#pragma unroll
+  for (int q = 0; q < TRSV_RPW; ++q) {
+    const long row = row0 + q < rows ? row0 + q : rows - 1;     // (clamped: unconditional loads, results of the extra rows dropped)
+    const double2_t* a = reinterpret_cast<const double2_t*>(Lp + row * ldl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) av[q][k] = a[lane + 64 * k];
+  }
+  double sum[TRSV_RPW];
+#pragma unroll
+  for (int q = 0; q < TRSV_RPW; ++q) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0 = fma(av[q][k].x, zv[k].x, s0); s1 = fma(av[q][k].y, zv[k].y, s1); }
+    sum[q] = s0 + s1;
+  }
+#pragma unroll
+  for (int q = 0; q < TRSV_RPW; ++q)
+    for (int off = 32; off > 0; off >>= 1) sum[q] += __shfl_down(sum[q], off, 64);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < TRSV_RPW; ++q)
+      if (row0 + q < rows) r[row0 + q] -= sum[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_trsv_blk_bwd(const double* __restrict__ M, int w, const double* __restrict__ r,
+                                                      double* __restrict__ out) {
+  __shared__ double s_r[CHOL_NB];
+  __shared__ double s_p[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  for (int i = threadIdx.x; i < CHOL_NB; i += 256) s_r[i] = i < w ? r[i] : 0.0;
+  __syncthreads();
+  // out[col] = sum_{i >= col} M[i][col] r[i]: the inverse is exactly zero above its diagonal, so the rows start at
+  // the workgroup's first column; row i goes to wave i mod 4
+  const int cc = col < w ? col : w - 1;
+  double s0 = 0.0, s1 = 0.0;
+  int i = blockIdx.x * 64 + wv;
+  for (; i + 28 < w; i += 32) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = M[(long)(i + 4 * u) * CHOL_NB + cc];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 = fma(v[u], s_r[i + 4 * u], s0); s1 = fma(v[u + 1], s_r[i + 4 * u + 4], s1); }
+  }
+  for (; i < w; i += 4) s0 = fma(M[(long)i * CHOL_NB + cc], s_r[i], s0);
+  s_p[wv][lane] = s0 + s1;
+  __syncthreads();
+  if (wv == 0 && col < w) out[col] = (s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void k_trsv_upd_bwd(const double* __restrict__ Lr, long ldl, int w, long cols,
+                                                      const double* __restrict__ a, double* __restrict__ r) {
+  // Lr: the block row (w x cols, stride ldl); a: the block's solution (w); r: the residuals of the columns before it
+  __shared__ double s_a[CHOL_NB];
+  __shared__ double s_p[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + lane;
+  for (int i = threadIdx.x; i < CHOL_NB; i += 256) s_a[i] = i < w ? a[i] : 0.0;
+  __syncthreads();
+  const long cc = col < cols ? col : cols - 1;
+  const double* p = Lr + cc;
+  double s0 = 0.0, s1 = 0.0;
+  int i = wv;
+  for (; i + 60 < w; i += 64) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(long)(i + 4 * u) * ldl];
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) { s0 = fma(v[u], s_a[i + 4 * u], s0); s1 = fma(v[u + 1], s_a[i + 4 * u + 4], s1); }
+  }
+  for (; i < w; i += 4) s0 = fma(p[(long)i * ldl], s_a[i], s0);
+  s_p[wv][lane] = s0 + s1;
+  __syncthreads();
+  if (wv == 0 && col < cols) r[col] -= (s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]);
+}
+
+static bool trsv_fast_applies(const double* L, int64_t n, int64_t ldl, const double* inv, const double* x, const int* refine) {
+  static const int on = env_int("DFH_TRSV_FAST", 1);
+  if (!on || (ldl & 1) || ((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(inv) | reinterpret_cast<uintptr_t>(x)) & 15)) return false;
+  for (int64_t b = 0; refine && b < (n + CHOL_NB - 1) / CHOL_NB; ++b)
+    if (refine[b] > 0) return false;
+  return true;
+}
+
+// z = L^-1 r (r is used up) -- the forward half
+static int trsv_fast_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv, double* r, double* z) {
+  const int64_t NB = CHOL_NB;
+  for (int64_t c0 = 0; c0 < n; c0 += NB) {
+    const int64_t w = std::min<int64_t>(NB, n - c0), below = n - c0 - w;
+    hipLaunchKernelGGL(k_trsv_blk_fwd, dim3((unsigned)((w + 3) / 4)), dim3(256), 0, ctx->stream, inv + (c0 / NB) * NB * NB,
+                       (int)w, r + c0, z + c0);
+    DFH_LAUNCH_CHECK();
+    if (below > 0) {
+      hipLaunchKernelGGL(k_trsv_upd_fwd, dim3((unsigned)((below + 4 * TRSV_RPW - 1) / (4 * TRSV_RPW))), dim3(256), 0, ctx->stream,
+                         L + (c0 + w) * ldl + c0, (long)ldl, (long)below, z + c0, r + c0 + w);
+      DFH_LAUNCH_CHECK();
+    }
+  }
+  return DFH_OK;
+}
+
+// a = L^-T r (r is used up) -- the backward half
+static int trsv_fast_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv, double* r, double* a) {
+  const int64_t NB = CHOL_NB, nblk = (n + NB - 1) / NB;
+  for (int64_t b = nblk - 1; b >= 0; --b) {
+    const int64_t c0 = b * NB, w = std::min<int64_t>(NB, n - c0);
+    hipLaunchKernelGGL(k_trsv_blk_bwd, dim3((unsigned)((w + 63) / 64)), dim3(256), 0, ctx->stream, inv + b * NB * NB, (int)w,
+                       r + c0, a + c0);
+    DFH_LAUNCH_CHECK();
+    if (c0 > 0) {
+      hipLaunchKernelGGL(k_trsv_upd_bwd, dim3((unsigned)((c0 + 63) / 64)), dim3(256), 0, ctx->stream, L + c0 * ldl, (long)ldl,
+                         (int)w, (long)c0, a + c0, r);
+      DFH_LAUNCH_CHECK();
+    }
+  }
+  return DFH_OK;
+}
+
+// x <- L^-T L^-1 x  (gp_core.py:161-163): the forward half leaves z in a scratch vector, the backward half reads it
+// there and writes alpha to x -- no copy in between
+int trsv_both(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv, double* x, const int* refine) {
+  if (!trsv_fast_applies(L, n, ldl, inv, x, refine)) {
+    DFH_TRY(trsv_forward(ctx, L, n, ldl, inv, x, refine));
+    return trsv_backward(ctx, L, n, ldl, inv, x, refine);
+  }
+  double* z = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)std::max<int64_t>(2 * CHOL_NB, n) * 8, (void**)&z));
+  DFH_TRY(trsv_fast_forward(ctx, L, n, ldl, inv, x, z));
+  return trsv_fast_backward(ctx, L, n, ldl, inv, z, x);
+}
+
 int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
                  double* x, const int* refine) {
   const int64_t NB = CHOL_NB;
+  if (trsv_fast_applies(L, n, ldl, inv, x, refine)) {
+    double* z = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)std::max<int64_t>(2 * NB, n) * 8, (void**)&z));
+    DFH_TRY(trsv_fast_forward(ctx, L, n, ldl, inv, x, z));
+    DFH_HIP(hipMemcpyAsync(x, z, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return DFH_OK;
+  }
   const int64_t nblk = (n + NB - 1) / NB;
   const double* diag = inv + nblk * NB * NB;
   double* tmp = nullptr;
@@ -2295,6 +2576,13 @@ int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const do
 int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
                   double* x, const int* refine) {
   const int64_t NB = CHOL_NB;
+  if (trsv_fast_applies(L, n, ldl, inv, x, refine)) {
+    double* a = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_VEC3, (size_t)std::max<int64_t>(2 * NB, n) * 8, (void**)&a));
+    DFH_TRY(trsv_fast_backward(ctx, L, n, ldl, inv, x, a));
+    DFH_HIP(hipMemcpyAsync(x, a, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return DFH_OK;
+  }
   const int64_t nblk = (n + NB - 1) / NB;
   const double* diag = inv + nblk * NB * NB;
   double* tmp = nullptr;
@@ -2496,6 +2784,54 @@ int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int
 #endif
   hipLaunchKernelGGL(lml_team_kernel, dim3((unsigned)(count * team)), dim3(256), LMLT_SMEM, ctx->stream, a);
   DFH_LAUNCH_CHECK();
+  return DFH_OK;
+}
+
+bool lml_wg_fused_applies(const KernDev* kds, int count, int64_t n) {
+  static const int fused_max = env_int("DFH_LML_FUSED", 16);       // candidates per call; 0: off
+  if (count < 1 || count > fused_max || n < 1 || n > LMLF_MAX_N) return false;
+  for (int c = 0; c < count; ++c)
+    if (kds[c].P > TINY_MAX_P || kds[c].n_parts > TINY_MAX_PARTS || kds[c].P < 1 || !kds[c].stationary ||
+        n * (int64_t)(kds[c].P + kds[c].n_parts) > LMLF_LDS_DOUBLES) return false;
+  return true;
+}
+
+int lml_wg_fused_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
+                       const double* y_host, const double* noise_vars, const double* mean_consts,
+                       double* logdet_dot, long long* info) {
+  DFH_ARG(ctx && kds && dX && y_host && noise_vars && logdet_dot && info && lml_wg_fused_applies(kds, count, n));
+  const int64_t nbt = (n + 1 + PB - 1) / PB, NP = PB * nbt, sK = NP * NP;
+  static bool attr_set_dev[DFH_MAX_DEVICES] = {false};
+  if (!attr_set_dev[ctx->device]) {
+    DFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lml_wgf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DIAG_STEP_SMEM));
+    attr_set_dev[ctx->device] = true;
+  }
+  TinyBlob tb;
+  DFH_TRY(tiny_blob_build(ctx, kds, count, n, y_host, noise_vars, mean_consts, &tb));
+  double *Kb = nullptr, *ybuf = nullptr;
+  DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)count * sK * 8, (void**)&Kb));
+  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)std::max<int64_t>(256, n * 8), (void**)&ybuf));
+  LmlWgArgs a;
+  a.K = Kb; a.sK = (long)sK; a.ld = (long)NP; a.n = (int)n; a.nbt = (int)nbt;
+  a.y = ybuf; a.par = nullptr; a.count = count; a.out2 = nullptr; a.info = nullptr;
+  a.T = 1; a.sync = nullptr; a.linvbuf = nullptr; a.status = nullptr; a.spin_limit = 0;
+  LmlFuse f;
+  f.ec = kExpConsts;
+  f.X = dX; f.ldx = (long)ldx;
+  f.blob = tb.host; f.y_off = (long)tb.y_off;
+  f.ybuf = ybuf; f.out4 = tb.res; f.direct = 1;
+  volatile double* vres = tb.res;
+  for (int c = 0; c < count; ++c) vres[4 * c + 3] = -1.0;          // "not there yet"
+  hipLaunchKernelGGL(lml_wgf_kernel, dim3((unsigned)count), dim3(256), DIAG_STEP_SMEM, ctx->stream, a, f);
+  DFH_LAUNCH_CHECK();
+  DFH_TRY(tiny_poll_results(ctx, vres, count, "lml_wgf_kernel"));
+  for (int c = 0; c < count; ++c) {
+    logdet_dot[2 * c] = vres[4 * c];
+    logdet_dot[2 * c + 1] = vres[4 * c + 1];
+    info[c] = (long long)vres[4 * c + 2];
+    if (info[c] == 0 && (!std::isfinite(logdet_dot[2 * c]) || !std::isfinite(logdet_dot[2 * c + 1]))) info[c] = -2;
+  }
   return DFH_OK;
 }
 

@@ -264,8 +264,28 @@ int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, siz
 // One-launch tuning objective for small problems (kernmat.hip: k_lml_tiny): applies when
 // n <= TINY_MAX_N and every candidate's packed width / part count fits the LDS budget.
 constexpr int64_t TINY_MAX_N = 128;
+constexpr int64_t TINY64_MAX_N = 63;      // k_lml_tiny64: the system (n + 1 rows) is one 64 x 64 tile
 constexpr int TINY_MAX_P = 64, TINY_MAX_PARTS = 16;
 bool lml_tiny_applies(const KernDev* kds, int count, int64_t n);
+// The blob of a small-problem tuning call in the context's pinned (mapped, coherent) buffer:
+// TinyCand[count] | kernel images | y[n] | 10^-11 .. 10^4 | (64-byte aligned) results [count][4]
+struct TinyBlob {
+  char* host = nullptr; size_t bytes = 0, y_off = 0, pow_off = 0;
+  double* res = nullptr;
+  int Pmax = 1, parts_max = 1;
+};
+int tiny_blob_build(dfh_ctx* ctx, const KernDev* kds, int count, int64_t n, const double* y_host,
+                    const double* noise_vars, const double* mean_consts, TinyBlob* tb);
+int tiny_poll_results(dfh_ctx* ctx, volatile double* vres, int count, const char* what);
+// TINY64_MAX_N < n <= LMLF_MAX_N, a handful of candidates: Gram matrix, factorisation and forward solve of each candidate in ONE
+// launch by one workgroup (chol.hip: lml_wgf_kernel), descriptors and results through the pinned buffer.
+// info[c]: 0 = logdet_dot[2c], [2c+1] are valid; otherwise the candidate is for the lock-step schedule (a failed pivot:
+// the ladder; no noise: nothing bounds the augmented pivot).
+constexpr int64_t LMLF_MAX_N = 191;     // (three tile rows; beyond, the Gram matrix by one workgroup costs more than the launches it saves: 181 against 190 us at n = 200)
+bool lml_wg_fused_applies(const KernDev* kds, int count, int64_t n);
+int lml_wg_fused_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
+                       const double* y_host, const double* noise_vars, const double* mean_consts,
+                       double* logdet_dot, long long* info);
 int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
                    const double* y_host, const double* noise_vars, const double* mean_consts,
                    bool allow_jitter, double* logdet_dot, int32_t* powers);
@@ -338,6 +358,7 @@ int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x
 // refine (host, one entry per diagonal block, or null): refinement steps per block, see above
+int trsv_both(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv, double* x, const int* refine);
 int trsv_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,
                  double* x, const int* refine = nullptr);
 int trsv_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* inv,

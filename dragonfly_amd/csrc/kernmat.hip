@@ -29,19 +29,7 @@ constexpr int KM_BM = 128;
 constexpr int KM_KC = 32;          // packed columns per LDS chunk
 constexpr int KM_KP = 34;          // LDS row stride (doubles); 34 = 2 mod 32 -> conflict-free b64 frag reads
 
-// exp_fast's constants travel as kernel arguments (scalar loads into SGPR pairs, unknown to the
-// compiler): with literal coefficients the compiler emits v_fmac_f64 and re-materialises every
-// 64-bit constant with two v_mov_b32 per Horner step -- 18 extra VALU instructions per element,
-// over a third of the VALU-bound epilogue.
-struct ExpConsts {
-  double log2e, ln2_hi, ln2_lo;
-  double c[12];
-};
-static const ExpConsts kExpConsts = {
-    1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
-    {0x1.af631d0059becp-26, 0x1.28b4057f44145p-22, 0x1.71ddf5749d126p-19, 0x1.a01991ac8730ap-16,
-     0x1.a01a01b14378fp-13, 0x1.6c16c187fbe02p-10, 0x1.111111110f225p-7, 0x1.555555554f0cfp-5,
-     0x1.555555555555ap-3, 0x1.0000000000011p-1, 1.0, 1.0}};
+#include "kerneval.h"   // ExpConsts, exp_fast, kern_eval, combine_nested, np_sumsq, TinyCand
 
 struct KmArgs {
   ExpConsts ec;
@@ -70,102 +58,6 @@ struct KmArgs {
   int mu_nblk;
 };
 constexpr int KM_MU_BLOCK = 512;
-
-__device__ __forceinline__ double ipow(double m, int k) {
-  double r = 1.0;                      // 0**0 == 1 as in numpy (kernel.py:266)
-  for (int i = 0; i < k; ++i) r *= m;
-  return r;
-}
-
-// exp(x) for the arguments a stationary kernel produces (x <= 0; also fine for moderate x > 0):
-// x = n ln2 + r, |r| <= ln2/2, degree-11 polynomial (Chebyshev-node interpolant of exp on that
-// interval: 4e-18 approximation error, ~0.7 ulp after Horner in fp64), scaled by v_ldexp_f64.
-// 17 fp64 VALU ops -- the epilogue of the kernel-matrix build is VALU-bound, so this is the lever.
-__device__ __forceinline__ double exp_fast(double x, const ExpConsts& ec) {
-  const double n = rint(x * ec.log2e);
-  double r = fma(-n, ec.ln2_hi, x);
-  r = fma(-n, ec.ln2_lo, r);
-  double p = ec.c[0];
-#pragma unroll
-  for (int i = 1; i < 12; ++i) p = fma(p, r, ec.c[i]);
-  // |x| beyond the double exponent range: n saturates, ldexp returns 0 / inf; NaN propagates
-  return ldexp(p, (int)fmax(fmin(n, 4000.0), -4000.0));
-}
-
-// exp(x) for x <= 0 without the exponent clamp of exp_fast: v_cvt_i32_f64 saturates, and v_ldexp_f64
-// with a hugely negative exponent returns 0 (what exp of such an x rounds to); NaN propagates
-__device__ __forceinline__ double exp_fast_neg(double x, const ExpConsts& ec) {
-  const double n = rint(x * ec.log2e);
-  double r = fma(-n, ec.ln2_hi, x);
-  r = fma(-n, ec.ln2_lo, r);
-  double p = ec.c[0];
-#pragma unroll
-  for (int i = 1; i < 12; ++i) p = fma(p, r, ec.c[i]);
-  return ldexp(p, (int)n);
-}
-
-__device__ __forceinline__ double sqrt_fast(double d) {
-  // rsq + two Goldschmidt steps: <= 1 ulp on the range a clipped squared distance has; sqrt(0) = 0
-  const double y = __builtin_amdgcn_rsq(d);
-  double g = d * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  return d > 0.0 ? g : d;               // d == 0 -> 0 ; NaN -> NaN
-}
-
-__device__ __forceinline__ double kern_eval(const PartDev& pd, double dsq, const ExpConsts& ec) {
-  if (pd.kind == DFH_KERNEL_SE) {
-    return pd.scale_c * exp_fast(-dsq / 2, ec);                // kernel.py:176
-  } else if (pd.kind == DFH_KERNEL_MATERN) {
-    const double dist = sqrt_fast(dsq);                    // kernel.py:296 (<= 1 ulp)
-    const double mult = pd.s8 * dist;                      // kernel.py:265
-    double u;                                              // sum_i coeff_i mult^(p-i), kernel.py:266 (Horner)
-    if (pd.p == 0) u = pd.coeff[0];
-    else if (pd.p == 1) u = fma(pd.coeff[0], mult, pd.coeff[1]);
-    else if (pd.p == 2) u = fma(fma(pd.coeff[0], mult, pd.coeff[1]), mult, pd.coeff[2]);
-    else {
-      u = 0.0;
-      for (int i = 0; i <= pd.p; ++i) u += pd.coeff[i] * ipow(mult, pd.p - i);
-    }
-    u *= (pd.gfac * exp_fast_neg(-pd.s2 * dist, ec));      // kernel.py:268-269
-    return pd.scale_c * u;                                 // kernel.py:298
-  }
-  return dsq;                                              // DFH_KERNEL_DIST
-}
-
-// x ** order as NumPy evaluates it for a scalar integer exponent: its fast paths for 0, 1 and 2
-// (ones, copy, square), libm pow otherwise.
-__device__ __forceinline__ double pow_order(double x, int order) {
-  if (order == 0) return 1.0;
-  if (order == 1) return x;
-  if (order == 2) return x * x;
-  return pow(x, (double)order);
-}
-
-// Polynomial kernel from the dot product of the scaled points (kernel.py:381-386)
-__device__ __forceinline__ double poly_eval(const PartDev& pd, double dot) {
-  return pd.scale_c * pow_order(dot + 1.0, pd.p);
-}
-
-// Exponential-decay kernel from the two (unscaled) points (kernel.py:418-432): the product runs
-// over the dimensions in order, starting from the scale, and the offset is added last.
-__device__ __forceinline__ double expdecay_eval(const PartDev& pd, const double* x, const double* y) {
-  double r = pd.scale_c;
-  for (int c = 0; c < pd.p; ++c) r *= 1.0 / pow(1.0 + (x[c] + y[c]), pd.coeff[c]);
-  return r + pd.gfac;
-}
-
-// One part's value into the running result of a product kernel whose factors may be sums of parts
-// (PartDev::fmode): a plain factor multiplies; inside an additive factor the parts are added up from
-// zero (np.zeros + k_1 + k_2 ..., kernel.py:490-493) and the scaled sum multiplies at its last part.
-__device__ __forceinline__ void combine_nested(const PartDev& pd, double kv, double& res, double& fsum) {
-  if (pd.fmode == 0) { res = res * kv; return; }
-  fsum = (pd.fmode & FM_BEGIN) ? 0.0 + kv : fsum + kv;
-  if (pd.fmode & FM_END) res = res * (pd.fscale * fsum);
-}
-
 // NS: the parts may be polynomial / exponential-decay kernels (an instance of its own: their pow()
 // calls cost the stationary multi-part kernel its registers).  NESTED (with NS): a product kernel
 // with additive factors.
@@ -919,22 +811,6 @@ __global__ void k_pack_cols(const double* __restrict__ X, long n, long ldx, int 
   }
 }
 
-// (X**2).sum(axis=1) with numpy's pairwise-sum order for rows of <= 128 elements
-__device__ double np_sumsq(const double* a, int n) {
-  if (n < 8) {
-    double res = 0.0;
-    for (int i = 0; i < n; ++i) res += a[i] * a[i];
-    return res;
-  }
-  double r[8];
-  for (int j = 0; j < 8; ++j) r[j] = a[j] * a[j];
-  int i = 8;
-  for (; i < n - (n % 8); i += 8)
-    for (int j = 0; j < 8; ++j) r[j] += a[i + j] * a[i + j];
-  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-  for (; i < n; ++i) res += a[i] * a[i];
-  return res;
-}
 
 __global__ void k_pack_norms(const double* __restrict__ Xp, long n, int P, int n_parts_total,
                              const PartDev* __restrict__ parts, const int* __restrict__ cols,
@@ -1125,11 +1001,6 @@ void add_part_cols(KernDev* kd, PartDev& pd, const int* cols, const double* bw, 
 // launch per stage a call costs ~0.3 ms of launches and synchronisations, far more than the
 // arithmetic of a 50 x 50 Cholesky.
 // ---------------------------------------------------------------------------------------
-struct TinyCand {
-  long image;              // byte offset of the kernel image (blob_layout) in the blob
-  int P, n_parts, multi, product;
-  double outer, noise, mean;
-};
 struct TinyArgs {
   ExpConsts ec;
   const double* X; long ldx;       // [n x d] raw inputs (device)
@@ -1142,20 +1013,6 @@ struct TinyArgs {
 #endif
   double* out;                     // [count][4] = {sum log L_ii, |L^-1 (y - m)|^2, jitter power or -100, status}
 };
-
-// Results of a candidate.  direct: `out` is pinned host memory and the host is polling out[3] -- the three values go out
-// as system-scope (write-through) stores, are drained, and only then the status word follows.
-__device__ __forceinline__ void tiny_publish(double* out, bool direct, double v0, double v1, double v2, double status) {
-  if (direct) {
-    __hip_atomic_store(out + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(out + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(out + 2, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(out + 3, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  } else {
-    out[0] = v0; out[1] = v1; out[2] = v2; out[3] = status;
-  }
-}
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, j <= i
 
@@ -1430,7 +1287,6 @@ __device__ __forceinline__ int tiny64_factor(double (&a)[16], int lane, int w, c
 #else
 #define TSTAMP(a, e) do {} while (0)
 #endif
-constexpr int TINY64_MAX_N = 63;
 constexpr size_t TINY64_FIXED_LDS = sizeof(double) * (PB * SPP_STAGE + PB * PB + 3 * PB * 17);
 
 __global__ __launch_bounds__(256, 1) void k_lml_tiny64(TinyArgs a) {
@@ -1585,9 +1441,8 @@ bool lml_tiny_applies(const KernDev* kds, int count, int64_t n) {
 // logdet_dot[2c], [2c+1] = sum(log(diag(L_c))), (y - m_c)^T (K_c + noise_c I)^-1 (y - m_c);
 // powers[c] = jitter power used (INT32_MIN: none).  Returns DFH_ERR_NOT_PD / DFH_ERR_JITTER as the
 // one-fit path would.
-int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
-                   const double* y_host, const double* noise_vars, const double* mean_consts,
-                   bool allow_jitter, double* logdet_dot, int32_t* powers) {
+int tiny_blob_build(dfh_ctx* ctx, const KernDev* kds, int count, int64_t n, const double* y_host,
+                    const double* noise_vars, const double* mean_consts, TinyBlob* tb) {
   std::vector<size_t> image_off((size_t)count);
   size_t at = ((sizeof(TinyCand) * (size_t)count) + 15) & ~size_t(15);
   int Pmax = 1, parts_max = 1;
@@ -1608,7 +1463,6 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   DFH_TRY(pinned_get(ctx, res_off + sizeof(double) * 4 * (size_t)count, &pinned));
   char* host_blob = static_cast<char*>(pinned);
   std::memset(host_blob, 0, at);
-  double* res = reinterpret_cast<double*>(host_blob + res_off);
   TinyCand* cands = reinterpret_cast<TinyCand*>(host_blob);
   for (int c = 0; c < count; ++c) {
     cands[c].image = (long)image_off[c];
@@ -1627,6 +1481,42 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
     return t;
   }();
   std::memcpy(pw, pow10_table.data(), sizeof(double) * 16);
+  tb->host = host_blob; tb->bytes = at; tb->y_off = y_off; tb->pow_off = pow_off;
+  tb->res = reinterpret_cast<double*>(host_blob + res_off);
+  tb->Pmax = Pmax; tb->parts_max = parts_max;
+  return DFH_OK;
+}
+
+// Host side of a direct call's results: the kernel's status words (res[4 c + 3], -1.0 before the launch) polled in the
+// pinned buffer; past the budget the stream is synchronised like any other call and a kernel that never wrote is an error.
+int tiny_poll_results(dfh_ctx* ctx, volatile double* vres, int count, const char* what) {
+  bool all_in = false;
+  const auto t_start = std::chrono::steady_clock::now();
+  for (long spin = 0; !all_in; ++spin) {
+    all_in = true;
+    for (int c = 0; c < count; ++c) all_in = all_in && vres[4 * c + 3] != -1.0;
+    if (all_in) break;
+    if ((spin & 1023) == 1023 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 0.25) break;
+  }
+  if (!all_in) {
+    DFH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < count; ++c)
+      if (vres[4 * c + 3] == -1.0) { dfh_set_error("%s: no result for candidate %d", what, c); return DFH_ERR_HIP; }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return DFH_OK;
+}
+
+int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
+                   const double* y_host, const double* noise_vars, const double* mean_consts,
+                   bool allow_jitter, double* logdet_dot, int32_t* powers) {
+  TinyBlob tb;
+  DFH_TRY(tiny_blob_build(ctx, kds, count, n, y_host, noise_vars, mean_consts, &tb));
+  char* host_blob = tb.host;
+  const size_t at = tb.bytes, y_off = tb.y_off, pow_off = tb.pow_off;
+  const int Pmax = tb.Pmax, parts_max = tb.parts_max;
+  double* res = tb.res;
   // A handful of candidates (a slice sampler's or a tree search's call: gp_core.py:551-574 under sampling/slice.py,
   // utils/doo.py) is latency, not work: the kernel reads the descriptors straight from the pinned buffer (mapped into
   // the device: a few hundred bytes over PCIe) and writes its four numbers per candidate straight back into it, status
@@ -1677,23 +1567,8 @@ int lml_tiny_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX
   }
   DFH_LAUNCH_CHECK();
   if (direct) {
-    // bounded poll (a kernel of this size runs tens of microseconds; a ladder over seventeen attempts a millisecond);
-    // past the budget the stream is synchronised like any other call and a kernel that never wrote is an error
-    bool all_in = false;
-    const auto t_start = std::chrono::steady_clock::now();
-    for (long spin = 0; !all_in; ++spin) {
-      all_in = true;
-      for (int c = 0; c < count; ++c) all_in = all_in && vres[4 * c + 3] != -1.0;
-      if (all_in) break;
-      if ((spin & 1023) == 1023 &&
-          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 0.25) break;
-    }
-    if (!all_in) {
-      DFH_HIP(hipStreamSynchronize(ctx->stream));
-      for (int c = 0; c < count; ++c)
-        if (vres[4 * c + 3] == -1.0) { dfh_set_error("k_lml_tiny: no result for candidate %d", c); return DFH_ERR_HIP; }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
+    // (a kernel of this size runs tens of microseconds; a ladder over seventeen attempts a millisecond)
+    DFH_TRY(tiny_poll_results(ctx, vres, count, "k_lml_tiny"));
   } else {
     DFH_HIP(hipMemcpyAsync(res, d_out, sizeof(double) * 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     DFH_HIP(hipStreamSynchronize(ctx->stream));

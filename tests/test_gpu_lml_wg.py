@@ -145,6 +145,10 @@ VARIANTS = {
   # one workgroup per candidate (counted in dfh_ctx_counters)
   'forced-handoff-timeout': ({'DFH_TEST_SPIN_LIMIT': '0'}, 1),
   'lock-step-schedule': ({'DFH_LML_WG': '0'}, 0),
+  # (round 6: groups of at most 16 candidates at 64 <= n <= 191 take lml_wgf_kernel by default -- tests/test_gpu_lml_fused.py;
+  #  without it those sizes are back on the teams / one workgroup per candidate)
+  'no-one-launch-small-groups': ({'DFH_LML_FUSED': '0'}, 0),
+  'no-one-launch-small-groups-no-teams': ({'DFH_LML_FUSED': '0', 'DFH_LML_TEAM': '0'}, 0),
 }
 
 
