@@ -2374,7 +2374,7 @@ int cholesky_device(dfh_ctx* ctx, double* A, int64_t n, int64_t lda, double* kee
 // solution goes to a vector of its own (no copy), and each kernel is shaped for its operand:
 //   k_trsv_blk_fwd   z_b = M_b r_b             one wave per row of the lower-triangular inverse, columns <= row only
 //   k_trsv_upd_fwd   r_i -= L[i, b] z_b        eight rows per wave, z_b in registers, 32 KB of loads in flight per wave
-//   k_trsv_blk_bwd   a_b = M_b^T r_b           64 columns per workgroup, rows dealt to the four waves, one LDS reduce
+//   k_trsv_blk_bwd   a_b = M_b^T r_b           64 columns per workgroup, rows dealt to sixteen waves, one LDS reduce
 //   k_trsv_upd_bwd   r_j -= L[b, j]^T a_b      64 columns per workgroup, a_b in LDS, sixteen row loads in flight per wave
 // Sums run in a fixed order (deterministic); a block that needs refinement steps takes the general route below.
 // ---------------------------------------------------------------------------------------------
@@ -2395,7 +2395,7 @@ __global__ __launch_bounds__(256) void k_trsv_blk_fwd(const double* __restrict__
   if (lane == 0) z[row] = sum;
 }
 
-constexpr int TRSV_RPW = 8;                            // rows per wave of the forward update
+template <int TRSV_RPW>                                // rows per wave of the forward update
 __global__ __launch_bounds__(256) void k_trsv_upd_fwd(const double* __restrict__ Lp, long ldl, long rows,
                                                       const double* __restrict__ z, double* __restrict__ r) {
   // Lp: the panel below the block (rows x 512, stride ldl); z: the block's solution (512); r: the rows' residuals
@@ -2431,56 +2431,70 @@ __global__ __launch_bounds__(256) void k_trsv_upd_fwd(const double* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void k_trsv_blk_bwd(const double* __restrict__ M, int w, const double* __restrict__ r,
-                                                      double* __restrict__ out) {
-  __shared__ double s_r[CHOL_NB];
-  __shared__ double s_p[4][64];
+// (the two transposed products walk DOWN 512 rows per column: with four waves a lane's chain of row loads is eight memory
+//  latencies long -- 9.4 us even for the smallest update; sixteen waves of 32 rows each make it two)
+constexpr int TRSV_BW = 16;                            // waves per workgroup of the backward kernels
+// CW columns per workgroup (64: a lane per column; 16: four row phases inside the wave as well, for the block's own solve
+// and the short updates -- eight workgroups of 256 KB each are bound by what ONE CU can pull from HBM, 8 us a launch)
+template <int CW>
+__device__ __forceinline__ void trsv_colsum(const double* __restrict__ p0, long ld, int row0, int w, const double* s_x,
+                                            double (*s_p)[64], double& out, bool& writer) {
+  // p0: column `cc` of the first row; rows row0 .. w - 1; lane (rp, c): row phase rp of 64 / CW, column c
+  constexpr int RP = 64 / CW, PH = TRSV_BW * RP;       // row phases: per wave, per workgroup
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
-  for (int i = threadIdx.x; i < CHOL_NB; i += 256) s_r[i] = i < w ? r[i] : 0.0;
-  __syncthreads();
-  // out[col] = sum_{i >= col} M[i][col] r[i]: the inverse is exactly zero above its diagonal, so the rows start at
-  // the workgroup's first column; row i goes to wave i mod 4
-  const int cc = col < w ? col : w - 1;
+  const int rp = lane / CW;
   double s0 = 0.0, s1 = 0.0;
-  int i = blockIdx.x * 64 + wv;
-  for (; i + 28 < w; i += 32) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = M[(long)(i + 4 * u) * CHOL_NB + cc];
-#pragma unroll
-    for (int u = 0; u < 8; u += 2) { s0 = fma(v[u], s_r[i + 4 * u], s0); s1 = fma(v[u + 1], s_r[i + 4 * u + 4], s1); }
-  }
-  for (; i < w; i += 4) s0 = fma(M[(long)i * CHOL_NB + cc], s_r[i], s0);
-  s_p[wv][lane] = s0 + s1;
-  __syncthreads();
-  if (wv == 0 && col < w) out[col] = (s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]);
-}
-
-__global__ __launch_bounds__(256) void k_trsv_upd_bwd(const double* __restrict__ Lr, long ldl, int w, long cols,
-                                                      const double* __restrict__ a, double* __restrict__ r) {
-  // Lr: the block row (w x cols, stride ldl); a: the block's solution (w); r: the residuals of the columns before it
-  __shared__ double s_a[CHOL_NB];
-  __shared__ double s_p[4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long col = (long)blockIdx.x * 64 + lane;
-  for (int i = threadIdx.x; i < CHOL_NB; i += 256) s_a[i] = i < w ? a[i] : 0.0;
-  __syncthreads();
-  const long cc = col < cols ? col : cols - 1;
-  const double* p = Lr + cc;
-  double s0 = 0.0, s1 = 0.0;
-  int i = wv;
-  for (; i + 60 < w; i += 64) {
+  int i = row0 + wv * RP + rp;
+  for (; i + 15 * PH < w; i += 16 * PH) {
     double v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = p[(long)(i + 4 * u) * ldl];
+    for (int u = 0; u < 16; ++u) v[u] = p0[(long)(i + PH * u) * ld];
 #pragma unroll
-    for (int u = 0; u < 16; u += 2) { s0 = fma(v[u], s_a[i + 4 * u], s0); s1 = fma(v[u + 1], s_a[i + 4 * u + 4], s1); }
+    for (int u = 0; u < 16; u += 2) { s0 = fma(v[u], s_x[i + PH * u], s0); s1 = fma(v[u + 1], s_x[i + PH * (u + 1)], s1); }
   }
-  for (; i < w; i += 4) s0 = fma(p[(long)i * ldl], s_a[i], s0);
+  for (; i < w; i += PH) s0 = fma(p0[(long)i * ld], s_x[i], s0);
   s_p[wv][lane] = s0 + s1;
   __syncthreads();
-  if (wv == 0 && col < cols) r[col] -= (s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]);
+  writer = threadIdx.x < CW;
+  double t = 0.0;
+  if (writer) {
+#pragma unroll
+    for (int q = 0; q < TRSV_BW; ++q)
+#pragma unroll
+      for (int h = 0; h < RP; ++h) t += s_p[q][h * CW + lane];
+  }
+  out = t;
+}
+
+template <int CW>
+__global__ __launch_bounds__(1024) void k_trsv_blk_bwd(const double* __restrict__ M, int w, const double* __restrict__ r,
+                                                       double* __restrict__ out) {
+  __shared__ double s_r[CHOL_NB];
+  __shared__ double s_p[TRSV_BW][64];
+  for (int i = threadIdx.x; i < CHOL_NB; i += 64 * TRSV_BW) s_r[i] = i < w ? r[i] : 0.0;
+  __syncthreads();
+  // out[col] = sum_{i >= col} M[i][col] r[i]: the inverse is exactly zero above its diagonal, so the rows start at
+  // the workgroup's first column
+  const int col = blockIdx.x * CW + (threadIdx.x & 63) % CW;
+  const int cc = col < w ? col : w - 1;
+  double t; bool writer;
+  trsv_colsum<CW>(M + cc, CHOL_NB, blockIdx.x * CW, w, s_r, s_p, t, writer);
+  if (writer && col < w) out[col] = t;
+}
+
+template <int CW>
+__global__ __launch_bounds__(1024) void k_trsv_upd_bwd(const double* __restrict__ Lr, long ldl, int w, long cols,
+                                                       const double* __restrict__ a, double* __restrict__ r) {
+  // Lr: the block row (w x cols, stride ldl); a: the block's solution (w); r: the residuals of the columns before it
+  __shared__ double s_a[CHOL_NB];
+  __shared__ double s_p[TRSV_BW][64];
+  for (int i = threadIdx.x; i < CHOL_NB; i += 64 * TRSV_BW) s_a[i] = i < w ? a[i] : 0.0;
+  __syncthreads();
+  const long col = (long)blockIdx.x * CW + (threadIdx.x & 63) % CW;
+  const long cc = col < cols ? col : cols - 1;
+  double t; bool writer;
+  trsv_colsum<CW>(Lr + cc, ldl, 0, w, s_a, s_p, t, writer);
+  if (writer && col < cols) r[col] -= t;
 }
 
 static bool trsv_fast_applies(const double* L, int64_t n, int64_t ldl, const double* inv, const double* x, const int* refine) {
@@ -2499,8 +2513,12 @@ static int trsv_fast_forward(dfh_ctx* ctx, const double* L, int64_t n, int64_t l
     hipLaunchKernelGGL(k_trsv_blk_fwd, dim3((unsigned)((w + 3) / 4)), dim3(256), 0, ctx->stream, inv + (c0 / NB) * NB * NB,
                        (int)w, r + c0, z + c0);
     DFH_LAUNCH_CHECK();
-    if (below > 0) {
-      hipLaunchKernelGGL(k_trsv_upd_fwd, dim3((unsigned)((below + 4 * TRSV_RPW - 1) / (4 * TRSV_RPW))), dim3(256), 0, ctx->stream,
+    if (below > 4 * NB) {
+      hipLaunchKernelGGL(k_trsv_upd_fwd<8>, dim3((unsigned)((below + 31) / 32)), dim3(256), 0, ctx->stream,
+                         L + (c0 + w) * ldl + c0, (long)ldl, (long)below, z + c0, r + c0 + w);
+      DFH_LAUNCH_CHECK();
+    } else if (below > 0) {                            // a short panel: two rows per wave, four times the workgroups
+      hipLaunchKernelGGL(k_trsv_upd_fwd<2>, dim3((unsigned)((below + 7) / 8)), dim3(256), 0, ctx->stream,
                          L + (c0 + w) * ldl + c0, (long)ldl, (long)below, z + c0, r + c0 + w);
       DFH_LAUNCH_CHECK();
     }
@@ -2513,12 +2531,16 @@ static int trsv_fast_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t 
   const int64_t NB = CHOL_NB, nblk = (n + NB - 1) / NB;
   for (int64_t b = nblk - 1; b >= 0; --b) {
     const int64_t c0 = b * NB, w = std::min<int64_t>(NB, n - c0);
-    hipLaunchKernelGGL(k_trsv_blk_bwd, dim3((unsigned)((w + 63) / 64)), dim3(256), 0, ctx->stream, inv + b * NB * NB, (int)w,
-                       r + c0, a + c0);
+    hipLaunchKernelGGL(k_trsv_blk_bwd<16>, dim3((unsigned)((w + 15) / 16)), dim3(64 * TRSV_BW), 0, ctx->stream, inv + b * NB * NB,
+                       (int)w, r + c0, a + c0);
     DFH_LAUNCH_CHECK();
-    if (c0 > 0) {
-      hipLaunchKernelGGL(k_trsv_upd_bwd, dim3((unsigned)((c0 + 63) / 64)), dim3(256), 0, ctx->stream, L + c0 * ldl, (long)ldl,
-                         (int)w, (long)c0, a + c0, r);
+    if (c0 > 0 && c0 < 8 * NB) {                       // fewer than 64 workgroups of 64 columns: 16 columns each
+      hipLaunchKernelGGL(k_trsv_upd_bwd<16>, dim3((unsigned)((c0 + 15) / 16)), dim3(64 * TRSV_BW), 0, ctx->stream, L + c0 * ldl,
+                         (long)ldl, (int)w, (long)c0, a + c0, r);
+      DFH_LAUNCH_CHECK();
+    } else if (c0 > 0) {
+      hipLaunchKernelGGL(k_trsv_upd_bwd<64>, dim3((unsigned)((c0 + 63) / 64)), dim3(64 * TRSV_BW), 0, ctx->stream, L + c0 * ldl,
+                         (long)ldl, (int)w, (long)c0, a + c0, r);
       DFH_LAUNCH_CHECK();
     }
   }

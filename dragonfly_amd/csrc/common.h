@@ -138,6 +138,7 @@ enum ScratchSlot {
   SCR_REFINE,       // residual of the refined row solves (trsm_rows*)
   SCR_CHOLKEEP,     // ... block inverses when the caller keeps none
   SCR_MUPART,       // cross matrix with the posterior mean fused in: per-block partial sums
+  SCR_RED2,         // two-stage log-determinant: per-workgroup partial sums
   SCR_COUNT
 };
 
