@@ -672,6 +672,11 @@ extern "C" int dfh_gp_fit(dfh_ctx* ctx, const dfh_kernel_desc* k, const double* 
     auto build_M = [&]() -> int {     // K + noise_var * I     (gp_core.py:843)
       SectionTimer t(ctx, DFH_T_KERNMAT);
       ctx->km_lower_only = lower_env && n >= 2048;
+      // test hook (tests/test_gpu_upper_triangle_unread.py): the buffer comes recycled from the pool, and with the
+      // lower-triangle-only build the tiles above the diagonal keep whatever it held -- correctness rests on no schedule
+      // of the factorisation or the solves ever reading them.  DFH_TEST_POISON_L=1 fills the buffer with NaN first.
+      if (const char* e = getenv("DFH_TEST_POISON_L"); e && atoi(e) != 0)
+        DFH_HIP(hipMemsetAsync(gp->L, 0xFF, (size_t)n * n * 8, ctx->stream));
       const int rc = kernmat_packed(ctx, kd, 0, kd.n_parts, true, gp->Xp, gp->Np, n, gp->Xp, gp->Np, n, true, noise_var, gp->L, n);
       ctx->km_lower_only = false;
       return rc;
@@ -1365,7 +1370,12 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
     DFH_HIP(hipMemcpyAsync(dpar, hpar.data(), (size_t)g * 24, hipMemcpyHostToDevice, ctx->stream));
     // a group that leaves most of the device idle gets a TEAM of workgroups per candidate (chol.hip: lml_team_kernel)
     int team = 1;
-    if (team_env != 0) {
+    // (a timed-out hand-off costs ~0.1 s of polling plus the rebuilt group, and a slice sampler calls a hundred thousand
+    //  times: after one, the context's next 32 groups take one workgroup per candidate -- a shared device does not pay
+    //  the stall on every call; advisor, round 5)
+    const bool team_cooling = ctx->lml_team_cooldown > 0;
+    if (team_cooling) --ctx->lml_team_cooldown;
+    if (team_env != 0 && !team_cooling) {
       const int cap = team_env > 0 ? team_env : 8;
       while (team * 2 <= cap && (int64_t)team * 2 * g <= ctx->n_cu && team * 2 <= nbt) team *= 2;
     }
@@ -1401,6 +1411,7 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
       // a hand-off between the members of a team timed out (the device is shared, or not all of them were
       // resident): the matrices are rebuilt and every candidate gets ONE workgroup, which waits for nobody
       ++ctx->chol_fallbacks;
+      ctx->lml_team_cooldown = 32;
       hstatus = 0;
       DFH_TRY(run_group(1));
     }

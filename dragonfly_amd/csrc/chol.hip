@@ -397,6 +397,25 @@ __device__ __forceinline__ void lmlwg_solve_store(const double4_t (&acc)[4], con
   COMPILER_BARRIER();                                // (the next tile's substitution overwrites Rw)
 }
 
+// The last diagonal tile of lml_wg_body, staged in Sp by the caller (ring flags zeroed, barrier passed): columns 0 .. klast
+// only, no inverses; leaves the factor image in Sp (perm16 columns).  Returns this wave's first bad column or -1.
+// NOT inlined, for lmlt_factor_tile's reason: next to factor64_waves in one body the register allocator put sixteen
+// registers of the pivot chain into scratch.  LDS pointers formed here, from the dynamic LDS base (lml_wg_body's layout).
+__device__ __attribute__((noinline)) int lmlwg_factor_last(int klast, int* ring_timeout) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* Sp = dsm;
+  double* ring = dsm + PB * SPP_STAGE + PB * PBP + PB;
+  double* tbuf0 = ring + PB * PB;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double av[16];
+  int bad = tiny64_factor(av, lane, w, Sp, tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17, ring, klast, ring_timeout);
+  bad = (bad > klast) ? -1 : bad;
+  const bool active = 16 * w <= klast;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) Sp[lane * SPP_STAGE + perm16(16 * w + q)] = active ? av[q] : 0.0;   // (columns nobody reads: defined values all the same)
+  return bad;
+}
+
 // FUSED (round 6): the workgroup first builds its candidate's Gram matrix itself -- descriptor, inputs and labels as
 // k_lml_tiny takes them (kernmat.hip; LmlFuse), scaled inputs in the LDS the factorisation uses later -- writes the n x n
 // lower triangle to Km, and publishes {sum log L_ii, z.z, failed pivot or 0, done} per candidate the way tiny_publish does:
@@ -474,30 +493,9 @@ __device__ __forceinline__ void lml_wg_body(const LmlWgArgs& a, const LmlFuse& f
       if (tid == 0) tiny_publish(f.out4 + 4 * (long)c, f.direct != 0, NAN, NAN, -1.0, 1.0);
       return;
     }
-    // the lower triangle as a rectangle: row p and row n - 1 - p together hold n + 1 entries
-    for (int idx = tid; idx < ((n + 1) >> 1) * (n + 1); idx += 256) {
-      const int p = idx / (n + 1), q = idx - p * (n + 1);
-      const int i = q <= p ? p : n - 1 - p, j = q <= p ? q : q - p - 1;
-      if (q > p && n - 1 - p == p) continue;         // (odd n: the middle row is its own partner)
-      double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
-      double fsum = 0.0;
-      for (int part = 0; part < n_parts; ++part) {
-        const PartDev& pd = parts[part];
-        const double* xi = Xp + i * P + pd.poff;
-        const double* xj = Xp + j * P + pd.poff;
-        double dot = 0.0;
-        for (int qq = 0; qq < pd.kc; ++qq) dot = fma(xi[qq], xj[qq], dot);
-        double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
-        dsq = dsq < 0.0 ? 0.0 : dsq;
-        const double kv = kern_eval(pd, dsq, f.ec);
-        if (!cand.multi) res = kv;
-        else if (!cand.product) res = res + kv;
-        else combine_nested(pd, kv, res, fsum);
-      }
-      if (cand.multi && !cand.product) res = cand.outer * res;
-      if (i == j) res += cand.noise;                 // gp_core.py:843
-      Km[(long)i * ld + j] = res;
-    }
+    // K + noise I, lower triangle (gp_core.py:843)
+    tiny_gram_lower(cand, parts, n_parts, Xp, P, Np, n, f.ec,
+                    [&](int i, int j, double v) { Km[(long)i * ld + j] = (i == j) ? v + cand.noise : v; });
     // the matrix and the labels are out: every wave drains its stores, then all of them may read
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -509,6 +507,11 @@ __device__ __forceinline__ void lml_wg_body(const LmlWgArgs& a, const LmlFuse& f
   double* Tt = tbuf0 + w * (16 * 17);
   for (int j = 0; j < nbt; ++j) {
     double4_t acc[2][4];
+    // (round 6) the LAST diagonal tile is read only as far as the last observation's column: sum log L_ii runs over the
+    // rows of K, and row n of the factor -- z -- is final in column k as soon as column k is.  Its factorisation stops
+    // there, and when the tile holds the augmented row alone (n a multiple of 64) the whole block column is not needed.
+    const int klast = (j == nbt - 1) ? n - 1 - 64 * j : 63;
+    if (klast < 0) break;
     // ---- tile rows j (the diagonal tile) and j + 1 ----
     const bool two = j + 1 < nbt;
 #pragma unroll
@@ -535,10 +538,15 @@ __device__ __forceinline__ void lml_wg_body(const LmlWgArgs& a, const LmlFuse& f
     {
       double av[16];
       double* tbuf = tbuf0 + (w > 0 ? (w - 1) : 0) * PB * 17;
-      const int bad = factor64_waves<false>(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout);
-      if (lane == 0) s_badv[w] = bad;
+      if (klast < 63) {
+        const int bad = lmlwg_factor_last(klast, &s_ring_timeout);
+        if (lane == 0) s_badv[w] = bad;
+      } else {
+        const int bad = factor64_waves<false>(av, lane, w, Sp, tbuf, ring, lbb, linv, rdiag, &s_ring_timeout);
+        if (lane == 0) s_badv[w] = bad;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Sp[lane * SPP_STAGE + perm16(16 * w + q)] = av[q];
+        for (int q = 0; q < 16; ++q) Sp[lane * SPP_STAGE + perm16(16 * w + q)] = av[q];
+      }
     }
     __syncthreads();
     const int s_bad = (s_badv[0] >= 0) ? s_badv[0] : (s_badv[1] >= 0) ? s_badv[1] : (s_badv[2] >= 0) ? s_badv[2] : s_badv[3];

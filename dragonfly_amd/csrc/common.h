@@ -65,6 +65,7 @@ struct dfh_ctx {
   // the time-out of ~1 s on every fit
   int64_t chol_fallbacks = 0;
   int chol_fallback_streak = 0, chol_cooldown = 0;
+  int lml_team_cooldown = 0;       // tuning batches that take one workgroup per candidate after a team's hand-off timed out
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
   std::vector<DevBuf> scratch;

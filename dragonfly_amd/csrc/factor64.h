@@ -332,6 +332,74 @@ __device__ __forceinline__ int factor64_waves(double (&a)[16], int lane, int w, 
   return bad;
 }
 
+// ---- the factorisation of the first klast + 1 columns only, without the 16 x 16 inverses (round 6) ----
+// (the tuning objective's last diagonal tile and the one-tile system of k_lml_tiny64: nothing reads the columns beyond the
+//  last observation's, and no tile below needs the inverses)
+template <int... KLs>
+__device__ __forceinline__ void f64_owner_block_upto(double (&a)[16], int lane, int w, double* ring, int& bad, int klast,
+                                                     std::integer_sequence<int, KLs...>) {
+  double mprev = 0.0;
+  ((16 * w + KLs <= klast ? f64_owner_step<KLs>(a, lane, w, ring, bad, mprev) : (void)0), ...);
+}
+
+// factor64_waves without the 16 x 16 inverses, columns 0 .. klast only.  a[]: this wave's sixteen columns of L, row per
+// lane (garbage in columns beyond klast).  Returns the first non-positive pivot column of the wave's block or -1.
+__device__ __forceinline__ int tiny64_factor(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
+                                             double* ring, int klast, int* ring_timeout) {
+  int bad = -1;
+  const bool active = 16 * w <= klast;                 // wave-uniform
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = stage[lane * SPP_STAGE + j];
+    __syncthreads();
+  } else {
+    double4_t acc[4];
+    const int kq = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = stage[(16 * t + kq + 4 * r) * SPP_STAGE + 16 * w + l15];
+    __syncthreads();
+    if (!active) return -1;
+    for (int kb = 0; kb < w; ++kb) f64_consume_block(acc, lane, w, kb, ring, ring_timeout);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tbuf[(16 * t + kq + 4 * r) * 17 + l15] = acc[t][r];
+    COMPILER_BARRIER();                                // same wave: LDS executes its operations in order
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = tbuf[lane * 17 + j];
+  }
+  f64_owner_block_upto(a, lane, w, ring, bad, klast, std::make_integer_sequence<int, 16>{});
+  // L[:,k] = u[:,k] * sqrt(1/d_k), sixteen independent chains stage by stage (as factor64_waves)
+  double x[16], y[16], h[16], e[16], sq[16];
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) { x[kl] = ring[(16 * w + kl) * PB]; x[kl] = (16 * w + kl <= klast) ? x[kl] : 1.0; }
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) { y[kl] = __builtin_amdgcn_rsq(x[kl]); h[kl] = 0.5 * x[kl]; }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-(h[kl] * y[kl]), y[kl], 0.5);
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) y[kl] = fma(y[kl], e[kl], y[kl]);
+  }
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) sq[kl] = x[kl] * y[kl];
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) sq[kl] = fma(fma(-sq[kl], sq[kl], x[kl]), 0.5 * y[kl], sq[kl]);
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-sq[kl], y[kl], 1.0);
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) y[kl] = fma(e[kl], y[kl], y[kl]);
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) {
+    const int k = 16 * w + kl;
+    a[kl] = (lane == k) ? y[kl] : ((lane > k) ? a[kl] * sq[kl] : 0.0);
+  }
+  return bad;
+}
+
 // sum over the four lanes of a quad, in every lane (DPP quad_perm, no LDS crossbar)
 __device__ __forceinline__ double quad_sum(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);

@@ -154,3 +154,77 @@ __device__ __forceinline__ void tiny_publish(double* out, bool direct, double v0
   }
 }
 
+// The lower triangle of a small Gram matrix K (the caller's store adds what belongs on the diagonal) from scaled inputs in LDS (Xp [n][P], Np [n][n_parts]), by the
+// 256 threads of a workgroup; store(i, j, value) for j <= i < n.  The triangle is walked as a rectangle: row p and row
+// n - 1 - p together hold n + 1 entries.  (k_lml_tiny64 and the fused tuning objective of chol.hip, round 6.)
+// A single SE part -- the commonest candidate -- takes four entries per thread at a time: such a workgroup runs one wave
+// per SIMD, nothing hides the latency of an entry's chain (index division -> LDS -> dot product -> twelve dependent FMAs
+// of the exponential, ~850 cycles), so four independent chains in flight are worth a factor of two to three.  The
+// arithmetic of an entry is the same in both paths, operation for operation.
+__device__ __forceinline__ void tri_rect_index(int idx, int n, int& i, int& j, bool& valid) {
+  const int p = idx / (n + 1), q = idx - p * (n + 1);
+  i = q <= p ? p : n - 1 - p;
+  j = q <= p ? q : q - p - 1;
+  valid = !(q > p && n - 1 - p == p);                  // (odd n: the middle row is its own partner)
+}
+
+template <typename Store>
+__device__ __forceinline__ void tiny_gram_lower(const TinyCand& cand, const PartDev* parts, int n_parts, const double* Xp, int P,
+                                                const double* Np, int n, const ExpConsts& ec, Store store) {
+  const int tid = threadIdx.x;
+  const int total = ((n + 1) >> 1) * (n + 1);
+  if (!cand.multi && n_parts == 1 && parts[0].kind == DFH_KERNEL_SE && parts[0].poff == 0) {     // (uniform)
+    const int kc = parts[0].kc;
+    const double scale_c = parts[0].scale_c;
+    for (int base = tid; base < total; base += 4 * 256) {
+      int i[4], j[4];
+      bool ok[4];
+      double dot[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + 256 * u;
+        tri_rect_index(idx < total ? idx : base, n, i[u], j[u], ok[u]);
+        ok[u] = ok[u] && idx < total;
+        dot[u] = 0.0;
+      }
+      for (int q = 0; q < kc; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dot[u] = fma(Xp[i[u] * P + q], Xp[j[u] * P + q], dot[u]);
+      }
+      double res[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double dsq = (Np[j[u]] + Np[i[u]]) - 2.0 * dot[u];                      // general_utils.py:66-68
+        dsq = dsq < 0.0 ? 0.0 : dsq;
+        res[u] = scale_c * exp_fast(-dsq / 2, ec);                            // kernel.py:176 (kern_eval's SE branch)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) store(i[u], j[u], res[u]);
+    }
+    return;
+  }
+  for (int idx = tid; idx < total; idx += 256) {
+    int i, j;
+    bool ok;
+    tri_rect_index(idx, n, i, j, ok);
+    if (!ok) continue;
+    double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
+    double fsum = 0.0;
+    for (int part = 0; part < n_parts; ++part) {
+      const PartDev& pd = parts[part];
+      const double* xi = Xp + i * P + pd.poff;
+      const double* xj = Xp + j * P + pd.poff;
+      double dot = 0.0;
+      for (int q = 0; q < pd.kc; ++q) dot = fma(xi[q], xj[q], dot);
+      double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
+      dsq = dsq < 0.0 ? 0.0 : dsq;
+      const double kv = kern_eval(pd, dsq, ec);
+      if (!cand.multi) res = kv;
+      else if (!cand.product) res = res + kv;
+      else combine_nested(pd, kv, res, fsum);
+    }
+    if (cand.multi && !cand.product) res = cand.outer * res;
+    store(i, j, res);
+  }
+}

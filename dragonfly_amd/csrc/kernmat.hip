@@ -1217,71 +1217,6 @@ __global__ __launch_bounds__(256) void k_lml_tiny(TinyArgs a) {
 // column k is, so the augmented row never has to be a pivot, and the waves whose sixteen columns lie beyond n - 1 sit
 // the factorisation out.  Everything else -- packing, Gram entries, the jitter ladder, the results -- is k_lml_tiny's.
 // ---------------------------------------------------------------------------------------
-template <int... KLs>
-__device__ __forceinline__ void f64_owner_block_upto(double (&a)[16], int lane, int w, double* ring, int& bad, int klast,
-                                                     std::integer_sequence<int, KLs...>) {
-  double mprev = 0.0;
-  ((16 * w + KLs <= klast ? f64_owner_step<KLs>(a, lane, w, ring, bad, mprev) : (void)0), ...);
-}
-
-// factor64_waves without the 16 x 16 inverses, columns 0 .. klast only.  a[]: this wave's sixteen columns of L, row per
-// lane (garbage in columns beyond klast).  Returns the first non-positive pivot column of the wave's block or -1.
-__device__ __forceinline__ int tiny64_factor(double (&a)[16], int lane, int w, const double* stage, double* tbuf,
-                                             double* ring, int klast, int* ring_timeout) {
-  int bad = -1;
-  const bool active = 16 * w <= klast;                 // wave-uniform
-  if (w == 0) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = stage[lane * SPP_STAGE + j];
-    __syncthreads();
-  } else {
-    double4_t acc[4];
-    const int kq = lane >> 4, l15 = lane & 15;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] = stage[(16 * t + kq + 4 * r) * SPP_STAGE + 16 * w + l15];
-    __syncthreads();
-    if (!active) return -1;
-    for (int kb = 0; kb < w; ++kb) f64_consume_block(acc, lane, w, kb, ring, ring_timeout);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tbuf[(16 * t + kq + 4 * r) * 17 + l15] = acc[t][r];
-    COMPILER_BARRIER();                                // same wave: LDS executes its operations in order
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = tbuf[lane * 17 + j];
-  }
-  f64_owner_block_upto(a, lane, w, ring, bad, klast, std::make_integer_sequence<int, 16>{});
-  // L[:,k] = u[:,k] * sqrt(1/d_k), sixteen independent chains stage by stage (as factor64_waves)
-  double x[16], y[16], h[16], e[16], sq[16];
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) { x[kl] = ring[(16 * w + kl) * PB]; x[kl] = (16 * w + kl <= klast) ? x[kl] : 1.0; }
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) { y[kl] = __builtin_amdgcn_rsq(x[kl]); h[kl] = 0.5 * x[kl]; }
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-#pragma unroll
-    for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-(h[kl] * y[kl]), y[kl], 0.5);
-#pragma unroll
-    for (int kl = 0; kl < 16; ++kl) y[kl] = fma(y[kl], e[kl], y[kl]);
-  }
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) sq[kl] = x[kl] * y[kl];
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) sq[kl] = fma(fma(-sq[kl], sq[kl], x[kl]), 0.5 * y[kl], sq[kl]);
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) e[kl] = fma(-sq[kl], y[kl], 1.0);
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) y[kl] = fma(e[kl], y[kl], y[kl]);
-#pragma unroll
-  for (int kl = 0; kl < 16; ++kl) {
-    const int k = 16 * w + kl;
-    a[kl] = (lane == k) ? y[kl] : ((lane > k) ? a[kl] * sq[kl] : 0.0);
-  }
-  return bad;
-}
-
 #ifdef DFH_DEBUG_HOOKS
 #define TSTAMP(a, e) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(long)blockIdx.x * 16 + (e)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -1357,35 +1292,14 @@ __global__ __launch_bounds__(256, 1) void k_lml_tiny64(TinyArgs a) {
       power = attempt - 12;                          // -11 ... 4 (general_utils.py:183-203)
       jitter = pow10[attempt - 1] * max_diag;
     }
-    // the lower triangle as a rectangle: row p and row n - 1 - p together hold n + 1 entries
-    for (int idx = tid; idx < ((n + 1) >> 1) * (n + 1); idx += 256) {
-      {
-        const int p = idx / (n + 1), q = idx - p * (n + 1);
-        const int i = q <= p ? p : n - 1 - p, j = q <= p ? q : q - p - 1;
-        if (q > p && n - 1 - p == p) continue;       // (odd n: the middle row is its own partner)
-        double res = cand.multi ? (cand.product ? cand.outer : 0.0) : 0.0;
-        double fsum = 0.0;
-        for (int part = 0; part < n_parts; ++part) {
-          const PartDev& pd = parts[part];
-          const double* xi = Xp + i * P + pd.poff;
-          const double* xj = Xp + j * P + pd.poff;
-          double dot = 0.0;
-          for (int q = 0; q < pd.kc; ++q) dot = fma(xi[q], xj[q], dot);
-          double dsq = (Np[j * n_parts + part] + Np[i * n_parts + part]) - 2.0 * dot;   // general_utils.py:66-68
-          dsq = dsq < 0.0 ? 0.0 : dsq;
-          const double kv = kern_eval(pd, dsq, a.ec);
-          if (!cand.multi) res = kv;
-          else if (!cand.product) res = res + kv;
-          else combine_nested(pd, kv, res, fsum);
-        }
-        if (cand.multi && !cand.product) res = cand.outer * res;
-        if (i == j) {
-          res += cand.noise;                         // gp_core.py:843
-          if (attempt > 0) res += jitter;            // M + diag_noise * np.eye(n)
-        }
-        stage[i * SPP_STAGE + j] = res;
+    // K + noise I (+ jitter I: M + diag_noise * np.eye(n), general_utils.py:190), lower triangle   (gp_core.py:843)
+    tiny_gram_lower(cand, parts, n_parts, Xp, P, Np, n, a.ec, [&](int i, int j, double v) {
+      if (i == j) {
+        v += cand.noise;                             // gp_core.py:843
+        if (attempt > 0) v += jitter;                // M + diag_noise * np.eye(n)
       }
-    }
+      stage[i * SPP_STAGE + j] = v;
+    });
     if (tid < PB) ring[tid * PB] = 0.0;              // row-0 entries double as the "published" flags
     if (tid == 0) s_ring_timeout = 0;
     __syncthreads();

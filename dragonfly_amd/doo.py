@@ -24,6 +24,7 @@ from argparse import Namespace
 
 import numpy as np
 
+from . import gaplog
 from .general_utils import map_to_bounds
 
 
@@ -201,6 +202,8 @@ class OptimisticTreeSearch(object):
     visited = {}              # box key -> leaf, in first-visit order
     while cost <= budget:
       leaf = heapq.heappop(heap)
+      if gaplog.ENABLED and heap:
+        gaplog.pair('doo_expand', leaf.bound, heap[0].bound)
       visited[leaf.key()] = leaf
       children, split_cost = self._split(leaf, rho, nu, heap)
       first = children[0]
@@ -219,6 +222,8 @@ class OptimisticTreeSearch(object):
         best, best_score = leaf, score
     if best is None:
       return 0, 0, 0, cost, 0
+    if gaplog.ENABLED:
+      gaplog.top2('doo_best', [leaf.value - self.C * (1.0 - leaf.fidel) for leaf in visited.values()])
     return best.value, best.fidel, (best.lo + best.hi) / 2, cost, best.height
 
   # -- PDOO ------------------------------------------------------------------------------------
@@ -233,6 +238,7 @@ class OptimisticTreeSearch(object):
       rho = (self.rho_max) ** (float(num_runs) / (num_runs - i))
       results.append(self.run_doo(budget, self.nu_max, rho))
     scores = [r[0] - self.C * (1 - r[1]) for r in results]
+    gaplog.top2('pdoo_run', scores)
     return results, int(np.argmax(scores))
 
 

@@ -20,6 +20,7 @@ from copy import copy
 
 import numpy as np
 
+from . import gaplog
 from .general_utils import map_to_bounds
 from .kernel import AdditiveKernel, _as_2d_array
 from .doo import pdoo_maximise_batched
@@ -176,9 +177,17 @@ def _fused_argmax(gp, acq, params, anc_data):
   Xh = _halluc_points(anc_data)
   if DEVICE_CANDIDATES:
     cands, mean = _device_candidates(gp, anc_data)
+    if gaplog.ENABLED:
+      _, idx, vals = gp.device_gp.acq_argmax(acq, cands, params=params, X_halluc=Xh, return_vals=True, **mean)
+      gaplog.top2('acq_argmax', vals)
+      return cands.row(idx)
     _, idx = gp.device_gp.acq_argmax(acq, cands, params=params, X_halluc=Xh, **mean)
     return cands.row(idx)
   cands = _candidates(anc_data)
+  if gaplog.ENABLED:
+    _, idx, vals = gp.device_gp.acq_argmax(acq, cands, params=params, mean_vals=gp.mean_func(cands), X_halluc=Xh, return_vals=True)
+    gaplog.top2('acq_argmax', vals)
+    return cands[idx]
   _, idx = gp.device_gp.acq_argmax(acq, cands, params=params, mean_vals=gp.mean_func(cands), X_halluc=Xh)
   return cands[idx]
 
@@ -250,6 +259,10 @@ def asy_ts(gp, anc_data):
     return cands.row(idx)
   cands = _candidates(anc_data)
   normals = np.random.normal(size=(len(cands), 1)).ravel()
+  if gaplog.ENABLED:
+    _, idx, samples, _ = gp.device_gp.thompson(cands, normals, block=len(cands), mean_vals=gp.mean_func(cands), return_samples=True)
+    gaplog.top2('thompson', samples)
+    return cands[idx]
   _, idx = gp.device_gp.thompson(cands, normals, block=len(cands), mean_vals=gp.mean_func(cands))
   return cands[idx]
 

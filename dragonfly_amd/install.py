@@ -55,6 +55,8 @@ import os
 
 import numpy as np
 
+from . import gaplog
+
 
 _saved = []     # (object, attribute name, original value)
 
@@ -331,7 +333,10 @@ def make_batched_fitter(ref_fitter_cls):
         specs, means, noises = decoded
         if getattr(self, '_X_dev', None) is None:
           self._X_dev = get_engine().to_device(_as_2d_array(self.X))
-        return get_engine().gp_lml_batch(specs, self._X_dev, self._labels_array(), means, noises)
+        lmls = get_engine().gp_lml_batch(specs, self._X_dev, self._labels_array(), means, noises)
+        if gaplog.ENABLED and len(lmls) >= 16:       # (a random-search batch: its arg-max is the fitter's choice)
+          gaplog.top2('hp_batch', lmls)
+        return lmls
       specs, means, noises = [], [], []
       probe = [np.zeros(self.dim)]
       # build_gp ends in `EuclideanGP(self.X, self.Y, kernel, mean_func, noise_var, build_posterior=False)`, a module

@@ -6,6 +6,7 @@ from argparse import Namespace
 import numpy as np
 
 from .doo import pdoo_maximise, pdoo_maximise_batched, pdoo_minimise    # pylint: disable=unused-import
+from . import gaplog
 from .general_utils import map_to_bounds
 
 
@@ -28,6 +29,7 @@ def random_maximise(obj, bounds, max_evals, return_history=False, vectorised=Tru
   """ Best of a random sample (oper_utils.py:70-80): np.argmax's rule -- the first maximum, a NaN
       beats everything -- picks the winner.  Returns (value, point, history or None). """
   pts, vals = random_sample(obj, bounds, max_evals, vectorised)
+  gaplog.top2('random_maximise', vals)
   best = vals.argmax()
   history = Namespace(query_vals=vals, query_points=pts) if return_history else None
   return vals[best], pts[best], history

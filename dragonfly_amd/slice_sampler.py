@@ -26,6 +26,8 @@ import ctypes
 import numpy as np
 import numpy.random as nr
 
+from . import gaplog
+
 
 class _GlobalStreamPosition(object):
   """ Un-reading the last few draws of the GLOBAL legacy stream without copying its 2.5 KB state.
@@ -94,11 +96,16 @@ class SpeculativeSlice(object):
     self.evaluated = 0        # densities evaluated in them
     self.consumed = 0         # densities the reference's loops would have asked for
     self._known = (None, None)
+    self._level = None        # the current slice's level y (for the margin log of dragonfly_amd.gaplog)
 
   def _logp(self, xs):
     self.batches += 1
     self.evaluated += len(xs)
-    return np.asarray(self.logp_batch(list(xs)), dtype=np.float64).ravel()
+    vals = np.asarray(self.logp_batch(list(xs)), dtype=np.float64).ravel()
+    if gaplog.ENABLED and self._level is not None:      # every value of a batch is compared with the slice's level
+      for v in vals:
+        gaplog.pair('slice_compare', self._level, v)
+    return vals
 
   def _step_out(self, y, ql, qr, w, need_l=True, need_r=True):
     """ slice.py:52-63: move each edge outwards by w until the density there is below the level. """
@@ -219,9 +226,11 @@ class SpeculativeSlice(object):
       lp0 = known_lp                  # the density of the point accepted in the previous update
       self.consumed += 1
     else:
+      self._level = None
       lp0 = self._logp([q0])[0]
       self.consumed += 1
     y = lp0 - nr.standard_exponential()
+    self._level = y
     ql = q0 - nr.uniform(0, w)
     qr = q0 + w
     if self.merge_first:

@@ -7,7 +7,8 @@ with dragonfly_amd.install() on the NumPy stand-in engine, checked that each run
 bit for bit, and recorded every call on the engine object (dragonfly/opt/gp_bandit.py:405-421, 490, 647-673 ->
 fitters, GPs, acquisitions -> Engine / FittedGP).  Here the same 34 990 calls go to libdfhip.so: fits and appends
 (lml within 1e-10, jitter powers equal), tuning batches, posterior mean / std / covariance, fused acquisition
-arg-maxes (values within 1e-10, indices equal), Thompson draws, additive-UCB groups.  This is the driver-visible half
+arg-maxes (values within 1e-10, indices equal -- or, round 6, the two candidates' values equal to 1e-12: a tie), Thompson
+draws, additive-UCB groups.  This is the driver-visible half
 of tests/test_gpu_install_end_to_end.py (which needs the checkout beside the GPU)."""
 import glob
 import os
@@ -29,4 +30,10 @@ def test_all_25_configurations_are_there():
 def test_reference_optimiser_calls_replayed_on_the_device(engine, path):
   calls, worst, meta = ET.replay(path, engine, tol=1e-10)
   assert calls == meta['events'] and meta['reference_points_equal']
-  print('%s: %d calls, largest relative difference %.1e' % (meta['name'], calls, worst))
+  # (round 6) an arg-max index may differ from the recorded one only on a TIE -- the live values at the two indices agree
+  # to 1e-12 (tests/engine_trace.py); such ties exist (symmetric tree-search cells: profiles/r06_argmax_gaps.json) but
+  # they are a handful of a trace's thousands of calls
+  ties = meta.get('ties', [])
+  assert len(ties) <= max(3, calls // 2000), ties
+  print('%s: %d calls, largest relative difference %.1e, arg-max ties resolved the other way %d %s'
+        % (meta['name'], calls, worst, len(ties), ['%.1e' % g for _, g in ties]))

@@ -306,3 +306,23 @@ def test_rccl_id_rendezvous_file_is_private_and_fresh(tmp_path, monkeypatch):
   os.chmod(str(d), 0o777)
   with pytest.raises(RuntimeError):
     parallel._rendezvous_path()                           # pylint: disable=protected-access
+
+
+def test_gaplog_margins(monkeypatch):
+  """ dragonfly_amd/gaplog.py (round 6): the relative margin of an arg-max / of a comparison, NaNs out of competition,
+      the summary's counts -- the instrument behind profiles/r06_argmax_gaps.json. """
+  from dragonfly_amd import gaplog
+  monkeypatch.setattr(gaplog, 'ENABLED', True)
+  gaplog.reset()
+  gaplog.top2('a', [1.0, 3.0, np.nan, 2.0, -np.inf])          # (3 - 2) / 3
+  gaplog.top2('a', [5.0, 5.0])                                # an exact tie
+  gaplog.top2('a', [7.0])                                     # nothing to compare with
+  gaplog.pair('b', -2.0, -2.0 * (1 + 1e-13))
+  gaplog.pair('b', np.nan, 1.0)
+  s = gaplog.summary()
+  assert s['a']['count'] == 2 and s['a']['min'] == 0.0 and s['a']['exact_ties'] == 1 and s['a']['below_1e-8'] == 1
+  assert s['b']['count'] == 1 and 0.5e-13 < s['b']['min'] < 2e-13 and s['b']['below_1e-12'] == 1 and s['b']['below_1e-10'] == 1
+  gaplog.reset()
+  monkeypatch.setattr(gaplog, 'ENABLED', False)
+  gaplog.top2('a', [1.0, 2.0])
+  assert gaplog.summary() == {}

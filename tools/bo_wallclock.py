@@ -77,4 +77,8 @@ out = {'mode': mode, 'evals': evals, 'seed': seed, 'wall_s': round(wall, 3), 'ma
        'calls': counts, 'points_head': [[float(v) for v in p] for p in np.array(history.query_points)[:3]],
        'points_checksum': float(np.sum(np.array(history.query_points) * np.arange(1, 7))),
        'cpu_count': os.cpu_count()}
+if mode == 'install':
+  from dragonfly_amd import gaplog
+  if gaplog.ENABLED:          # DFH_GAP_LOG set: the margins of this run's decisions (dragonfly_amd/gaplog.py)
+    out['argmax_gaps'] = gaplog.summary()
 print(json.dumps(out))
