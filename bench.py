@@ -71,7 +71,7 @@ def km_bytes_moved(n, d):
   return 8.0 * (n * n + 2 * n * d)
 
 
-PMC_TRAFFIC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+PMC_TRAFFIC_FILES = ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def rel(a, b):
