@@ -1308,29 +1308,43 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
   const int64_t by_mem = std::max<int64_t>(1, (int64_t)(group_gib * 1073741824.0 / ((double)sK * 8.0)));
   const int64_t by_cu = group_max > 0 ? group_max : std::max(1, ctx->n_cu);
   const int G = (int)std::min<int64_t>(std::min<int64_t>(nb, by_cu), by_mem);
+  // The labels stay resident between calls (round 6): a fitter asks thousands of times with the same y, and staging
+  // 16 KB of pageable memory per call -- copy, synchronise -- was a sixth of a small group's call.  Host labels are
+  // compared with the copy of the last call (memcmp: exact); device labels are used where they are.
   const double* dy = nullptr;
-  DFH_TRY(to_device(ctx, y, (size_t)n * 8, SCR_STAGE_B, &dy));
-  std::vector<double> y_host((size_t)n);
-  if (is_device_ptr(y)) {
+  double sum_y = 0.0, sum_y2 = 0.0;
+  if (!(flags & DFH_LML_Y_IS_HOST) && is_device_ptr(y)) {
+    dy = y;
+    std::vector<double> y_host((size_t)n);
     DFH_HIP(hipMemcpyAsync(y_host.data(), y, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     DFH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; ++i) { sum_y += y_host[(size_t)i]; sum_y2 = fma(y_host[(size_t)i], y_host[(size_t)i], sum_y2); }
   } else {
-    std::memcpy(y_host.data(), y, (size_t)n * 8);
+    double* ybuf = nullptr;
+    DFH_TRY(scratch_get(ctx, SCR_YCACHE, (size_t)std::max<int64_t>(2048, n) * 8, (void**)&ybuf));
+    if (ybuf != ctx->ycache_dev || ctx->ycache_host.size() != (size_t)n ||
+        std::memcmp(ctx->ycache_host.data(), y, (size_t)n * 8) != 0) {
+      ctx->ycache_host.assign(y, y + n);
+      DFH_HIP(hipMemcpyAsync(ybuf, ctx->ycache_host.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+      DFH_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->ycache_dev = ybuf;
+      double s1 = 0.0, s2 = 0.0;
+      for (int64_t i = 0; i < n; ++i) { s1 += y[i]; s2 = fma(y[i], y[i], s2); }
+      ctx->ycache_sum = s1; ctx->ycache_sum2 = s2;
+    }
+    dy = ybuf;
+    sum_y = ctx->ycache_sum; sum_y2 = ctx->ycache_sum2;
   }
-  double sum_y = 0.0, sum_y2 = 0.0;
-  for (int64_t i = 0; i < n; ++i) { sum_y += y_host[(size_t)i]; sum_y2 = fma(y_host[(size_t)i], y_host[(size_t)i], sum_y2); }
-  double *Kb = nullptr, *red = nullptr, *dpar = nullptr;
-  long long* dinfo = nullptr;
+  // One control block per group on the device -- results [2 g] | failed pivots [g] | status [1] | team flags -- zeroed by
+  // ONE memset and copied back by ONE copy into the pinned buffer; descriptors and {aug. diagonal, mean, noise} go up
+  // from the pinned buffer in ONE copy.  (Round 5: three pageable copies up, three memsets, three pageable copies
+  // back and three synchronisations per group -- 160 of a small group's 210 us, profiles/r06_small_calls.txt.)
+  double *Kb = nullptr, *ctl = nullptr;
   DFH_TRY(scratch_get(ctx, SCR_KCT, (size_t)G * sK * 8, (void**)&Kb));
-  DFH_TRY(scratch_get(ctx, SCR_OUT2, (size_t)std::max(256, G * 16), (void**)&red));
-  DFH_TRY(scratch_get(ctx, SCR_OUT, (size_t)std::max(256, G * 24), (void**)&dpar));   // {aug. diagonal, mean, noise} per candidate
-  DFH_TRY(scratch_get(ctx, SCR_VEC, (size_t)std::max(256, G * 8), (void**)&dinfo));
+  const size_t ctl_bytes = (size_t)(3 * G + 8) * 8 + (size_t)G * LMLT_SYNC_INTS_PER_CANDIDATE * sizeof(int);
+  DFH_TRY(scratch_get(ctx, SCR_LMLCTL, ctl_bytes, (void**)&ctl));
   std::vector<KernDev> kds((size_t)G);
-  std::vector<double> hred((size_t)G * 2), hpar((size_t)G * 3);
-  std::vector<long long> hinfo((size_t)G);
   std::vector<char> skip((size_t)G, 0);
-  unsigned long long hstatus = 0;
-  unsigned long long* d_status = reinterpret_cast<unsigned long long*>(ctx->d_info + CHOL_MAX_BATCH + 8);
   // DFH_LML_TEAM: 0 = never a team, N = teams of up to N workgroups (default: up to 8)
   static const int team_env = []() { const char* e = getenv("DFH_LML_TEAM"); return e ? atoi(e) : -1; }();
   std::vector<int> redo;                       // candidates for the lock-step schedule
@@ -1348,9 +1362,24 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
       uniform = uniform && !kds[c].multi && kds[c].n_parts == 1 && kds[c].P == kds[0].P &&
                 kerndev_blob_bytes(kds[c]) == kerndev_blob_bytes(kds[0]);
     }
+    // pinned: descriptors | {aug. diagonal, mean, noise} [3 g] | (64-byte aligned) what comes back [3 g + 1]
+    const size_t up_par = (blob_bytes + 15) & ~size_t(15), up_bytes = up_par + (size_t)g * 24;
+    const size_t back_off = (up_bytes + 63) & ~size_t(63), back_bytes = (size_t)(3 * g + 1) * 8;
+    void* pinned = nullptr;
+    DFH_TRY(pinned_get(ctx, back_off + back_bytes, &pinned));
+    char* hup = static_cast<char*>(pinned);
+    double* hpar = reinterpret_cast<double*>(hup + up_par);
+    const double* hred = reinterpret_cast<const double*>(hup + back_off);
+    const long long* hinfo = reinterpret_cast<const long long*>(hup + back_off) + 2 * g;
+    const unsigned long long* hstatus_p = reinterpret_cast<const unsigned long long*>(hup + back_off) + 3 * g;
     void* blob = nullptr;
-    DFH_TRY(scratch_get(ctx, SCR_AUG2, blob_bytes, &blob));
-    DFH_TRY(kerndev_upload_many(ctx, kds.data(), g, blob, blob_bytes));
+    DFH_TRY(scratch_get(ctx, SCR_AUG2, up_bytes, &blob));
+    DFH_TRY(kerndev_stage_many(kds.data(), g, hup, blob, blob_bytes));
+    double* dpar = reinterpret_cast<double*>(static_cast<char*>(blob) + up_par);
+    double* red = ctl;
+    long long* dinfo = reinterpret_cast<long long*>(ctl + 2 * g);
+    unsigned long long* d_status = reinterpret_cast<unsigned long long*>(ctl + 3 * g);
+    int* d_sync = reinterpret_cast<int*>(ctl + 3 * g + 1);
     double *Xpb = nullptr, *Npb = nullptr;
     DFH_TRY(scratch_get(ctx, SCR_XS, (size_t)g * n * Pmax * 8, (void**)&Xpb));
     DFH_TRY(scratch_get(ctx, SCR_XS2, (size_t)g * n * parts_max * 8, (void**)&Npb));
@@ -1367,7 +1396,7 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
       skip[c] = !(s2 > 0.0) || !std::isfinite(hpar[c]);
       if (skip[c]) hpar[c] = 1.0;
     }
-    DFH_HIP(hipMemcpyAsync(dpar, hpar.data(), (size_t)g * 24, hipMemcpyHostToDevice, ctx->stream));
+    DFH_HIP(hipMemcpyAsync(blob, hup, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     // a group that leaves most of the device idle gets a TEAM of workgroups per candidate (chol.hip: lml_team_kernel)
     int team = 1;
     // (a timed-out hand-off costs ~0.1 s of polling plus the rebuilt group, and a slice sampler calls a hundred thousand
@@ -1397,22 +1426,21 @@ static int lml_batch_wg(dfh_ctx* ctx, const dfh_kernel_desc* descs, int32_t nb, 
       }
       {
         SectionTimer t(ctx, DFH_T_CHOL);
-        DFH_TRY(lml_wg_batch(ctx, Kb, sK, NP, n, g, dy, dpar, red, dinfo, tm, d_status));
+        // failed pivots, status and the team's flags: one memset (the results in front of them are always written)
+        DFH_HIP(hipMemsetAsync(dinfo, 0, (size_t)(g + 1) * 8 + (tm > 1 ? (size_t)g * LMLT_SYNC_INTS_PER_CANDIDATE * sizeof(int) : 0),
+                               ctx->stream));
+        DFH_TRY(lml_wg_batch(ctx, Kb, sK, NP, n, g, dy, dpar, red, dinfo, tm, d_status, d_sync));
       }
-      DFH_HIP(hipMemcpyAsync(hred.data(), red, (size_t)g * 16, hipMemcpyDeviceToHost, ctx->stream));
-      DFH_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)g * 8, hipMemcpyDeviceToHost, ctx->stream));
-      if (tm > 1) DFH_HIP(hipMemcpyAsync(&hstatus, d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
+      DFH_HIP(hipMemcpyAsync(hup + back_off, ctl, back_bytes, hipMemcpyDeviceToHost, ctx->stream));
       DFH_HIP(hipStreamSynchronize(ctx->stream));
       return DFH_OK;
     };
-    hstatus = 0;
     DFH_TRY(run_group(team));
-    if (team > 1 && hstatus != 0) {
+    if (team > 1 && *hstatus_p != 0) {
       // a hand-off between the members of a team timed out (the device is shared, or not all of them were
       // resident): the matrices are rebuilt and every candidate gets ONE workgroup, which waits for nobody
       ++ctx->chol_fallbacks;
       ctx->lml_team_cooldown = 32;
-      hstatus = 0;
       DFH_TRY(run_group(1));
     }
     for (int c = 0; c < g; ++c) {
@@ -1439,8 +1467,8 @@ extern "C" int dfh_gp_lml_batch(dfh_ctx* ctx, const dfh_kernel_desc* descs, int3
   if (flags & DFH_LML_X_IS_DEVICE) dX = X;
   else DFH_TRY(to_device(ctx, X, (size_t)n * d * 8, SCR_STAGE_A, &dX));
   static const bool tiny_enabled = []() { const char* e = getenv("DFH_LML_TINY"); return e ? atoi(e) != 0 : true; }();
-  if (tiny_enabled && n > TINY64_MAX_N && n <= LMLF_MAX_N && nb <= 64) {
-    // a handful of mid-sized candidates (a slice sampler's call at 64 <= n <= 191): Gram matrix, factorisation and
+  if (tiny_enabled && n > TINY64_MAX_N && n <= 255 && nb <= 64) {
+    // a handful of mid-sized candidates (a slice sampler's call at 64 <= n <= 128): Gram matrix, factorisation and
     // forward solve of each in ONE launch by one workgroup, nothing copied (chol.hip: lml_wgf_kernel)
     std::vector<KernDev> all((size_t)nb);
     for (int c = 0; c < nb; ++c) DFH_TRY(kerndev_build_host(&descs[c], &all[c]));

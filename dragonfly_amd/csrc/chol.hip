@@ -419,7 +419,7 @@ __device__ __attribute__((noinline)) int lmlwg_factor_last(int klast, int* ring_
 // FUSED (round 6): the workgroup first builds its candidate's Gram matrix itself -- descriptor, inputs and labels as
 // k_lml_tiny takes them (kernmat.hip; LmlFuse), scaled inputs in the LDS the factorisation uses later -- writes the n x n
 // lower triangle to Km, and publishes {sum log L_ii, z.z, failed pivot or 0, done} per candidate the way tiny_publish does:
-// a small group of mid-sized candidates (a slice sampler's call at 64 <= n <= 191) is then ONE launch with no copy at all.
+// a small group of mid-sized candidates (a slice sampler's call at 64 <= n <= 128) is then ONE launch with no copy at all.
 struct LmlFuse {
   ExpConsts ec;
   const double* X; long ldx;       // [n x d] raw inputs (device)
@@ -2778,7 +2778,11 @@ int trsm_rows_backward(dfh_ctx* ctx, const double* L, int64_t n, int64_t ldl, co
 // (device, 8 bytes, or null when team == 1) is zeroed here and non-zero afterwards iff a hand-off wait expired:
 // the results of the launch are then void.
 int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int count, const double* d_y,
-                 const double* d_par, double* d_out2, long long* d_info, int team, unsigned long long* d_status) {
+                 const double* d_par, double* d_out2, long long* d_info, int team, unsigned long long* d_status,
+                 int* d_sync_zeroed) {
+  // d_sync_zeroed: the team's flags ([count][LMLT_SYNC_INTS]) in a block the caller has ALREADY zeroed together with
+  // d_info and d_status (one memset per group instead of three); null: allocated and zeroed here.
+  static_assert(LMLT_SYNC_INTS == LMLT_SYNC_INTS_PER_CANDIDATE, "common.h and chol.hip disagree on the flags per candidate");
   DFH_ARG(ctx && K && d_y && d_par && d_out2 && d_info && n >= 1 && n <= LMLWG_MAX_N && count >= 1 && team >= 1 &&
           team <= 32 && (team == 1 || d_status));
   const int64_t nbt = (n + 1 + PB - 1) / PB;
@@ -2792,7 +2796,7 @@ int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int
                                 LMLT_SMEM));
     attr_set = true;
   }
-  DFH_HIP(hipMemsetAsync(d_info, 0, (size_t)count * 8, ctx->stream));
+  if (!d_sync_zeroed) DFH_HIP(hipMemsetAsync(d_info, 0, (size_t)count * 8, ctx->stream));
   LmlWgArgs a;
   a.K = K; a.sK = (long)sK; a.ld = (long)ld; a.n = (int)n; a.nbt = (int)nbt;
   a.y = d_y; a.par = d_par; a.count = count; a.out2 = d_out2; a.info = d_info;
@@ -2802,10 +2806,14 @@ int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int
     DFH_LAUNCH_CHECK();
     return DFH_OK;
   }
-  DFH_TRY(scratch_get(ctx, SCR_CHOLSYNC, (size_t)count * LMLT_SYNC_INTS * sizeof(int), (void**)&a.sync));
   DFH_TRY(scratch_get(ctx, SCR_CHOLINV, (size_t)count * nbt * LMLT_LINV * 8, (void**)&a.linvbuf));
-  DFH_HIP(hipMemsetAsync(a.sync, 0, (size_t)count * LMLT_SYNC_INTS * sizeof(int), ctx->stream));
-  DFH_HIP(hipMemsetAsync(d_status, 0, 8, ctx->stream));
+  if (d_sync_zeroed) {
+    a.sync = d_sync_zeroed;
+  } else {
+    DFH_TRY(scratch_get(ctx, SCR_CHOLSYNC, (size_t)count * LMLT_SYNC_INTS * sizeof(int), (void**)&a.sync));
+    DFH_HIP(hipMemsetAsync(a.sync, 0, (size_t)count * LMLT_SYNC_INTS * sizeof(int), ctx->stream));
+    DFH_HIP(hipMemsetAsync(d_status, 0, 8, ctx->stream));
+  }
   // a legitimate wait lasts well under a millisecond; a poll is ~1 us: give up after ~0.1 s (DFH_TEST_SPIN_LIMIT=0: at once, the fallback's test)
   static const int spin_limit = env_int("DFH_TEST_SPIN_LIMIT", 1 << 17);
   a.spin_limit = spin_limit;
@@ -2819,7 +2827,8 @@ int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int
 
 bool lml_wg_fused_applies(const KernDev* kds, int count, int64_t n) {
   static const int fused_max = env_int("DFH_LML_FUSED", 16);       // candidates per call; 0: off
-  if (count < 1 || count > fused_max || n < 1 || n > LMLF_MAX_N) return false;
+  static const int max_n = std::min(255, env_int("DFH_LML_FUSED_MAX_N", (int)LMLF_MAX_N));
+  if (count < 1 || count > fused_max || n < 1 || n > max_n) return false;
   for (int c = 0; c < count; ++c)
     if (kds[c].P > TINY_MAX_P || kds[c].n_parts > TINY_MAX_PARTS || kds[c].P < 1 || !kds[c].stationary ||
         n * (int64_t)(kds[c].P + kds[c].n_parts) > LMLF_LDS_DOUBLES) return false;

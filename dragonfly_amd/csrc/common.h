@@ -65,6 +65,10 @@ struct dfh_ctx {
   // the time-out of ~1 s on every fit
   int64_t chol_fallbacks = 0;
   int chol_fallback_streak = 0, chol_cooldown = 0;
+  // labels of the last tuning call, resident (lml_batch_wg): host copy to compare with, device copy, sum y and sum y^2
+  std::vector<double> ycache_host;
+  const double* ycache_dev = nullptr;
+  double ycache_sum = 0.0, ycache_sum2 = 0.0;
   int lml_team_cooldown = 0;       // tuning batches that take one workgroup per candidate after a team's hand-off timed out
   hipEvent_t ev0 = nullptr, ev1 = nullptr;         // dfh_timer_begin / end
   // scratch pool: grow-only named slots reused across calls (no hipMalloc in hot loops)
@@ -140,6 +144,8 @@ enum ScratchSlot {
   SCR_CHOLKEEP,     // ... block inverses when the caller keeps none
   SCR_MUPART,       // cross matrix with the posterior mean fused in: per-block partial sums
   SCR_RED2,         // two-stage log-determinant: per-workgroup partial sums
+  SCR_YCACHE,       // labels of the last tuning call (kept across calls: a fitter asks thousands of times with the same y)
+  SCR_LMLCTL,       // tuning group: results | failed pivots | status | team flags, one block (one memset, one copy back)
   SCR_COUNT
 };
 
@@ -261,6 +267,7 @@ int kerndev_build(dfh_ctx* ctx, const dfh_kernel_desc* k, KernDev* out);
 // host-only part of kerndev_build, and the upload of several descriptors with one copy into a
 // caller-provided device blob (kerndev_blob_bytes each, in order); such KernDevs own no memory
 int kerndev_build_host(const dfh_kernel_desc* k, KernDev* out);
+int kerndev_stage_many(KernDev* kds, int count, char* host, void* d_blob, size_t blob_bytes);
 size_t kerndev_blob_bytes(const KernDev& kd);
 int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, size_t blob_bytes);
 // One-launch tuning objective for small problems (kernmat.hip: k_lml_tiny): applies when
@@ -283,7 +290,8 @@ int tiny_poll_results(dfh_ctx* ctx, volatile double* vres, int count, const char
 // launch by one workgroup (chol.hip: lml_wgf_kernel), descriptors and results through the pinned buffer.
 // info[c]: 0 = logdet_dot[2c], [2c+1] are valid; otherwise the candidate is for the lock-step schedule (a failed pivot:
 // the ladder; no noise: nothing bounds the augmented pivot).
-constexpr int64_t LMLF_MAX_N = 191;     // (three tile rows; beyond, the Gram matrix by one workgroup costs more than the launches it saves: 181 against 190 us at n = 200)
+constexpr int64_t LMLF_MAX_N = 128;     // (beyond, the team schedule -- one copy up, one memset, one copy back per group since round 6 -- is as fast: 101 us
+                                         //  at n = 129 .. 191 against the one workgroup's 105 .. 143; the kernel itself is tested up to n = 255 through DFH_LML_FUSED_MAX_N)
 bool lml_wg_fused_applies(const KernDev* kds, int count, int64_t n);
 int lml_wg_fused_batch(dfh_ctx* ctx, const KernDev* kds, int count, const double* dX, int64_t n, int64_t ldx,
                        const double* y_host, const double* noise_vars, const double* mean_consts,
@@ -355,7 +363,8 @@ constexpr int64_t LMLWG_MAX_N = 2047;
 // means a hand-off between them timed out and the launch's results are void (repeat with team = 1).
 int lml_wg_batch(dfh_ctx* ctx, double* K, int64_t sK, int64_t ld, int64_t n, int count, const double* d_y,
                  const double* d_par, double* d_out2, long long* d_info, int team = 1,
-                 unsigned long long* d_status = nullptr);
+                 unsigned long long* d_status = nullptr, int* d_sync_zeroed = nullptr);
+constexpr int LMLT_SYNC_INTS_PER_CANDIDATE = 64;     // (= chol.hip's LMLT_SYNC_INTS: flags of a team, per candidate)
 
 // alpha-solves with the factor and its diagonal-block inverses (in place on x[n]):
 //   forward : x <- L^{-1} x          backward : x <- L^{-T} x

@@ -1668,6 +1668,22 @@ size_t kerndev_blob_bytes(const KernDev& kd) {
   return total;
 }
 
+// The same without the copy: the images are laid out in `host` (the caller's pinned staging memory, copied up by the
+// caller together with whatever else the launch needs) and the descriptors pointed at where they WILL be on the device.
+int kerndev_stage_many(KernDev* kds, int count, char* host, void* d_blob, size_t blob_bytes) {
+  std::memset(host, 0, blob_bytes);
+  size_t at = 0;
+  for (int c = 0; c < count; ++c) {
+    const size_t sz = kerndev_blob_bytes(kds[c]);
+    DFH_ARG(at + sz <= blob_bytes);
+    blob_fill(kds[c], host + at);
+    kds[c].d_blob = nullptr;                    // not owned
+    blob_point(&kds[c], static_cast<char*>(d_blob) + at);
+    at += sz;
+  }
+  return DFH_OK;
+}
+
 int kerndev_upload_many(dfh_ctx* ctx, KernDev* kds, int count, void* d_blob, size_t blob_bytes) {
   std::vector<char> host(blob_bytes, 0);
   size_t at = 0;

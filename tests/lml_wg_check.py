@@ -15,7 +15,7 @@ from oracle import ref_numpy as O                          # noqa: E402
 eng = get_engine()
 worst = 0.0
 # (n <= 128 reaches the one-workgroup form only when the one-launch small-problem kernel is off or does not apply)
-for n, nb in ((1, 2), (45, 2), (64, 3), (127, 4), (130, 3), (257, 5), (448, 2), (641, 9), (1000, 4), (1000, 70), (1600, 3), (300, 300)):
+for n, nb in ((1, 2), (45, 2), (64, 3), (127, 4), (130, 3), (150, 2), (191, 3), (200, 1), (255, 4), (257, 5), (448, 2), (641, 9), (1000, 4), (1000, 70), (1600, 3), (300, 300)):
   rs = np.random.RandomState(7 * n + nb)
   d = 4
   X = rs.rand(n, d)

@@ -1,4 +1,4 @@
-"""MI355X: a handful of mid-sized candidates in ONE launch (csrc/chol.hip: lml_wgf_kernel, 64 <= n <= 191, at most 16
+"""MI355X: a handful of mid-sized candidates in ONE launch (csrc/chol.hip: lml_wgf_kernel, 64 <= n <= 128 by default, at most 16
 candidates per call -- the slice sampler's and the tree search's calls of GPFitter._tuning_objective,
 dragonfly/gp/gp_core.py:551-574 -> build_posterior :155-163 -> :222-227): the workgroup builds its candidate's Gram
 matrix itself (get_scaled_repr kernel.py:179-181, dist_squared general_utils.py:58-70, SE / Matern / additive /
@@ -39,7 +39,8 @@ def _specs(rs, d, nb, y_var):
   return specs, ospecs, means, noises
 
 
-# (n = 192, 255: one past the kernel's range -- the same call takes the team schedule)
+# (n > 128: past the kernel's default range -- the same call takes the team schedule; the kernel itself up to n = 255 is
+#  forced in tests/test_gpu_lml_wg.py::test_schedule_variant[one-launch-small-groups-up-to-255])
 @pytest.mark.parametrize('n', [64, 65, 100, 126, 127, 128, 129, 150, 190, 191, 192, 255])
 @pytest.mark.parametrize('nb', [1, 3, 16])
 def test_tile_edges_and_group_sizes(engine, n, nb):

@@ -145,9 +145,11 @@ VARIANTS = {
   # one workgroup per candidate (counted in dfh_ctx_counters)
   'forced-handoff-timeout': ({'DFH_TEST_SPIN_LIMIT': '0'}, 1),
   'lock-step-schedule': ({'DFH_LML_WG': '0'}, 0),
-  # (round 6: groups of at most 16 candidates at 64 <= n <= 191 take lml_wgf_kernel by default -- tests/test_gpu_lml_fused.py;
+  # (round 6: groups of at most 16 candidates at 64 <= n <= 128 take lml_wgf_kernel by default -- tests/test_gpu_lml_fused.py;
   #  without it those sizes are back on the teams / one workgroup per candidate)
   'no-one-launch-small-groups': ({'DFH_LML_FUSED': '0'}, 0),
+  # (the one-launch form stops at n = 128 by default -- beyond, the team schedule is as fast; the kernel itself goes to 255)
+  'one-launch-small-groups-up-to-255': ({'DFH_LML_FUSED_MAX_N': '255'}, 0),
   'no-one-launch-small-groups-no-teams': ({'DFH_LML_FUSED': '0', 'DFH_LML_TEAM': '0'}, 0),
 }
 
