@@ -15,7 +15,7 @@ from oracle import ref_numpy as O                          # noqa: E402
 eng = get_engine()
 worst = 0.0
 # (n <= 128 reaches the one-workgroup form only when the one-launch small-problem kernel is off or does not apply)
-for n, nb in ((1, 2), (45, 2), (64, 3), (127, 4), (130, 3), (150, 2), (191, 3), (200, 1), (255, 4), (257, 5), (448, 2), (641, 9), (1000, 4), (1000, 70), (1600, 3), (300, 300)):
+for n, nb in ((1, 2), (2, 1), (17, 1), (45, 2), (63, 5), (63, 20), (64, 3), (100, 17), (127, 4), (130, 3), (150, 2), (191, 3), (200, 1), (255, 4), (257, 5), (448, 2), (641, 9), (1000, 4), (1000, 70), (1600, 3), (300, 300)):
   rs = np.random.RandomState(7 * n + nb)
   d = 4
   X = rs.rand(n, d)
@@ -45,5 +45,18 @@ specs = [KernelSpec('se', d, 1.0, np.full(d, b)) for b in (0.3, 2.0, 0.5)]
 lml, powers = eng.gp_lml_batch(specs, X, Y, None, [1e-3, 1e-18, 1e-2], return_powers=True)
 og = O.GPOracle(X, Y, O.KernelSpec('se', d, 1.0, np.full(d, 2.0)), 0.0, 1e-18)
 assert powers[0] is None and powers[2] is None and powers[1] == og.jitter_power, powers
+# ... and inside the small-problem forms (one 64 x 64 tile; the one-launch small group): the reference's jitter power
+for n in (40, 100):
+  rs = np.random.RandomState(5 + n)
+  X = rs.rand(n, d); X[n // 2:] = X[:n // 2]
+  Y = np.cos(3 * X[:, 0]) + X[:, 1]
+  lml, powers = eng.gp_lml_batch(specs, X, Y, None, [1e-3, 1e-18, 1e-2], return_powers=True)
+  og = O.GPOracle(X, Y, O.KernelSpec('se', d, 1.0, np.full(d, 2.0)), 0.0, 1e-18)
+  assert powers[0] is None and powers[2] is None and powers[1] == og.jitter_power, (n, powers, og.jitter_power)
+  assert np.isfinite(lml[1])       # (a jittered, numerically singular system: the power is the contract; its value is held to computed bounds in tests/test_gpu_lml_wg.py)
+  for c, (b, s2) in enumerate(((0.3, 1e-3), (2.0, 1e-18), (0.5, 1e-2))):
+    if c != 1:
+      ref = O.GPOracle(X, Y, O.KernelSpec('se', d, 1.0, np.full(d, b)), 0.0, s2).lml()
+      assert abs(lml[c] - ref) <= 1e-10 * abs(ref), (n, c, lml[c], ref)
 print('worst %.2e fallbacks %d' % (worst, eng.counters()['chol_fallbacks']))
 print('OK')

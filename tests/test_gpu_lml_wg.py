@@ -150,6 +150,12 @@ VARIANTS = {
   'no-one-launch-small-groups': ({'DFH_LML_FUSED': '0'}, 0),
   # (the one-launch form stops at n = 128 by default -- beyond, the team schedule is as fast; the kernel itself goes to 255)
   'one-launch-small-groups-up-to-255': ({'DFH_LML_FUSED_MAX_N': '255'}, 0),
+  # (round 6, n <= 128: descriptors / results through the mapped pinned buffer or by copies; n <= 63 on the 64 x 64
+  #  factorisation or on k_lml_tiny's column loop)
+  'small-problems-by-copies': ({'DFH_LML_DIRECT': '0'}, 0),
+  'small-problems-old-kernel': ({'DFH_LML_TINY64': '0'}, 0),
+  'small-problems-old-kernel-by-copies': ({'DFH_LML_TINY64': '0', 'DFH_LML_DIRECT': '0', 'DFH_LML_FUSED': '0'}, 0),
+  'substitutions-general-route': ({'DFH_TRSV_FAST': '0'}, 0),
   'no-one-launch-small-groups-no-teams': ({'DFH_LML_FUSED': '0', 'DFH_LML_TEAM': '0'}, 0),
 }
 
