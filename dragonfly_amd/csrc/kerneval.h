@@ -157,7 +157,7 @@ __device__ __forceinline__ void tiny_publish(double* out, bool direct, double v0
 // The lower triangle of a small Gram matrix K (the caller's store adds what belongs on the diagonal) from scaled inputs in LDS (Xp [n][P], Np [n][n_parts]), by the
 // 256 threads of a workgroup; store(i, j, value) for j <= i < n.  The triangle is walked as a rectangle: row p and row
 // n - 1 - p together hold n + 1 entries.  (k_lml_tiny64 and the fused tuning objective of chol.hip, round 6.)
-// A single SE part -- the commonest candidate -- takes four entries per thread at a time: such a workgroup runs one wave
+// A single SE or Matern (nu <= 2.5) part -- the commonest candidates -- takes four entries per thread at a time: such a workgroup runs one wave
 // per SIMD, nothing hides the latency of an entry's chain (index division -> LDS -> dot product -> twelve dependent FMAs
 // of the exponential, ~850 cycles), so four independent chains in flight are worth a factor of two to three.  The
 // arithmetic of an entry is the same in both paths, operation for operation.
@@ -173,9 +173,14 @@ __device__ __forceinline__ void tiny_gram_lower(const TinyCand& cand, const Part
                                                 const double* Np, int n, const ExpConsts& ec, Store store) {
   const int tid = threadIdx.x;
   const int total = ((n + 1) >> 1) * (n + 1);
-  if (!cand.multi && n_parts == 1 && parts[0].kind == DFH_KERNEL_SE && parts[0].poff == 0) {     // (uniform)
-    const int kc = parts[0].kc;
-    const double scale_c = parts[0].scale_c;
+  // KIND 0: SE; 1 + p: Matern with nu = p + 1/2, p <= 2 (Dragonfly's default kernel is Matern-2.5)
+  const int fast_kind = (!cand.multi && n_parts == 1 && parts[0].poff == 0)
+                            ? (parts[0].kind == DFH_KERNEL_SE ? 0 : (parts[0].kind == DFH_KERNEL_MATERN && parts[0].p <= 2 ? 1 + parts[0].p : -1))
+                            : -1;
+  if (fast_kind >= 0) {                                // (uniform)
+    const PartDev pd = parts[0];
+    const int kc = pd.kc;
+    const double scale_c = pd.scale_c;
     for (int base = tid; base < total; base += 4 * 256) {
       int i[4], j[4];
       bool ok[4];
@@ -191,12 +196,35 @@ __device__ __forceinline__ void tiny_gram_lower(const TinyCand& cand, const Part
 #pragma unroll
         for (int u = 0; u < 4; ++u) dot[u] = fma(Xp[i[u] * P + q], Xp[j[u] * P + q], dot[u]);
       }
-      double res[4];
+      double res[4], dsq[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        double dsq = (Np[j[u]] + Np[i[u]]) - 2.0 * dot[u];                      // general_utils.py:66-68
-        dsq = dsq < 0.0 ? 0.0 : dsq;
-        res[u] = scale_c * exp_fast(-dsq / 2, ec);                            // kernel.py:176 (kern_eval's SE branch)
+        dsq[u] = (Np[j[u]] + Np[i[u]]) - 2.0 * dot[u];                        // general_utils.py:66-68
+        dsq[u] = dsq[u] < 0.0 ? 0.0 : dsq[u];
+      }
+      if (fast_kind == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) res[u] = scale_c * exp_fast(-dsq[u] / 2, ec);              // kernel.py:176 (kern_eval's SE branch)
+      } else {
+        // kern_eval's Matern branch, operation for operation, the branch on p taken once for the four entries
+        double dist[4], mult[4], uu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { dist[u] = sqrt_fast(dsq[u]); mult[u] = pd.s8 * dist[u]; }      // kernel.py:296, 265
+        if (fast_kind == 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) uu[u] = pd.coeff[0];
+        } else if (fast_kind == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) uu[u] = fma(pd.coeff[0], mult[u], pd.coeff[1]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) uu[u] = fma(fma(pd.coeff[0], mult[u], pd.coeff[1]), mult[u], pd.coeff[2]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          uu[u] *= (pd.gfac * exp_fast_neg(-pd.s2 * dist[u], ec));             // kernel.py:268-269
+          res[u] = scale_c * uu[u];                                           // kernel.py:298
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
