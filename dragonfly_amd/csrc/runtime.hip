@@ -160,7 +160,7 @@ int pinned_get(dfh_ctx* ctx, size_t bytes, void** out) {
     size_t cap = 1 << 16;
     while (cap < bytes) cap <<= 1;
     // mapped + coherent: kernels of the small-call paths read descriptors from it and write results into it directly
-    DFH_HIP(hipHostMalloc(&ctx->h_stage, cap, hipHostMallocMapped | hipHostMallocCoherent));
+    DFH_HIP(hipHostMalloc(&ctx->h_stage, cap, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
     void* dev_view = nullptr;
     DFH_HIP(hipHostGetDevicePointer(&dev_view, ctx->h_stage, 0));
     if (dev_view != ctx->h_stage) {        // (one address space on this platform; anything else is not supported here)
