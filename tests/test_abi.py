@@ -95,3 +95,15 @@ def test_array_addresses_go_to_void_pointer_parameters_only():
             assert len(arg.args) == 1 and isinstance(arg.args[0], ast.Name), \
                 '%s:%d %s argument %d: a temporary would be freed before the call' % (fn, node.lineno, node.func.attr, i)
   assert seen >= 60
+
+
+def test_flag_constants_of_the_binding_are_the_headers():
+  """ the bits a caller ORs into `flags` (fit modes, round 6: the pointer-kind hints of dfh_gp_lml_batch) have one
+      definition, the header's; the binding's copies must equal it """
+  text = open(HEADER).read()
+  defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r'^#define\s+(DFH_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\b', text, flags=re.M)}
+  assert defs['DFH_FIT_NO_JITTER'] == _lib.FIT_NO_JITTER
+  assert defs['DFH_FIT_PROJECT_FIRST'] == _lib.FIT_PROJECT_FIRST and defs['DFH_FIT_TRY_BEFORE_PROJECT'] == _lib.FIT_TRY_BEFORE_PROJECT
+  assert defs['DFH_LML_X_IS_DEVICE'] == _lib.LML_X_IS_DEVICE and defs['DFH_LML_Y_IS_HOST'] == _lib.LML_Y_IS_HOST
+  # the hint bits do not collide with the fit modes
+  assert (_lib.LML_X_IS_DEVICE | _lib.LML_Y_IS_HOST) & (_lib.FIT_NO_JITTER | _lib.FIT_PROJECT_FIRST | _lib.FIT_TRY_BEFORE_PROJECT) == 0
