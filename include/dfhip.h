@@ -233,7 +233,11 @@ int dfh_gp_append(dfh_gp* gp, const double* Xnew, int64_t q, const double* y_cen
  * the device).  Gram matrices of a group of candidates are factored in lock-step; a candidate that
  * needs the stable_cholesky ladder gets it individually (jitter_powers[c], INT32_MIN = none).
  * Errors as dfh_gp_fit (DFH_ERR_NOT_PD with DFH_FIT_NO_JITTER, DFH_ERR_JITTER when the ladder is
- * exhausted, utils/general_utils.py:200).                                                        */
+ * exhausted, utils/general_utils.py:200).
+ * A call with a handful of candidates -- what the slice sampler (sampling/slice.py:45-68) and the tree search
+ * (utils/doo.py:112-121) issue a hundred thousand times per run -- is ONE kernel launch up to n = 128 with nothing
+ * copied: descriptors are read from, and results written to, the context's mapped pinned buffer while the host polls
+ * a status word (bounded; the call is still synchronous: lml_out is valid on return).                           */
 /* Optional hints in `flags` of dfh_gp_lml_batch (a caller that knows where its buffers live saves the library one
  * pointer query each -- microseconds that matter when a slice sampler calls with one candidate at n = 50):          */
 #define DFH_LML_X_IS_DEVICE 0x100   /* X is device memory (a dfh_alloc buffer)                                   */
